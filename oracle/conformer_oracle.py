@@ -1,0 +1,305 @@
+"""CPU oracle for the Conformer encoder hot path.  TEST INFRASTRUCTURE ONLY.
+
+This file is a from-scratch, functional restatement (plain PyTorch CPU ops, any float
+dtype) of the arithmetic the reference performs on the hot path.  It is NOT part of the
+product: only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline``
+leg may import it, and only as the checker / the reported CPU baseline.  The product
+path (``conformer_amd``) never routes through it and fails loudly without its HIP library.
+
+Parity status: PINNED.  ``tests/golden/*.npz`` were produced by importing the reference's
+own ``model`` package in the build container (``tests/golden/make_golden.py``); every
+function here is checked against those vectors in ``tests/test_oracle_golden.py``.
+The log-mel / SpecAugment front end lives in torchaudio (absent here and in the
+reference tree) and is therefore "parity unpinned" -- see DESIGN.md.
+
+Each function cites the reference lines it follows (paths relative to /root/reference).
+Parameters are passed as a flat ``dict[str, Tensor]`` using the reference's state_dict
+keys, addressed with a key prefix.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+
+Params = Dict[str, torch.Tensor]
+
+LN_EPS = 1e-5   # nn.LayerNorm default, model/utils/ffn.py:8
+BN_EPS = 1e-5   # nn.BatchNorm1d default, model/utils/convolution.py:16
+BN_MOMENTUM = 0.1
+
+
+# --------------------------------------------------------------------------- primitives
+def layer_norm(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, eps: float = LN_EPS) -> torch.Tensor:
+    """nn.LayerNorm over the last dim (ffn.py:8,16; attention.py:10,15; convolution.py:12,22; block.py:15,27)."""
+    mu = x.mean(dim=-1, keepdim=True)
+    xc = x - mu
+    var = (xc * xc).mean(dim=-1, keepdim=True)
+    return xc / torch.sqrt(var + eps) * w + b
+
+
+def swish(x: torch.Tensor) -> torch.Tensor:
+    """activation.py:7-8."""
+    return x * torch.sigmoid(x)
+
+
+def subsampled_lengths(lengths: torch.Tensor) -> torch.Tensor:
+    """convolution.py:55."""
+    return ((lengths - 1) // 2 - 1) // 2
+
+
+def subsampled_frames(t: int) -> int:
+    return ((t - 1) // 2 - 1) // 2
+
+
+# --------------------------------------------------------------------------- FFN module
+def ffn_module(x: torch.Tensor, p: Params, pre: str) -> torch.Tensor:
+    """FeedForwardModule.forward, ffn.py:15-23 (dropout p=0)."""
+    h = layer_norm(x, p[pre + "layer_norm.weight"], p[pre + "layer_norm.bias"])
+    h = h @ p[pre + "hidden_linear.weight"].t() + p[pre + "hidden_linear.bias"]
+    h = swish(h)
+    return h @ p[pre + "out_linear.weight"].t() + p[pre + "out_linear.bias"]
+
+
+# --------------------------------------------------------------------------- rel-pos MHSA
+def relpos_table(t: int, div_term: torch.Tensor) -> torch.Tensor:
+    """RelativePositionalEncoding.forward without the batch repeat, position.py:11-27.
+
+    Row j (0 <= j <= 2t-2) encodes relative position r = t-1-j:
+    pe[j, 2c] = sin(r*w_c), pe[j, 2c+1] = cos(r*w_c).
+    ``div_term`` is the (1, d/2) parameter stored in the state_dict (position.py:9).
+    """
+    dt = div_term.reshape(-1)
+    r = torch.arange(t - 1, -t, -1, dtype=dt.dtype)
+    ang = r.abs()[:, None] * dt[None, :]           # the reference forms |r|*w then negates
+    sgn = torch.sign(r)[:, None]
+    pe = torch.empty(2 * t - 1, 2 * dt.numel(), dtype=dt.dtype)
+    pe[:, 0::2] = torch.sin(sgn * ang)
+    pe[:, 1::2] = torch.cos(sgn * ang)
+    return pe
+
+
+def relpos_attention_core(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, pp: torch.Tensor,
+                          u: torch.Tensor, vb: torch.Tensor, lengths: Optional[torch.Tensor]) -> torch.Tensor:
+    """scaled_dot_product_relative_attention + _relative_shift, attention.py:47-72,94-102.
+
+    q,k,v: (B,T,H,dh) projected; pp: (2T-1,H,dh) projected positions (row j <-> r=T-1-j);
+    u,vb: (H,dh) content/position biases.  Returns context (B,T,H*dh), heads h-major.
+    The shift is restated as an explicit gather: score_pos[i,k] = (q_i+v).p_{r=i-k}.
+    """
+    B, T, H, dh = q.shape
+    content = torch.einsum("bihc,bkhc->bhik", q + u, k)
+    full = torch.einsum("bihc,jhc->bhij", q + vb, pp)                   # (B,H,T,2T-1)
+    i = torch.arange(T)[:, None]
+    kk = torch.arange(T)[None, :]
+    j = (T - 1) - (i - kk)                                                # row of pp for r=i-k
+    pos = full.gather(-1, j.expand(B, H, T, T))
+    s = (content + pos) / math.sqrt(dh)
+    if lengths is not None:
+        pad = torch.arange(T)[None, :] >= lengths[:, None]                # True at padded keys
+        s = s.masked_fill(pad[:, None, None, :], torch.finfo(s.dtype).min)
+    a = torch.softmax(s, dim=-1)
+    ctx = torch.einsum("bhik,bkhc->bihc", a, v)
+    return ctx.reshape(B, T, H * dh)
+
+
+def mhsa_module(x: torch.Tensor, pe: torch.Tensor, lengths: Optional[torch.Tensor], p: Params, pre: str,
+                n_heads: int) -> torch.Tensor:
+    """MultiHeadSelfAttentionModule.forward, attention.py:14-18, 74-92 (dropout p=0).
+
+    ``pe`` is the un-repeated (2T-1, d) table.
+    """
+    B, T, d = x.shape
+    dh = d // n_heads
+    a = pre + "attention."
+    xn = layer_norm(x, p[pre + "layer_norm.weight"], p[pre + "layer_norm.bias"])
+    q = (xn @ p[a + "query_proj.weight"].t() + p[a + "query_proj.bias"]).view(B, T, n_heads, dh)
+    k = (xn @ p[a + "key_proj.weight"].t() + p[a + "key_proj.bias"]).view(B, T, n_heads, dh)
+    v = (xn @ p[a + "value_proj.weight"].t() + p[a + "value_proj.bias"]).view(B, T, n_heads, dh)
+    pp = (pe @ p[a + "pos_proj.weight"].t() + p[a + "pos_proj.bias"]).view(2 * T - 1, n_heads, dh)
+    ctx = relpos_attention_core(q, k, v, pp, p[a + "content_bias"], p[a + "position_bias"], lengths)
+    return ctx @ p[a + "out_proj.weight"].t() + p[a + "out_proj.bias"]
+
+
+# --------------------------------------------------------------------------- conv module
+def conv_module(x: torch.Tensor, p: Params, pre: str, training: bool = False,
+                bn_state: Optional[Dict[str, torch.Tensor]] = None) -> torch.Tensor:
+    """ConvolutionModule.forward, convolution.py:21-32 (dropout p=0).
+
+    Channel-last restatement: the pointwise convs are row GEMMs on (B,T,C).
+    eval: BatchNorm uses running stats; train: batch mean / biased variance over all
+    B*T positions (padded frames included) and, if ``bn_state`` is given,
+    the running-stat update (momentum 0.1, unbiased variance) is written into it.
+    """
+    B, T, C = x.shape
+    xn = layer_norm(x, p[pre + "layer_norm.weight"], p[pre + "layer_norm.bias"])
+    z = xn @ p[pre + "pointwise_conv_1.weight"][:, :, 0].t() + p[pre + "pointwise_conv_1.bias"]
+    g = z[..., :C] * torch.sigmoid(z[..., C:])                            # GLU(dim=1): value first, gate second
+    wdw = p[pre + "deepwise_conv.weight"][:, 0, :]                        # (C,K)
+    K = wdw.shape[1]
+    half = (K - 1) // 2
+    gp = F.pad(g, (0, 0, half, half))                                     # zero pad in time, per utterance
+    c = p[pre + "deepwise_conv.bias"].expand(B, T, C).clone()
+    for jtap in range(K):
+        c = c + gp[:, jtap:jtap + T, :] * wdw[:, jtap]
+    if training:
+        flat = c.reshape(-1, C)
+        mean = flat.mean(0)
+        var = ((flat - mean) ** 2).mean(0)
+        if bn_state is not None:
+            n = flat.shape[0]
+            bn_state["running_mean"] = (1 - BN_MOMENTUM) * p[pre + "batch_norm.running_mean"] + BN_MOMENTUM * mean
+            bn_state["running_var"] = (1 - BN_MOMENTUM) * p[pre + "batch_norm.running_var"] + BN_MOMENTUM * var * n / max(n - 1, 1)
+    else:
+        mean = p[pre + "batch_norm.running_mean"]
+        var = p[pre + "batch_norm.running_var"]
+    bn = (c - mean) / torch.sqrt(var + BN_EPS) * p[pre + "batch_norm.weight"] + p[pre + "batch_norm.bias"]
+    s = swish(bn)
+    return s @ p[pre + "pointwise_conv_2.weight"][:, :, 0].t() + p[pre + "pointwise_conv_2.bias"]
+
+
+# --------------------------------------------------------------------------- block / stem / encoder
+def conformer_block(x: torch.Tensor, pe: torch.Tensor, lengths: Optional[torch.Tensor], p: Params, pre: str,
+                    n_heads: int, training: bool = False) -> torch.Tensor:
+    """ConformerBlock.forward, block.py:17-29."""
+    y = 0.5 * ffn_module(x, p, pre + "ffn_1.") + x
+    y = mhsa_module(y, pe, lengths, p, pre + "attention.", n_heads) + y
+    y = conv_module(y, p, pre + "conv.", training) + y
+    y = 0.5 * ffn_module(y, p, pre + "ffn_2.") + y
+    return layer_norm(y, p[pre + "layer_norm.weight"], p[pre + "layer_norm.bias"])
+
+
+def conv_subsampling(x: torch.Tensor, p: Params, pre: str) -> torch.Tensor:
+    """ConvolutionSubsampling.forward, convolution.py:42-57.  x: (B, n_mel, T) -> (B, T', C*F'), feature = c*F'+f."""
+    h = F.relu(F.conv2d(x[:, None], p[pre + "conv_1.weight"], p[pre + "conv_1.bias"], stride=2))
+    h = F.relu(F.conv2d(h, p[pre + "conv_2.weight"], p[pre + "conv_2.bias"], stride=2))
+    B, C, Fp, Tp = h.shape
+    return h.permute(0, 3, 1, 2).reshape(B, Tp, C * Fp)
+
+
+def encoder_forward(x: torch.Tensor, lengths: Optional[torch.Tensor], p: Params, n_blocks: int, n_heads: int,
+                    pre: str = "encoder.", training: bool = False,
+                    return_block_outputs: bool = False):
+    """Encoder.forward, encoder.py:18-37.  Returns (y (B,T',d), lengths')."""
+    h = conv_subsampling(x, p, pre + "downsampling_conv.")
+    out_len = subsampled_lengths(lengths) if lengths is not None else None
+    h = h @ p[pre + "linear.weight"].t() + p[pre + "linear.bias"]
+    T = h.shape[1]
+    if out_len is not None and int(out_len.max()) != T:
+        # masking.py:9-12 + encoder.py:30 raise a broadcast error in this case
+        raise RuntimeError(f"lengths.max() after subsampling ({int(out_len.max())}) must equal T'={T}")
+    pe = relpos_table(T, p[pre + "rel_pe.div_term"])
+    outs = []
+    for li in range(n_blocks):
+        h = conformer_block(h, pe, out_len, p, f"{pre}layers.{li}.", n_heads, training)
+        if return_block_outputs:
+            outs.append(h)
+    if return_block_outputs:
+        return h, out_len, outs
+    return h, out_len
+
+
+def decoder_forward(x: torch.Tensor, lengths: Optional[torch.Tensor], p: Params, pre: str = "decoder.") -> torch.Tensor:
+    """Decoder.forward in eval mode, decoder.py:15-27 (stock torch LSTM; not a HIP target)."""
+    hid = p[pre + "lstm.weight_hh_l0"].shape[1]
+    lstm = torch.nn.LSTM(x.shape[-1], hid, 1, batch_first=True).to(x.dtype)
+    with torch.no_grad():
+        for n in ("weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0"):
+            getattr(lstm, n).copy_(p[pre + "lstm." + n])
+    with torch.no_grad():
+        if lengths is not None:
+            pk = torch.nn.utils.rnn.pack_padded_sequence(x, lengths.cpu(), batch_first=True, enforce_sorted=False)
+            y, _ = lstm(pk)
+            y, _ = torch.nn.utils.rnn.pad_packed_sequence(y, batch_first=True)
+        else:
+            y, _ = lstm(x)
+    y = swish(y)
+    y = (y - p[pre + "norm.running_mean"]) / torch.sqrt(p[pre + "norm.running_var"] + BN_EPS) \
+        * p[pre + "norm.weight"] + p[pre + "norm.bias"]
+    return y @ p[pre + "linear.weight"].t() + p[pre + "linear.bias"]
+
+
+def conformer_forward(x, lengths, p: Params, n_blocks: int, n_heads: int):
+    """Conformer.forward (eval), conformer.py:24-27."""
+    h, out_len = encoder_forward(x, lengths, p, n_blocks, n_heads)
+    return decoder_forward(h, out_len, p), out_len
+
+
+def ctc_loss(logits: torch.Tensor, targets: torch.Tensor, in_len: torch.Tensor, tgt_len: torch.Tensor,
+             blank: int = 0) -> torch.Tensor:
+    """ConformerCriterion.ctc_loss, evaluation.py:12-16 (integer targets give the same value)."""
+    lp = logits.float().log_softmax(-1).transpose(0, 1)
+    return F.ctc_loss(lp, targets, in_len, tgt_len, blank=blank, zero_infinity=True)
+
+
+def greedy_indices(logits: torch.Tensor) -> torch.Tensor:
+    """Per-frame argmax of processor.py:302-303 (the 'CTC alignment indices')."""
+    return logits.argmax(-1)
+
+
+# --------------------------------------------------------------------------- deterministic weights
+def make_params(vocab: int, n_mel: int, n_blocks: int, d: int, n_heads: int, ksize: int, lstm_hidden: int,
+                seed: int, dtype=torch.float32, with_decoder: bool = True) -> Params:
+    """Deterministic random weights with the reference's state_dict keys/shapes.
+
+    numpy RandomState stream => identical on any machine, so large configs never need
+    to be stored.  Scales are fan-in style so activations stay O(1) through 16 blocks;
+    BN running stats are non-trivial so eval-mode BN is actually exercised.
+    """
+    import numpy as np
+    rs = np.random.RandomState(seed)
+    P: Params = {}
+
+    def rnd(name, shape, scale):
+        P[name] = torch.from_numpy((rs.standard_normal(shape) * scale).astype(np.float64)).to(dtype)
+
+    def lin(name, out_f, in_f, extra=()):
+        rnd(name + ".weight", (out_f, in_f) + tuple(extra), 1.0 / math.sqrt(in_f * max(1, int(np.prod(extra)) if extra else 1)))
+        rnd(name + ".bias", (out_f,), 0.05)
+
+    def ln(name, n):
+        P[name + ".weight"] = torch.from_numpy(1.0 + 0.1 * rs.standard_normal(n)).to(dtype)
+        P[name + ".bias"] = torch.from_numpy(0.05 * rs.standard_normal(n)).to(dtype)
+
+    def bn(name, n):
+        ln(name, n)
+        P[name + ".running_mean"] = torch.from_numpy(0.1 * rs.standard_normal(n)).to(dtype)
+        P[name + ".running_var"] = torch.from_numpy(0.5 + rs.uniform(0, 1, n)).to(dtype)
+        P[name + ".num_batches_tracked"] = torch.tensor(3, dtype=torch.int64)
+
+    fp = subsampled_frames(n_mel)
+    e = "encoder."
+    lin(e + "downsampling_conv.conv_1", d, 1, (3, 3))
+    lin(e + "downsampling_conv.conv_2", d, d, (3, 3))
+    lin(e + "linear", d, d * fp)
+    P[e + "rel_pe.div_term"] = torch.exp(torch.arange(0, d, 2) * -(math.log(10000.0) / d)).unsqueeze(0).to(dtype)
+    dh = d // n_heads
+    for i in range(n_blocks):
+        b = f"{e}layers.{i}."
+        for f in ("ffn_1.", "ffn_2."):
+            ln(b + f + "layer_norm", d)
+            lin(b + f + "hidden_linear", 4 * d, d)
+            lin(b + f + "out_linear", d, 4 * d)
+        ln(b + "attention.layer_norm", d)
+        a = b + "attention.attention."
+        rnd(a + "content_bias", (n_heads, dh), 0.2)
+        rnd(a + "position_bias", (n_heads, dh), 0.2)
+        for nm in ("query_proj", "key_proj", "value_proj", "pos_proj", "out_proj"):
+            lin(a + nm, d, d)
+        ln(b + "conv.layer_norm", d)
+        lin(b + "conv.pointwise_conv_1", 2 * d, d, (1,))
+        lin(b + "conv.deepwise_conv", d, 1, (ksize,))
+        bn(b + "conv.batch_norm", d)
+        lin(b + "conv.pointwise_conv_2", d, d, (1,))
+        ln(b + "layer_norm", d)
+    if with_decoder:
+        dd = "decoder."
+        rnd(dd + "lstm.weight_ih_l0", (4 * lstm_hidden, d), 1.0 / math.sqrt(d))
+        rnd(dd + "lstm.weight_hh_l0", (4 * lstm_hidden, lstm_hidden), 1.0 / math.sqrt(lstm_hidden))
+        rnd(dd + "lstm.bias_ih_l0", (4 * lstm_hidden,), 0.05)
+        rnd(dd + "lstm.bias_hh_l0", (4 * lstm_hidden,), 0.05)
+        bn(dd + "norm", lstm_hidden)
+        lin(dd + "linear", vocab, lstm_hidden)
+    return P
