@@ -1,0 +1,68 @@
+"""ctypes binding of libconformer_hip.so (the C ABI declared in include/conformer_hip.h).
+
+The product path has NO fallback: if the shared library is missing, or a call returns a negative status,
+an exception is raised.  Nothing here imports the CPU oracle.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libconformer_hip.so")
+
+_P, _I, _L, _F = c_void_p, c_int, c_int64, c_float
+
+# name -> (restype, argtypes).  Mirrors include/conformer_hip.h one to one (checked by tests/test_abi.py).
+SIGNATURES = {
+    "cfm_version": (c_int, []),
+    "cfm_strerror": (c_char_p, [_I]),
+    "cfm_device_check": (c_int, []),
+    "cfm_subsampled_length": (c_int64, [_L]),
+    "cfm_layernorm_fwd_f32": (c_int, [_P, _P, _P, _P, _P, _P, _L, _I, _F, _P]),
+    "cfm_gemm_bias_f32": (c_int, [_P, _P, _P, _P, _L, _I, _I, _L, _L, _P]),
+    "cfm_gemm_bias_swish_f32": (c_int, [_P, _P, _P, _P, _L, _I, _I, _L, _L, _P]),
+    "cfm_gemm_bias_relu_f32": (c_int, [_P, _P, _P, _P, _L, _I, _I, _L, _L, _P]),
+    "cfm_gemm_bias_glu_f32": (c_int, [_P, _P, _P, _P, _L, _I, _I, _L, _L, _P]),
+    "cfm_gemm_bias_residual_f32": (c_int, [_P, _P, _P, _P, _F, _P, _L, _I, _I, _L, _L, _L, _P]),
+    "cfm_relpos_table_f32": (c_int, [_P, _P, _I, _I, _P]),
+    "cfm_relpos_attention_fwd_f32": (c_int, [_P, _P, _P, _L, _P, _L, _P, _P, _P, _P, _L, _P, _I, _I, _I, _I, _P]),
+    "cfm_dwconv_bn_swish_fwd_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, _F, _P, _I, _I, _I, _I, _P]),
+    "cfm_subsample_conv1_relu_f32": (c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "cfm_pack_conv2_weight_f32": (c_int, [_P, _P, _I, _P]),
+    "cfm_subsample_conv2_relu_f32": (c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "cfm_pack_linear_weight_f32": (c_int, [_P, _P, _I, _I, _I, _P]),
+}
+
+
+class ConformerHipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load() -> ctypes.CDLL:
+    """Load the library once.  `import torch` first so the HIP runtime torch ships is the one bound."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ConformerHipError(
+            f"{LIB_PATH} is missing: build it with `python -m conformer_amd.build` "
+            "(there is no CPU/eager fallback for the Conformer hot path)")
+    import torch  # noqa: F401  (loads libamdhip64 from torch/lib before our DT_NEEDED is resolved)
+    lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(status: int, what: str) -> None:
+    if status != 0:
+        msg = load().cfm_strerror(status).decode()
+        raise ConformerHipError(f"{what} failed: {msg} (status {status})")

@@ -1,0 +1,202 @@
+// Fused relative-position multi-head self-attention forward, fp32 (Transformer-XL style scores).
+//
+//   score[i,k] = ((q_i+u).k_k + (q_i+v).p_{r=i-k}) / sqrt(dh);  P = softmax_k(score);  ctx = P.V
+//
+// Flash-style: the (B,H,T,T) / (B,H,T,2T-1) score tensors of the reference never exist.  One wave64 owns
+// 32 query rows of one (batch, head) and sweeps the keys in tiles of 32 with an online softmax.  Every
+// product runs on v_mfma_f32_32x32x2_f32 in the TRANSPOSED orientation (keys / band rows / head dims on
+// the MFMA row axis, queries on the lane axis):
+//   S^T = K . (Q+u)^T                       keys x queries        4*NC MFMAs
+//   G^T = Pband . (Q+v)^T                    63-row band x queries 8*NC MFMAs; band row jj <-> r = i0-k0-31+jj
+//   S^T[kk][i] += G^T[i-kk+31][i]            the "relative shift" = a per-lane column skew; done through a
+//                                            per-wave LDS tile in which every lane only touches its own bank
+//   O^T += V^T . P^T                         P^T is consumed straight from the accumulator registers (the
+//                                            softmax row reductions are in-lane + one cross-half shuffle)
+// Operands stream from L2 straight into registers (K/V/pos of one head are 64-127 KB and shared by the
+// 4 waves of a block and by the 2 blocks of a head); the only LDS use is the skew tile.
+// Key-padding mask: keys >= lengths[b] are skipped entirely (identical to the reference's finfo.min fill
+// because exp underflows to exactly 0; lengths[b] <= 0 reproduces its uniform-softmax degenerate case).
+#include "cfm_common.h"
+#include <math.h>
+
+namespace {
+
+struct AttnArgs {
+    const float* q; const float* k; const float* v; int64_t ld;
+    const float* pos; int64_t ldp; const float* u; const float* vb;
+    const int64_t* lengths; float* ctx; int64_t ldo; float* lse;
+    int B, T, H, dh; float sqrt_dh;
+};
+
+template <int NC, int ND>
+__global__ __launch_bounds__(256, 2) void relpos_attn_fwd_kernel(const AttnArgs a) {
+    __shared__ float skew[4][64 * 32];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 31, hf = lane >> 5;
+    const int bh = blockIdx.y, b = bh / a.H, h = bh % a.H;
+    const int T = a.T, dh = a.dh;
+    const int i0 = (blockIdx.x * 4 + wave) * 32;
+    if (i0 >= T) return;                                            // wave-uniform
+    float* gs = skew[wave];
+
+    int klen = T;
+    bool uniform = false;
+    if (a.lengths) {
+        const int64_t L = a.lengths[b];
+        if (L <= 0) uniform = true;                                // every key masked -> uniform weights
+        else if (L < T) klen = (int)L;
+    }
+
+    // ---- (Q+u)^T and (Q+v)^T as MFMA B operands: lane (query li, half hf) holds dims 8c+4hf+e at step 4c+e
+    const int qi = min(i0 + li, T - 1);
+    const float* qrow = a.q + ((int64_t)b * T + qi) * a.ld + h * dh;
+    float qu[4 * NC], qv[4 * NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const int dd = 8 * c + 4 * hf;
+        f32x4 x = {0.f, 0.f, 0.f, 0.f}, uu = x, vv = x;
+        if (dd < dh) {
+            x = *reinterpret_cast<const f32x4*>(qrow + dd);
+            uu = *reinterpret_cast<const f32x4*>(a.u + h * dh + dd);
+            vv = *reinterpret_cast<const f32x4*>(a.vb + h * dh + dd);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { qu[4 * c + e] = x[e] + uu[e]; qv[4 * c + e] = x[e] + vv[e]; }
+    }
+
+    f32x16 o[ND];
+#pragma unroll
+    for (int n = 0; n < ND; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[n][r] = 0.f;
+    float mrow = -INFINITY, lrow = 0.f;
+
+    const float* kbase = a.k + (int64_t)b * T * a.ld + h * dh;
+    const float* vbase = a.v + (int64_t)b * T * a.ld + h * dh;
+    const float* pbase = a.pos + h * dh;
+
+    for (int k0 = 0; k0 < klen; k0 += 32) {
+        // ---- content scores S^T[key][query]
+        f32x16 sc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sc[r] = 0.f;
+        {
+            const float* krow = kbase + (int64_t)min(k0 + li, T - 1) * a.ld;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const int dd = 8 * c + 4 * hf;
+                f32x4 kf = {0.f, 0.f, 0.f, 0.f};
+                if (dd < dh) kf = *reinterpret_cast<const f32x4*>(krow + dd);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) sc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[e], qu[4 * c + e], sc, 0, 0, 0);
+            }
+        }
+        // ---- positional band G^T[jj][query], jj = 0..63 <-> table row j = jbase - jj
+        const int jbase = T - 1 - i0 + k0 + 31;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            int j = jbase - (32 * mt + li);
+            j = max(0, min(j, 2 * T - 2));                          // out-of-range rows only feed masked pairs
+            const float* prow = pbase + (int64_t)j * a.ldp;
+            f32x16 ga;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ga[r] = 0.f;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const int dd = 8 * c + 4 * hf;
+                f32x4 pf = {0.f, 0.f, 0.f, 0.f};
+                if (dd < dh) pf = *reinterpret_cast<const f32x4*>(prow + dd);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ga = __builtin_amdgcn_mfma_f32_32x32x2f32(pf[e], qv[4 * c + e], ga, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) gs[(32 * mt + (r & 3) + 8 * (r >> 2) + 4 * hf) * 32 + li] = ga[r];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+        // ---- skewed read + scale + mask, online softmax (query = lane column; keys = registers x 2 halves)
+        float p[16];
+        float tmax = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int kk = (r & 3) + 8 * (r >> 2) + 4 * hf;
+            float s = (sc[r] + gs[(li - kk + 31) * 32 + li]) / a.sqrt_dh;
+            if (uniform) s = 0.f;
+            if (k0 + kk >= klen) s = -INFINITY;
+            p[r] = s;
+            tmax = fmaxf(tmax, s);
+        }
+        __builtin_amdgcn_wave_barrier();                            // skew tile is rewritten next iteration
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        const float mnew = fmaxf(mrow, tmax);                       // finite: key k0 (< klen) is always valid
+        const float alpha = expf(mrow - mnew);
+        float psum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { p[r] = expf(p[r] - mnew); psum += p[r]; }
+        psum += __shfl_xor(psum, 32, 64);
+        lrow = lrow * alpha + psum;
+        mrow = mnew;
+#pragma unroll
+        for (int n = 0; n < ND; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[n][r] *= alpha;
+
+        // ---- O^T += V^T . P^T ; MFMA step s contracts key (s&3)+8*(s>>2)+4*hf = the key held in register s
+#pragma unroll
+        for (int n = 0; n < ND; ++n) {
+            const int dd = 32 * n + li;
+            const bool dok = dd < dh;
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                const int key = min(k0 + (s & 3) + 8 * (s >> 2) + 4 * hf, T - 1);
+                const float vv = dok ? vbase[(int64_t)key * a.ld + dd] : 0.f;
+                o[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv, p[s], o[n], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- normalise and store: lane = query row, registers = head dims (4 consecutive dims per r>>2 group)
+    const float inv = 1.0f / lrow;
+    if (i0 + li < T) {
+        float* orow = a.ctx + ((int64_t)b * T + i0 + li) * a.ldo + h * dh;
+#pragma unroll
+        for (int n = 0; n < ND; ++n)
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const int dd = 32 * n + 8 * gq + 4 * hf;
+                if (dd < dh) {
+                    f32x4 out = {o[n][4 * gq] * inv, o[n][4 * gq + 1] * inv, o[n][4 * gq + 2] * inv, o[n][4 * gq + 3] * inv};
+                    *reinterpret_cast<f32x4*>(orow + dd) = out;
+                }
+            }
+        if (a.lse && hf == 0) a.lse[((int64_t)b * a.H + h) * T + i0 + li] = mrow + logf(lrow);
+    }
+}
+
+}  // namespace
+
+extern "C" int cfm_relpos_attention_fwd_f32(const float* q, const float* k, const float* v, int64_t ld,
+                                            const float* pos, int64_t ldp, const float* u, const float* vbias,
+                                            const int64_t* lengths_or_null, float* ctx, int64_t ldo,
+                                            float* lse_or_null, int B, int T, int H, int dh, cfm_stream_t stream) {
+    CFM_REQUIRE(q && k && v && pos && u && vbias && ctx, CFM_ERR_NULL);
+    CFM_REQUIRE(B > 0 && T > 0 && H > 0 && dh > 0 && (dh & 3) == 0, CFM_ERR_BAD_SHAPE);
+    CFM_REQUIRE((ld & 3) == 0 && (ldp & 3) == 0 && (ldo & 3) == 0, CFM_ERR_BAD_SHAPE);
+    CFM_REQUIRE(dh <= 64, CFM_ERR_UNSUPPORTED);
+    CFM_REQUIRE(CFM_ALIGNED16(q) && CFM_ALIGNED16(k) && CFM_ALIGNED16(v) && CFM_ALIGNED16(pos) && CFM_ALIGNED16(u) &&
+                CFM_ALIGNED16(vbias) && CFM_ALIGNED16(ctx), CFM_ERR_ALIGN);
+    CFM_REQUIRE((int64_t)B * H <= 65535, CFM_ERR_UNSUPPORTED);
+    AttnArgs a{q, k, v, ld, pos, ldp, u, vbias, lengths_or_null, ctx, ldo, lse_or_null, B, T, H, dh, sqrtf((float)dh)};
+    const dim3 grid((unsigned)((T + 127) / 128), (unsigned)(B * H)), block(256);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+#define ATT_LAUNCH(NC, ND) hipLaunchKernelGGL((relpos_attn_fwd_kernel<NC, ND>), grid, block, 0, s, a)
+    if (dh <= 8) ATT_LAUNCH(1, 1);
+    else if (dh <= 16) ATT_LAUNCH(2, 1);
+    else if (dh <= 32) ATT_LAUNCH(4, 1);
+    else if (dh <= 40) ATT_LAUNCH(5, 2);
+    else ATT_LAUNCH(8, 2);
+#undef ATT_LAUNCH
+    return cfm_launch_status();
+}

@@ -1,0 +1,41 @@
+// Internal helpers shared by the gfx950 kernels of libconformer_hip.so (not part of the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/conformer_hip.h"
+
+#define CFM_WAVE 64
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define CFM_REQUIRE(cond, code) do { if (!(cond)) return (code); } while (0)
+#define CFM_ALIGNED16(p) ((reinterpret_cast<uintptr_t>(p) & 15u) == 0)
+
+static inline int cfm_launch_status() {
+    return hipGetLastError() == hipSuccess ? CFM_OK : CFM_ERR_LAUNCH;
+}
+
+// full-wave (64 lane) butterfly reductions
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+__device__ __forceinline__ float sigmoidf_acc(float x) { return 1.0f / (1.0f + expf(-x)); }
+__device__ __forceinline__ float swishf_acc(float x) { return x * sigmoidf_acc(x); }
+
+// Bijective XCD-aware remap of a 1-D block id: blocks that share an XCD (id % 8 under the observed
+// round-robin placement) get a contiguous chunk of the logical grid so neighbouring tiles reuse that
+// XCD's L2.  Speed only -- never correctness.
+__device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nwg) {
+    const unsigned q = nwg >> 3, r = nwg & 7u, x = bid & 7u, i = bid >> 3;
+    const unsigned base = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+    return base + i;
+}

@@ -1,0 +1,50 @@
+"""Encoder (surface of model/modules/encoder.py:9-37): stem -> input Linear -> N Conformer blocks, all on
+gfx950 kernels.  `forward(x (B,n_mel,T), lengths (B,) int64 | None) -> (y (B,T',d), lengths')`.
+
+`lengths` stays on the device and is handed to the attention kernel; T' comes from the tensor shape, so
+the two host syncs of the reference (masking.py:10) are gone.  Setting CONFORMER_AMD_STRICT=1 restores the
+reference's failure when lengths.max() != T' (masking.py:9-12 + encoder.py:30) at the cost of one sync.
+"""
+from typing import Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from ... import ops
+from ..utils._guard import STRICT, PackCache, require_inference
+from ..utils.block import ConformerBlock
+from ..utils.convolution import ConvolutionSubsampling
+from ..utils.position import RelativePositionalEncoding
+
+
+class Encoder(nn.Module):
+    def __init__(self, n_mel_channels: int, n_blocks: int, d_model: int, n_heads: int, kernel_size: int,
+                 dropout_rate: float = 0.0) -> None:
+        super().__init__()
+        self.n_freq_out = ((n_mel_channels - 1) // 2 - 1) // 2
+        self.downsampling_conv = ConvolutionSubsampling(channels=d_model)
+        self.linear = nn.Linear(in_features=d_model * self.n_freq_out, out_features=d_model)
+        self.dropout = nn.Dropout(p=dropout_rate)
+        self.rel_pe = RelativePositionalEncoding(d_model=d_model)
+        self.layers = nn.ModuleList([ConformerBlock(d_model=d_model, n_heads=n_heads, kernel_size=kernel_size,
+                                                    dropout_rate=dropout_rate) for _ in range(n_blocks)])
+        self._packs = PackCache()
+
+    def forward(self, x: torch.Tensor, lengths: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+        require_inference(self, "Encoder", x)
+        d = self.linear.out_features
+        h = self.downsampling_conv.channel_last(x)                                   # (B, T', F'*C)
+        out_len = ConvolutionSubsampling.out_lengths(lengths)
+        wlp = self._packs.get("wlp", (self.linear.weight,),
+                              lambda: ops.pack_linear_weight(self.linear.weight, d, self.n_freq_out))
+        h = ops.linear(h, wlp, self.linear.bias)                                     # (B, T', d)
+        n_frames = h.shape[1]
+        if out_len is not None:
+            if out_len.device != h.device:
+                out_len = out_len.to(h.device)
+            if STRICT and int(out_len.max()) != n_frames:
+                raise RuntimeError(f"lengths.max() after subsampling must equal T'={n_frames}")
+        table = self.rel_pe.table(n_frames)
+        for layer in self.layers:
+            h = layer.fused(h, table, out_len)
+        return h, out_len

@@ -1,0 +1,93 @@
+"""Relative-position MHSA (surface of model/utils/attention.py:7-102) on gfx950 kernels.
+
+Differences in HOW (not in results):
+  * Q, K, V are one fused (d -> 3d) MFMA GEMM; the three nn.Linear parameters stay separate in the
+    state_dict and are concatenated into a cached device buffer;
+  * pos_proj is applied ONCE to the (2T-1, d) table instead of to a batch-repeated (B, 2T-1, d) tensor
+    (attention.py:81, position.py:26);
+  * content scores, positional scores, the relative shift (attention.py:94-102), masking, softmax and
+    attention.V run inside one flash-style kernel (attention_f32.hip) -- no (B,H,T,T) tensor exists;
+  * the key-padding mask is consumed as `lengths`.
+"""
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from ... import ops
+from ._guard import PackCache, require_inference
+from .masking import lengths_from_key_padding_mask
+
+
+class RelativeMultiHeadAttention(nn.Module):
+    def __init__(self, d_model: int, n_heads: int, dropout_rate: float = 0.0):
+        super().__init__()
+        if d_model % n_heads != 0:
+            raise AssertionError("d_model must be divisible by n_heads")
+        self.d_model = d_model
+        self.n_heads = n_heads
+        self.head_samples = d_model // n_heads
+        self.sqrt_dim = float(self.head_samples) ** 0.5
+
+        self.query_proj = nn.Linear(d_model, d_model)
+        self.key_proj = nn.Linear(d_model, d_model)
+        self.value_proj = nn.Linear(d_model, d_model)
+        self.pos_proj = nn.Linear(d_model, d_model)
+        self.dropout = nn.Dropout(p=dropout_rate)
+        self.content_bias = nn.Parameter(torch.empty(n_heads, self.head_samples))
+        self.position_bias = nn.Parameter(torch.empty(n_heads, self.head_samples))
+        self.out_proj = nn.Linear(d_model, d_model)
+        self.mask_value = None          # kept for attribute parity; the fused kernel skips masked keys
+        nn.init.xavier_uniform_(self.content_bias)
+        nn.init.xavier_uniform_(self.position_bias)
+        self._packs = PackCache()
+
+    # ---- fused path -------------------------------------------------------------------------
+    def _qkv_params(self):
+        ws = (self.query_proj.weight, self.key_proj.weight, self.value_proj.weight)
+        bs = (self.query_proj.bias, self.key_proj.bias, self.value_proj.bias)
+        w = self._packs.get("qkv_w", ws, lambda: torch.cat([t.detach() for t in ws], dim=0).contiguous())
+        b = self._packs.get("qkv_b", bs, lambda: torch.cat([t.detach() for t in bs], dim=0).contiguous())
+        return w, b
+
+    def context(self, x: torch.Tensor, pos_table: torch.Tensor, lengths: Optional[torch.Tensor]) -> torch.Tensor:
+        """x: (B,T,d) already layer-normed; pos_table: (2T-1,d) un-projected; returns concat-head context."""
+        w, b = self._qkv_params()
+        qkv = ops.linear(x, w, b)
+        pos = ops.linear(pos_table, self.pos_proj.weight, self.pos_proj.bias)
+        return ops.relpos_attention(qkv, pos, self.content_bias, self.position_bias, lengths, self.n_heads)
+
+    def fused(self, x, pos_table, lengths, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+        ctx = self.context(x, pos_table, lengths)
+        if residual is None:
+            return ops.linear(ctx, self.out_proj.weight, self.out_proj.bias)
+        return ops.linear_residual(ctx, self.out_proj.weight, self.out_proj.bias, residual, 1.0)
+
+    # ---- reference-compatible entry (attention.py:74) ------------------------------------------
+    def forward(self, q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, pos_embedding: torch.Tensor,
+                mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+        require_inference(self, "RelativeMultiHeadAttention", q)
+        if not (k is q and v is q):
+            raise NotImplementedError("the fused gfx950 kernel implements SELF-attention (q is k is v), which is "
+                                      "the only way the reference calls it (attention.py:16)")
+        table = pos_embedding[0] if pos_embedding.dim() == 3 else pos_embedding
+        lengths = None if mask is None else lengths_from_key_padding_mask(mask)
+        return self.fused(q, table, lengths)
+
+
+class MultiHeadSelfAttentionModule(nn.Module):
+    def __init__(self, d_model: int, n_heads: int, dropout_rate: float = 0.0) -> None:
+        super().__init__()
+        self.layer_norm = nn.LayerNorm(normalized_shape=d_model)
+        self.attention = RelativeMultiHeadAttention(d_model=d_model, n_heads=n_heads, dropout_rate=dropout_rate)
+        self.dropout = nn.Dropout(p=dropout_rate)
+
+    def fused(self, x, pos_table, lengths, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+        require_inference(self, "MultiHeadSelfAttentionModule", x)
+        xn = ops.layernorm(x, self.layer_norm.weight, self.layer_norm.bias, self.layer_norm.eps)
+        return self.attention.fused(xn, pos_table, lengths, residual)
+
+    def forward(self, x: torch.Tensor, pos_embedding: torch.Tensor, mask: Optional[torch.Tensor] = None):
+        table = pos_embedding[0] if pos_embedding.dim() == 3 else pos_embedding
+        lengths = None if mask is None else lengths_from_key_padding_mask(mask)
+        return self.fused(x, table, lengths)

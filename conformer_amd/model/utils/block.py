@@ -1,0 +1,38 @@
+"""ConformerBlock (surface of model/utils/block.py:8-29): the Macaron sandwich on gfx950 kernels.
+
+Each of the four residual sub-layers ends in an MFMA GEMM whose epilogue applies `alpha*y + x`
+(alpha = 1/2 for the two FFNs, block.py:19,25), so no stand-alone add/scale kernels run; the closing
+LayerNorm (block.py:27) is the wave-per-row kernel.  16 launches per block in total.
+"""
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from ... import ops
+from .attention import MultiHeadSelfAttentionModule
+from .convolution import ConvolutionModule
+from .ffn import FeedForwardModule
+from .masking import lengths_from_key_padding_mask
+
+
+class ConformerBlock(nn.Module):
+    def __init__(self, d_model: int, n_heads: int, kernel_size: int, dropout_rate: float = 0.0) -> None:
+        super().__init__()
+        self.ffn_1 = FeedForwardModule(dim=d_model, dropout_rate=dropout_rate)
+        self.attention = MultiHeadSelfAttentionModule(n_heads=n_heads, d_model=d_model, dropout_rate=dropout_rate)
+        self.conv = ConvolutionModule(channels=d_model, kernel_size=kernel_size, dropout_rate=dropout_rate)
+        self.ffn_2 = FeedForwardModule(dim=d_model, dropout_rate=dropout_rate)
+        self.layer_norm = nn.LayerNorm(normalized_shape=d_model)
+
+    def fused(self, x: torch.Tensor, pos_table: torch.Tensor, lengths: Optional[torch.Tensor]) -> torch.Tensor:
+        y = self.ffn_1.fused(x, residual=x, alpha=0.5)
+        y = self.attention.fused(y, pos_table, lengths, residual=y)
+        y = self.conv.fused(y, residual=y)
+        y = self.ffn_2.fused(y, residual=y, alpha=0.5)
+        return ops.layernorm(y, self.layer_norm.weight, self.layer_norm.bias, self.layer_norm.eps)
+
+    def forward(self, x: torch.Tensor, pos_embedding: torch.Tensor, mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+        table = pos_embedding[0] if pos_embedding.dim() == 3 else pos_embedding
+        lengths = None if mask is None else lengths_from_key_padding_mask(mask)
+        return self.fused(x, table, lengths)

@@ -1,0 +1,36 @@
+"""FeedForwardModule (surface of model/utils/ffn.py:5-23) on gfx950 kernels.
+
+LN -> Linear(d,4d)+Swish (one MFMA GEMM, Swish in the epilogue) -> Linear(4d,d) (+ optional fused
+`alpha*y + residual` epilogue used by ConformerBlock, block.py:19,25).  Sub-module names/shapes match the
+reference state_dict.
+"""
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from ... import ops
+from ._guard import require_inference
+from .activation import Swish
+
+
+class FeedForwardModule(nn.Module):
+    def __init__(self, dim: int, dropout_rate: float = 0.0) -> None:
+        super().__init__()
+        self.layer_norm = nn.LayerNorm(normalized_shape=dim)
+        self.hidden_linear = nn.Linear(in_features=dim, out_features=4 * dim)
+        self.swish = Swish()
+        self.dropout_1 = nn.Dropout(p=dropout_rate)
+        self.out_linear = nn.Linear(in_features=4 * dim, out_features=dim)
+        self.dropout_2 = nn.Dropout(p=dropout_rate)
+
+    def fused(self, x: torch.Tensor, residual: Optional[torch.Tensor] = None, alpha: float = 1.0) -> torch.Tensor:
+        require_inference(self, "FeedForwardModule", x)
+        h = ops.layernorm(x, self.layer_norm.weight, self.layer_norm.bias, self.layer_norm.eps)
+        h = ops.linear(h, self.hidden_linear.weight, self.hidden_linear.bias, act="swish")
+        if residual is None:
+            return ops.linear(h, self.out_linear.weight, self.out_linear.bias)
+        return ops.linear_residual(h, self.out_linear.weight, self.out_linear.bias, residual, alpha)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return self.fused(x)

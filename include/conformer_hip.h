@@ -1,0 +1,125 @@
+/*
+ * conformer_hip.h -- C ABI of libconformer_hip.so: hand-written gfx950 (MI355X, CDNA4) kernels for the
+ * Conformer encoder hot path.
+ *
+ * The reference (Alan-404/Conformer) has no FFI layer: its "operator API" is torch.nn.  Each entry
+ * point below therefore cites the reference nn.Module call site(s) it replaces (file:line under the
+ * reference tree).  Conventions:
+ *   - plain pointers + sizes, no torch types; all pointers are DEVICE pointers unless stated;
+ *   - the caller owns every buffer (outputs, workspaces); nothing here allocates, frees or
+ *     synchronises; every launch is enqueued on `stream` (a hipStream_t passed as void*);
+ *   - return 0 on success or a negative cfm_status; never throws; re-entrant (no mutable globals);
+ *   - activations are row-major (B, T, d) fp32, d contiguous; weights keep the PyTorch layout of the
+ *     reference state_dict unless a cfm_pack_* routine is named;
+ *   - `lengths` are int64 device arrays of B valid-frame counts, or NULL for "no mask".
+ */
+#ifndef CONFORMER_HIP_H
+#define CONFORMER_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* cfm_stream_t; /* hipStream_t */
+
+enum cfm_status {
+    CFM_OK = 0,
+    CFM_ERR_BAD_SHAPE = -1,    /* a dimension is <= 0 or violates a documented divisibility rule */
+    CFM_ERR_UNSUPPORTED = -2,  /* e.g. head dim > 64, depthwise kernel > 63 */
+    CFM_ERR_NULL = -3,         /* a required pointer is NULL */
+    CFM_ERR_LAUNCH = -4,       /* hipGetLastError() reported a launch failure */
+    CFM_ERR_DEVICE = -5,       /* current device is not gfx950 */
+    CFM_ERR_ALIGN = -6         /* a pointer or leading dimension is not 16-byte aligned */
+};
+
+/* ---- library ------------------------------------------------------------------------------- */
+int cfm_version(void);                  /* ABI version, currently 1 */
+const char* cfm_strerror(int status);   /* static string */
+int cfm_device_check(void);             /* CFM_OK iff the current HIP device is gfx950 */
+
+/* ---- LayerNorm (nn.LayerNorm eps=1e-5 affine: ffn.py:8,16; attention.py:10,15;
+ *      convolution.py:12,22; block.py:15,27).  One wave64 per row, shuffle reductions.
+ *      y[r,:] = (x[r,:]-mean)/sqrt(var+eps)*gamma+beta.  d % 4 == 0, d <= 8192.
+ *      mean/rstd (rows) are optional outputs for a later backward. */
+int cfm_layernorm_fwd_f32(const float* x, const float* gamma, const float* beta, float* y,
+                          float* mean_or_null, float* rstd_or_null,
+                          int64_t rows, int d, float eps, cfm_stream_t stream);
+
+/* ---- dense GEMMs on the fp32 MFMA pipe (v_mfma_f32_32x32x2_f32), C = A . W^T with epilogues.
+ *      A: (M,K) row-major with leading dim lda; W: (N,K) row-major (= nn.Linear.weight, or
+ *      Conv1d(k=1).weight viewed (N,K)); bias: (N).  K % 4 == 0, lda % 4 == 0, A and W 16-byte aligned.
+ *
+ *      _bias          : nn.Linear                      encoder.py:23, attention.py:78-81,90
+ *      _bias_swish    : Linear + Swish                 ffn.py:17-18
+ *      _bias_relu     : (used by the conv stem)        convolution.py:46-47
+ *      _bias_glu      : Conv1d(k=1, d->2d) + GLU(dim=1) convolution.py:24-25; N = 2*n_out is the weight
+ *                       row count, C is (M, n_out): C = (A.Wv^T+bv) * sigmoid(A.Wg^T+bg) with
+ *                       Wv = W[0:n_out], Wg = W[n_out:2n_out]
+ *      _bias_residual : Linear then `alpha*y + R`      block.py:19,21,23,25 (R: (M,N), leading dim ldr) */
+int cfm_gemm_bias_f32(const float* A, const float* W, const float* bias, float* C,
+                      int64_t M, int N, int K, int64_t lda, int64_t ldc, cfm_stream_t stream);
+int cfm_gemm_bias_swish_f32(const float* A, const float* W, const float* bias, float* C,
+                            int64_t M, int N, int K, int64_t lda, int64_t ldc, cfm_stream_t stream);
+int cfm_gemm_bias_relu_f32(const float* A, const float* W, const float* bias, float* C,
+                           int64_t M, int N, int K, int64_t lda, int64_t ldc, cfm_stream_t stream);
+int cfm_gemm_bias_glu_f32(const float* A, const float* W, const float* bias, float* C,
+                          int64_t M, int n_out, int K, int64_t lda, int64_t ldc, cfm_stream_t stream);
+int cfm_gemm_bias_residual_f32(const float* A, const float* W, const float* bias, const float* R,
+                               float alpha, float* C, int64_t M, int N, int K,
+                               int64_t lda, int64_t ldr, int64_t ldc, cfm_stream_t stream);
+
+/* ---- relative positional encoding table (RelativePositionalEncoding.forward, position.py:11-27,
+ *      WITHOUT the batch repeat of position.py:26).  pe: (2T-1, d); row j encodes r = T-1-j:
+ *      pe[j,2c] = sin(r*div_term[c]), pe[j,2c+1] = cos(r*div_term[c]).  div_term: (d/2). */
+int cfm_relpos_table_f32(const float* div_term, float* pe, int T, int d, cfm_stream_t stream);
+
+/* ---- fused relative-position attention (scaled_dot_product_relative_attention + _relative_shift
+ *      + head split/concat, attention.py:47-72,78-88,94-102).
+ *      q,k,v: row (b*T+t) at ptr + (b*T+t)*ld, head h in columns [h*dh,(h+1)*dh) (so a fused
+ *      (B*T, 3d) QKV buffer is passed as q=buf, k=buf+d, v=buf+2d, ld=3d);
+ *      pos: (2T-1, H*dh) PROJECTED table (pos_proj applied once, not per batch), leading dim ldp;
+ *      u, vbias: content_bias / position_bias (H, dh);  lengths: keys k >= lengths[b] are masked.
+ *      score[i,k] = ((q_i+u).k_k + (q_i+vbias).pos[T-1-(i-k)]) / sqrt(dh); softmax over k; ctx = P.V.
+ *      ctx: (B*T, H*dh) leading dim ldo.  lse_or_null: (B,H,T) log-sum-exp for a later backward.
+ *      dh <= 64 and dh % 4 == 0; ld, ldp, ldo % 4 == 0.  Scores are never materialised. */
+int cfm_relpos_attention_fwd_f32(const float* q, const float* k, const float* v, int64_t ld,
+                                 const float* pos, int64_t ldp, const float* u, const float* vbias,
+                                 const int64_t* lengths_or_null, float* ctx, int64_t ldo,
+                                 float* lse_or_null, int B, int T, int H, int dh, cfm_stream_t stream);
+
+/* ---- convolution module core: depthwise Conv1d(k=K, pad (K-1)/2, groups=C) + BatchNorm1d (eval,
+ *      running stats) + Swish, channel-last (convolution.py:26-28).
+ *      g: (B,T,C) GLU output; w: (C,1,K) = (C,K); y: (B,T,C).  Zero padding is per utterance over
+ *      [0,T) and padded frames are NOT masked.  K odd, K <= 63. */
+int cfm_dwconv_bn_swish_fwd_f32(const float* g, const float* w, const float* bias,
+                                const float* bn_weight, const float* bn_bias,
+                                const float* bn_mean, const float* bn_var, float bn_eps,
+                                float* y, int B, int T, int C, int K, cfm_stream_t stream);
+
+/* ---- convolution subsampling stem (ConvolutionSubsampling.forward, convolution.py:42-57)
+ *      x: (B, F, T) log-mel (mel axis is the conv "height").  T1=(T-1)/2, F1=(F-1)/2, T2=(T1-1)/2,
+ *      F2=(F1-1)/2 (integer division).
+ *      conv1: h1 (B,T1,F1,C) channel-last = relu(conv2d(x, w1 (C,1,3,3), stride 2) + b1)
+ *      pack : w2p (C, 3,3, C) = w2 (C_out, C_in, 3,3) permuted to (C_out, kf, kt, C_in)
+ *      conv2: h2 (B,T2,F2,C) channel-last = relu(implicit-GEMM conv2d(h1, w2p, stride 2) + b2) on MFMA
+ *      pack : wlp (d, F2*C) = linear.weight (d, C*F2) with columns reordered (c*F2+f) -> (f*C+c),
+ *             so that encoder.py:23 becomes cfm_gemm_bias_f32 on h2 viewed (B*T2, F2*C).
+ *      C % 16 == 0. */
+int cfm_subsample_conv1_relu_f32(const float* x, const float* w1, const float* b1, float* h1,
+                                 int B, int F, int T, int C, cfm_stream_t stream);
+int cfm_pack_conv2_weight_f32(const float* w2, float* w2p, int C, cfm_stream_t stream);
+int cfm_subsample_conv2_relu_f32(const float* h1, const float* w2p, const float* b2, float* h2,
+                                 int B, int F1, int T1, int C, cfm_stream_t stream);
+int cfm_pack_linear_weight_f32(const float* wl, float* wlp, int d_out, int C, int F2, cfm_stream_t stream);
+
+/* ---- integer helpers of the path (host-side, no device work) ---------------------------------
+ *      frames after the stem: ((n-1)/2-1)/2, convolution.py:55 */
+int64_t cfm_subsampled_length(int64_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CONFORMER_HIP_H */
