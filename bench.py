@@ -1,0 +1,247 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Conformer-L encoder forward, audio(mel)-frames/sec on MI355X (BASELINE.json).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
+
+A "step" = one pass of the hot path (Encoder.forward: conv-subsampling stem -> input Linear -> 16 Conformer
+blocks) over one synthetic batch that is already resident in HBM.  Utterances shard over the batch axis, so
+N GPUs run N independent replicas with their own B=32 (weak scaling, no data-path collective).
+Rank 0 prints ONE JSON line (see the driver contract in the task statement) carrying two extra objects:
+  roofline      -- the dominant kernel (fp32 MFMA GEMM family) timed live with HIP events on the launch stream
+  cpu_baseline  -- the CPU oracle (oracle/conformer_oracle.py, a restatement pinned against the reference)
+                   timed on this host's cores on a bounded sample of the same workload (N=1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# BASELINE.json configs[1]: 16-layer d=512 Conformer-L, B=32 T=1000 synthetic, fp32 forward
+CFG = dict(n_mel=80, n_blocks=16, d=512, n_heads=8, ksize=31, B=32, T=1000)
+PEAK_MFMA_F32_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
+PEAK_HBM_GBS = 8000.0
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def algorithmic_flops(B, T, d, L, K, n_mel=80):
+    """2*MAC of the encoder forward."""
+    T1 = (T - 1) // 2; Tp = (T1 - 1) // 2
+    F1 = (n_mel - 1) // 2; Fp = (F1 - 1) // 2
+    N = B * Tp; P = 2 * Tp - 1
+    front = 18 * d * F1 * T1 * B + 18 * d * d * Fp * Tp * B + 2 * (Fp * d) * d * N
+    block = 46 * N * d * d + 2 * P * d * d + 6 * B * Tp * Tp * d + 2 * N * d * K
+    return front + L * block
+
+
+def time_events(fn, iters, warm=2):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(iters + 1)]
+    ev[0].record()
+    for i in range(iters):
+        fn()
+        ev[i + 1].record()
+    torch.cuda.synchronize()
+    ts = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(iters))
+    return sum(ts) / len(ts), ts[len(ts) // 2]
+
+
+def gemm_site_table(enc, x, iters):
+    """Times every distinct MFMA-GEMM launch of the forward in isolation (HIP events on the launch stream =
+    torch's current stream) and returns rows: kernel instance, shape, launches/step, avg ms, TFLOP/s."""
+    from conformer_amd import ops
+    B, T, d, L = CFG["B"], CFG["T"], CFG["d"], CFG["n_blocks"]
+    dev = x.device
+    T1 = (T - 1) // 2; Tp = (T1 - 1) // 2; F1 = 39; Fp = 19
+    N = B * Tp; P = 2 * Tp - 1
+    lay = enc.layers[0]
+    att = lay.attention.attention
+    a_d = torch.randn(N, d, device=dev); a_4d = torch.randn(N, 4 * d, device=dev)
+    res = torch.randn(N, d, device=dev)
+    h2 = torch.randn(N, Fp * d, device=dev)
+    pe = torch.randn(P, d, device=dev)
+    stem = enc.downsampling_conv
+    w2p = stem._packs.get("w2p", (stem.conv_2.weight,), lambda: ops.pack_conv2_weight(stem.conv_2.weight))
+    h1 = torch.randn(B, T1, F1, d, device=dev).relu_()
+    h2o = torch.empty(B, Tp, Fp * d, device=dev)
+    from conformer_amd import _lib
+    lib = _lib.load()
+    st = torch.cuda.current_stream().cuda_stream
+
+    def conv2():
+        _lib.check(lib.cfm_subsample_conv2_relu_f32(h1.data_ptr(), w2p.data_ptr(), stem.conv_2.bias.data_ptr(),
+                                                    h2o.data_ptr(), B, F1, T1, d, st), "conv2")
+
+    qkvw, qkvb = att._qkv_params()
+    wl = enc.linear.weight
+    sites = [
+        ("gemm<relu,conv>  stem conv2 implicit GEMM", (B * Tp * Fp, d, 9 * d), 1, conv2),
+        ("gemm<bias>       input linear", (N, d, Fp * d), 1, lambda: ops.linear(h2, wl, enc.linear.bias)),
+        ("gemm<swish>      FFN hidden", (N, 4 * d, d), 2 * L,
+         lambda: ops.linear(a_d, lay.ffn_1.hidden_linear.weight, lay.ffn_1.hidden_linear.bias, act="swish")),
+        ("gemm<residual>   FFN out", (N, d, 4 * d), 2 * L,
+         lambda: ops.linear_residual(a_4d, lay.ffn_1.out_linear.weight, lay.ffn_1.out_linear.bias, res, 0.5)),
+        ("gemm<bias>       fused QKV", (N, 3 * d, d), L, lambda: ops.linear(a_d, qkvw, qkvb)),
+        ("gemm<bias>       pos proj", (P, d, d), L, lambda: ops.linear(pe, att.pos_proj.weight, att.pos_proj.bias)),
+        ("gemm<residual>   attn out / pw2", (N, d, d), 2 * L,
+         lambda: ops.linear_residual(a_d, att.out_proj.weight, att.out_proj.bias, res, 1.0)),
+        ("gemm<glu>        pw1+GLU", (N, 2 * d, d), L,
+         lambda: ops.linear_glu(a_d, lay.conv.pointwise_conv_1.weight, lay.conv.pointwise_conv_1.bias)),
+    ]
+    rows = []
+    for name, (m, n, k), per_step, fn in sites:
+        avg, med = time_events(fn, iters)
+        log(f"[bench] {name}: {m}x{n}x{k} avg {avg:.3f} ms  {2.0 * m * n * k / avg / 1e9:.1f} TFLOP/s")
+        fl = 2.0 * m * n * k
+        rows.append(dict(kernel=name, M=m, N=n, K=k, launches_per_step=per_step, avg_ms=avg, med_ms=med,
+                         tflops=fl / (avg * 1e-3) / 1e12, flops=fl))
+    return rows
+
+
+def host_cores() -> int:
+    """CPU cores this process may really use: affinity mask, capped by the cgroup CPU quota if there is one."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
+def cpu_baseline(enc, sample_b):
+    """The oracle on the host cores, same model weights, same T, a bounded batch sample."""
+    from oracle import conformer_oracle as O
+    P = {"encoder." + k: v.detach().cpu() for k, v in enc.state_dict().items()}
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(sample_b, CFG["n_mel"], CFG["T"], generator=g)
+    L = torch.full((sample_b,), CFG["T"], dtype=torch.int64)
+    cores = min(host_cores(), 32)
+    torch.set_num_threads(cores)
+    log(f"[bench] cpu_baseline: oracle on {cores} threads (os.cpu_count()={os.cpu_count()}), B={sample_b}")
+    ts = []
+    with torch.no_grad():
+        for i in range(3):
+            t0 = time.perf_counter()
+            O.encoder_forward(x, L, P, CFG["n_blocks"], CFG["n_heads"])
+            ts.append(time.perf_counter() - t0)
+    t = sorted(ts[1:])[0] if len(ts) > 1 else ts[0]
+    return dict(value=sample_b * CFG["T"] / t, unit="audio-frames/sec", cores=cores, kind="port",
+                sample=f"oracle Encoder.forward fp32, B={sample_b} of 32, T=1000, 16 blocks, best of 2 after 1 warm-up "
+                       f"({t:.2f} s/run, torch {torch.get_num_threads()} threads)")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the Conformer hot path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_
+        dist = dist_
+        dist.init_process_group("nccl", device_id=dev)     # "nccl" is RCCL on ROCm
+    if args.gpus != world and rank == 0:
+        log(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; reporting n_gpus={world}")
+
+    from conformer_amd import _lib
+    _lib.check(_lib.load().cfm_device_check(), "cfm_device_check")
+    from model.modules.encoder import Encoder
+
+    torch.manual_seed(0)
+    enc = Encoder(CFG["n_mel"], CFG["n_blocks"], CFG["d"], CFG["n_heads"], CFG["ksize"], 0.0).to(dev).eval()
+    g = torch.Generator().manual_seed(1234 + rank)
+    x = torch.randn(CFG["B"], CFG["n_mel"], CFG["T"], generator=g).to(dev)          # resident in HBM before timing
+    lengths = torch.full((CFG["B"],), CFG["T"], dtype=torch.int64, device=dev)
+
+    def step():
+        with torch.no_grad():
+            return enc(x, lengths)
+
+    log(f"[bench] rank {rank}/{world}: model on {dev}, warm-up {args.warmup} steps")
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        y, _ = step()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    if not torch.isfinite(y).all():
+        raise SystemExit("non-finite encoder output")
+
+    frames = world * CFG["B"] * CFG["T"] * args.steps
+    ms = dt / args.steps * 1e3
+    log(f"[bench] {args.steps} steps in {dt:.3f} s -> {ms:.2f} ms/step, {frames / dt:,.0f} frames/s")
+    flops = algorithmic_flops(CFG["B"], CFG["T"], CFG["d"], CFG["n_blocks"], CFG["ksize"])
+    out = {
+        "metric": "encoder audio-frames/sec (B=32,T=1000,d=512,L=16)",
+        "value": frames / dt, "unit": "audio-frames/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "cfg2 Conformer-L Encoder.forward: B=32/GPU, T=1000 mel frames (T'=249), d=512, 16 blocks, "
+                               "8 heads, k=31, fp32, eval, random-init weights, batch-sharded replicas",
+                   "per_gpu_batch": CFG["B"], "mel_frames": CFG["T"]},
+        "path_tflops": flops / (ms * 1e-3) / 1e12,
+        "path_frac_of_mfma_f32_peak": flops / (ms * 1e-3) / 1e12 / PEAK_MFMA_F32_TFLOPS,
+    }
+
+    if rank == 0 and not args.no_roofline:
+        rows = gemm_site_table(enc, x, iters=10)
+        tot = sum(r["avg_ms"] * r["launches_per_step"] for r in rows)
+        dom = max(rows, key=lambda r: r["avg_ms"] * r["launches_per_step"])
+        out["roofline"] = {
+            "bound": "mfma", "kernel": dom["kernel"], "shape_MNK": [dom["M"], dom["N"], dom["K"]],
+            "achieved": dom["tflops"], "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s",
+            "frac": dom["tflops"] / PEAK_MFMA_F32_TFLOPS, "traffic": None,
+            "avg_launch_ms": dom["avg_ms"], "launches_per_step": dom["launches_per_step"],
+            "gemm_ms_per_step": tot, "gemm_share_of_step": tot / ms,
+            "all_gemm_sites": [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in r.items() if k != "flops"}
+                               for r in rows],
+        }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(enc, sample_b=4)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
