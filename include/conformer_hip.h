@@ -115,6 +115,11 @@ int cfm_subsample_conv2_relu_f32(const float* h1, const float* w2p, const float*
                                  int B, int F1, int T1, int C, cfm_stream_t stream);
 int cfm_pack_linear_weight_f32(const float* wl, float* wlp, int d_out, int C, int F2, cfm_stream_t stream);
 
+/* ---- tuning / diagnostics: the residual-epilogue GEMM with a forced block-tile shape
+ *      (cfg 0..3 = 128x128, 128x64, 64x128, 64x64; -1 = built-in heuristic).  Same results for every cfg. */
+int cfm_debug_gemm_cfg_f32(int cfg, const float* A, const float* W, const float* bias, const float* R,
+                           float alpha, float* C, int64_t M, int N, int K, cfm_stream_t stream);
+
 /* ---- integer helpers of the path (host-side, no device work) ---------------------------------
  *      frames after the stem: ((n-1)/2-1)/2, convolution.py:55 */
 int64_t cfm_subsampled_length(int64_t n);
