@@ -141,7 +141,7 @@ def cpu_baseline(enc, sample_b):
             ts.append(time.perf_counter() - t0)
     t = sorted(ts[1:])[0] if len(ts) > 1 else ts[0]
     return dict(value=sample_b * CFG["T"] / t, unit="audio-frames/sec", cores=cores, kind="port",
-                sample=f"oracle Encoder.forward fp32, B={sample_b} of 32, T=1000, 16 blocks, best of 2 after 1 warm-up "
+                sample=f"oracle Encoder.forward fp32 on the same weights, B={sample_b} of 32, T=1000, 16 blocks, best of 2 after 1 warm-up "
                        f"({t:.2f} s/run, torch {torch.get_num_threads()} threads)")
 
 
@@ -235,7 +235,7 @@ def main():
                                for r in rows],
         }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(enc, sample_b=4)
+        out["cpu_baseline"] = cpu_baseline(enc, sample_b=32)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist:
