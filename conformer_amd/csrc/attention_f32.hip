@@ -2,24 +2,30 @@
 //
 //   score[i,k] = ((q_i+u).k_k + (q_i+v).p_{r=i-k}) / sqrt(dh);  P = softmax_k(score);  ctx = P.V
 //
-// Flash-style: the (B,H,T,T) / (B,H,T,2T-1) score tensors of the reference never exist.  One wave64 owns
-// 32 query rows of one (batch, head) and sweeps the keys in tiles of 32 with an online softmax.  Every
-// product runs on v_mfma_f32_32x32x2_f32 in the TRANSPOSED orientation (keys / band rows / head dims on
-// the MFMA row axis, queries on the lane axis):
+// Flash-style: the (B,H,T,T) / (B,H,T,2T-1) score tensors of the reference never exist.  A workgroup = 4 waves =
+// 128 query rows of one (batch, head); each wave owns 32 queries and the workgroup sweeps the keys in tiles of 32
+// with an online softmax.  Every product runs on v_mfma_f32_32x32x2_f32 in the TRANSPOSED orientation (keys / band
+// rows / head dims on the MFMA row axis, queries on the lane axis):
 //   S^T = K . (Q+u)^T                       keys x queries        4*NC MFMAs
-//   G^T = Pband . (Q+v)^T                    63-row band x queries 8*NC MFMAs; band row jj <-> r = i0-k0-31+jj
-//   S^T[kk][i] += G^T[i-kk+31][i]            the "relative shift" = a per-lane column skew; done through a
-//                                            per-wave LDS tile in which every lane only touches its own bank
-//   O^T += V^T . P^T                         P^T is consumed straight from the accumulator registers (the
-//                                            softmax row reductions are in-lane + one cross-half shuffle)
-// Operands stream from L2 straight into registers (K/V/pos of one head are 64-127 KB and shared by the
-// 4 waves of a block and by the 2 blocks of a head); the only LDS use is the skew tile.
-// Key-padding mask: keys >= lengths[b] are skipped entirely (identical to the reference's finfo.min fill
-// because exp underflows to exactly 0; lengths[b] <= 0 reproduces its uniform-softmax degenerate case).
+//   G^T = Pband . (Q+v)^T                    64-row band x queries 8*NC MFMAs; band row jj <-> r = i0-k0-31+jj
+//   S^T[kk][i] += G^T[i-kk+31][i]            the "relative shift" = a per-lane column skew through a 4 KB per-wave
+//                                            LDS tile in which every lane only ever touches its own bank
+//   O^T += V^T . P^T                         P^T is consumed straight from the accumulator registers (the softmax
+//                                            row reductions are in-lane + one cross-half shuffle)
+// LDS staging (75 KB / workgroup, 2 workgroups per CU): the K and V tiles (shared by the 4 waves) and a 160-row RING
+// of projected-position rows: the union of the four waves' bands for one key tile is 160 consecutive table rows and
+// moves by exactly 32 rows per key tile, so each step streams 8 KB of K, V and P each -- full 256-byte rows, loaded one
+// tile ahead into registers and written to LDS between two barriers.  K/P rows are padded to 272 B: conflict-free
+// ds_read_b128 fragment reads.
+// Key-padding mask: keys >= lengths[b] are skipped entirely (identical to the reference's finfo.min fill because exp
+// underflows to exactly 0; lengths[b] <= 0 reproduces its uniform-softmax degenerate case).
 #include "cfm_common.h"
 #include <math.h>
 
 namespace {
+
+constexpr int KROW = 68;                 // padded LDS row (floats) of the K tile and the P ring
+constexpr int RING = 160;                // P ring rows = 4 waves x 32 + 32 (band overlap)
 
 struct AttnArgs {
     const float* q; const float* k; const float* v; int64_t ld;
@@ -30,14 +36,19 @@ struct AttnArgs {
 
 template <int NC, int ND>
 __global__ __launch_bounds__(256, 2) void relpos_attn_fwd_kernel(const AttnArgs a) {
-    __shared__ float skew[4][64 * 32];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __shared__ __attribute__((aligned(16))) float smem[32 * KROW + 32 * 64 + RING * KROW + 4 * 32 * 32];
+    float* Ks = smem;                            // [32][KROW]
+    float* Vs = Ks + 32 * KROW;                  // [32][64]
+    float* Pr = Vs + 32 * 64;                    // [RING][KROW]
+    float* gs = Pr + RING * KROW + (threadIdx.x >> 6) * 1024;   // per-wave skew tile [32][32]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, hf = lane >> 5;
     const int bh = blockIdx.y, b = bh / a.H, h = bh % a.H;
     const int T = a.T, dh = a.dh;
-    const int i0 = (blockIdx.x * 4 + wave) * 32;
-    if (i0 >= T) return;                                            // wave-uniform
-    float* gs = skew[wave];
+    const int q0 = blockIdx.x * 128;
+    const int i0 = q0 + wave * 32;
+    const bool active = i0 < T;                                    // wave-uniform; idle waves still stage + barrier
 
     int klen = T;
     bool uniform = false;
@@ -46,22 +57,80 @@ __global__ __launch_bounds__(256, 2) void relpos_attn_fwd_kernel(const AttnArgs 
         if (L <= 0) uniform = true;                                // every key masked -> uniform weights
         else if (L < T) klen = (int)L;
     }
+    const int ntiles = (klen + 31) / 32;
+
+    const float* kbase = a.k + (int64_t)b * T * a.ld + h * dh;
+    const float* vbase = a.v + (int64_t)b * T * a.ld + h * dh;
+    const float* pbase = a.pos + h * dh;
+    const int jmax = 2 * T - 2;
+    const int ring_bias = RING * ((T + 128 + q0) / RING + 2);      // makes (j + ring_bias) non-negative
+
+    // ---- cooperative staging: thread -> (row srow + 16*pass, 16-byte chunk sch) of a 32-row x 256-byte tile
+    const int srow = tid >> 4, sch = tid & 15;
+    const bool sok = sch * 4 < dh;
+    f32x4 pk[2], pv[2], pp[2];
+    auto prefetch = [&](int kt) {                                  // K/V tile kt and the 32 new ring rows of tile kt
+        const int k0 = kt * 32;
+        const int jnew = T - 1 - q0 + k0 + 31 - 31;                // new rows: j in [jnew, jnew+31] = top of the window
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int r = srow + 16 * p;
+            const int key = min(k0 + r, T - 1);
+            const int j = max(0, min(jnew + r, jmax));
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            pk[p] = sok ? *reinterpret_cast<const f32x4*>(kbase + (int64_t)key * a.ld + sch * 4) : z;
+            pv[p] = sok ? *reinterpret_cast<const f32x4*>(vbase + (int64_t)key * a.ld + sch * 4) : z;
+            pp[p] = sok ? *reinterpret_cast<const f32x4*>(pbase + (int64_t)j * a.ldp + sch * 4) : z;
+        }
+    };
+    auto commit = [&](int kt) {
+        const int k0 = kt * 32;
+        const int jnew = T - 1 - q0 + k0;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int r = srow + 16 * p;
+            *reinterpret_cast<f32x4*>(Ks + r * KROW + sch * 4) = pk[p];
+            *reinterpret_cast<f32x4*>(Vs + r * 64 + sch * 4) = pv[p];
+            const int slot = (jnew + r + ring_bias) % RING;
+            *reinterpret_cast<f32x4*>(Pr + slot * KROW + sch * 4) = pp[p];
+        }
+    };
+
+    // ---- prologue: ring rows [jlo, jlo+127] of tile 0 (the top 32 rows arrive with prefetch(0)), then tile 0
+    {
+        const int jlo = T - 1 - q0 - 128;
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            const int r = srow + 16 * p;                           // 0..127
+            const int j = max(0, min(jlo + r, jmax));
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            const f32x4 val = sok ? *reinterpret_cast<const f32x4*>(pbase + (int64_t)j * a.ldp + sch * 4) : z;
+            const int slot = (jlo + r + ring_bias) % RING;
+            *reinterpret_cast<f32x4*>(Pr + slot * KROW + sch * 4) = val;
+        }
+    }
+    prefetch(0);
+    commit(0);
+    if (ntiles > 1) prefetch(1);
+    __syncthreads();
 
     // ---- (Q+u)^T and (Q+v)^T as MFMA B operands: lane (query li, half hf) holds dims 8c+4hf+e at step 4c+e
-    const int qi = min(i0 + li, T - 1);
-    const float* qrow = a.q + ((int64_t)b * T + qi) * a.ld + h * dh;
     float qu[4 * NC], qv[4 * NC];
+    {
+        const int qi = min(i0 + li, T - 1);
+        const float* qrow = a.q + ((int64_t)b * T + qi) * a.ld + h * dh;
 #pragma unroll
-    for (int c = 0; c < NC; ++c) {
-        const int dd = 8 * c + 4 * hf;
-        f32x4 x = {0.f, 0.f, 0.f, 0.f}, uu = x, vv = x;
-        if (dd < dh) {
-            x = *reinterpret_cast<const f32x4*>(qrow + dd);
-            uu = *reinterpret_cast<const f32x4*>(a.u + h * dh + dd);
-            vv = *reinterpret_cast<const f32x4*>(a.vb + h * dh + dd);
+        for (int c = 0; c < NC; ++c) {
+            const int dd = 8 * c + 4 * hf;
+            f32x4 x = {0.f, 0.f, 0.f, 0.f}, uu = x, vv = x;
+            if (dd < dh) {
+                x = *reinterpret_cast<const f32x4*>(qrow + dd);
+                uu = *reinterpret_cast<const f32x4*>(a.u + h * dh + dd);
+                vv = *reinterpret_cast<const f32x4*>(a.vb + h * dh + dd);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { qu[4 * c + e] = x[e] + uu[e]; qv[4 * c + e] = x[e] + vv[e]; }
         }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { qu[4 * c + e] = x[e] + uu[e]; qv[4 * c + e] = x[e] + vv[e]; }
     }
 
     f32x16 o[ND];
@@ -71,95 +140,94 @@ __global__ __launch_bounds__(256, 2) void relpos_attn_fwd_kernel(const AttnArgs 
         for (int r = 0; r < 16; ++r) o[n][r] = 0.f;
     float mrow = -INFINITY, lrow = 0.f;
 
-    const float* kbase = a.k + (int64_t)b * T * a.ld + h * dh;
-    const float* vbase = a.v + (int64_t)b * T * a.ld + h * dh;
-    const float* pbase = a.pos + h * dh;
-
-    for (int k0 = 0; k0 < klen; k0 += 32) {
-        // ---- content scores S^T[key][query]
-        f32x16 sc;
+    for (int kt = 0; kt < ntiles; ++kt) {
+        const int k0 = kt * 32;
+        if (active) {
+            // ---- content scores S^T[key][query]
+            f32x16 sc;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) sc[r] = 0.f;
-        {
-            const float* krow = kbase + (int64_t)min(k0 + li, T - 1) * a.ld;
+            for (int r = 0; r < 16; ++r) sc[r] = 0.f;
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
-                const int dd = 8 * c + 4 * hf;
-                f32x4 kf = {0.f, 0.f, 0.f, 0.f};
-                if (dd < dh) kf = *reinterpret_cast<const f32x4*>(krow + dd);
+                const f32x4 kf = *reinterpret_cast<const f32x4*>(Ks + li * KROW + 8 * c + 4 * hf);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) sc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[e], qu[4 * c + e], sc, 0, 0, 0);
             }
-        }
-        // ---- positional band G^T[jj][query], jj = 0..63 <-> table row j = jbase - jj
-        const int jbase = T - 1 - i0 + k0 + 31;
+            // ---- positional band G^T[jj][query], jj = 32*mt + row <-> table row j = jbase - jj; skew through LDS
+            const int jbase = T - 1 - i0 + k0 + 31;
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-            int j = jbase - (32 * mt + li);
-            j = max(0, min(j, 2 * T - 2));                          // out-of-range rows only feed masked pairs
-            const float* prow = pbase + (int64_t)j * a.ldp;
-            f32x16 ga;
+            for (int mt = 0; mt < 2; ++mt) {
+                const int slot = (jbase - (32 * mt + li) + ring_bias) % RING;
+                const float* prow = Pr + slot * KROW + 4 * hf;
+                f32x16 ga;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) ga[r] = 0.f;
+                for (int r = 0; r < 16; ++r) ga[r] = 0.f;
 #pragma unroll
-            for (int c = 0; c < NC; ++c) {
-                const int dd = 8 * c + 4 * hf;
-                f32x4 pf = {0.f, 0.f, 0.f, 0.f};
-                if (dd < dh) pf = *reinterpret_cast<const f32x4*>(prow + dd);
+                for (int c = 0; c < NC; ++c) {
+                    const f32x4 pf = *reinterpret_cast<const f32x4*>(prow + 8 * c);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) ga = __builtin_amdgcn_mfma_f32_32x32x2f32(pf[e], qv[4 * c + e], ga, 0, 0, 0);
+                    for (int e = 0; e < 4; ++e) ga = __builtin_amdgcn_mfma_f32_32x32x2f32(pf[e], qv[4 * c + e], ga, 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) gs[((r & 3) + 8 * (r >> 2) + 4 * hf) * 32 + li] = ga[r];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int kk = (r & 3) + 8 * (r >> 2) + 4 * hf;
+                    const int jj = li - kk + 31;                    // 0..62
+                    if ((jj >> 5) == mt) sc[r] += gs[(jj & 31) * 32 + li];
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();                    // tile is rewritten by the next mt / key tile
             }
+            // ---- scale + mask, online softmax (query = lane column; keys = registers x 2 halves)
+            float p[16];
+            float tmax = -INFINITY;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) gs[(32 * mt + (r & 3) + 8 * (r >> 2) + 4 * hf) * 32 + li] = ga[r];
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-
-        // ---- skewed read + scale + mask, online softmax (query = lane column; keys = registers x 2 halves)
-        float p[16];
-        float tmax = -INFINITY;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int kk = (r & 3) + 8 * (r >> 2) + 4 * hf;
-            float s = (sc[r] + gs[(li - kk + 31) * 32 + li]) / a.sqrt_dh;
-            if (uniform) s = 0.f;
-            if (k0 + kk >= klen) s = -INFINITY;
-            p[r] = s;
-            tmax = fmaxf(tmax, s);
-        }
-        __builtin_amdgcn_wave_barrier();                            // skew tile is rewritten next iteration
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-        const float mnew = fmaxf(mrow, tmax);                       // finite: key k0 (< klen) is always valid
-        const float alpha = expf(mrow - mnew);
-        float psum = 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { p[r] = expf(p[r] - mnew); psum += p[r]; }
-        psum += __shfl_xor(psum, 32, 64);
-        lrow = lrow * alpha + psum;
-        mrow = mnew;
-#pragma unroll
-        for (int n = 0; n < ND; ++n)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[n][r] *= alpha;
-
-        // ---- O^T += V^T . P^T ; MFMA step s contracts key (s&3)+8*(s>>2)+4*hf = the key held in register s
-#pragma unroll
-        for (int n = 0; n < ND; ++n) {
-            const int dd = 32 * n + li;
-            const bool dok = dd < dh;
-#pragma unroll
-            for (int s = 0; s < 16; ++s) {
-                const int key = min(k0 + (s & 3) + 8 * (s >> 2) + 4 * hf, T - 1);
-                const float vv = dok ? vbase[(int64_t)key * a.ld + dd] : 0.f;
-                o[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv, p[s], o[n], 0, 0, 0);
+            for (int r = 0; r < 16; ++r) {
+                const int kk = (r & 3) + 8 * (r >> 2) + 4 * hf;
+                float s = sc[r] / a.sqrt_dh;
+                if (uniform) s = 0.f;
+                if (k0 + kk >= klen) s = -INFINITY;
+                p[r] = s;
+                tmax = fmaxf(tmax, s);
             }
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+            const float mnew = fmaxf(mrow, tmax);                   // finite: key k0 (< klen) is always valid
+            const float alpha = expf(mrow - mnew);
+            float psum = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { p[r] = expf(p[r] - mnew); psum += p[r]; }
+            psum += __shfl_xor(psum, 32, 64);
+            lrow = lrow * alpha + psum;
+            mrow = mnew;
+#pragma unroll
+            for (int n = 0; n < ND; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[n][r] *= alpha;
+            // ---- O^T += V^T . P^T ; MFMA step s contracts key (s&3)+8*(s>>2)+4*hf = the key held in register s
+#pragma unroll
+            for (int n = 0; n < ND; ++n)
+#pragma unroll
+                for (int s = 0; s < 16; ++s) {
+                    const float vv = Vs[((s & 3) + 8 * (s >> 2) + 4 * hf) * 64 + ((32 * n + li) & 63)];
+                    o[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv, p[s], o[n], 0, 0, 0);
+                }
+        }
+        // ---- rotate the staged tiles: everyone is done reading tile kt -> write tile kt+1 -> fetch tile kt+2
+        if (kt + 1 < ntiles) {
+            __syncthreads();
+            commit(kt + 1);
+            __syncthreads();
+            if (kt + 2 < ntiles) prefetch(kt + 2);
         }
     }
 
     // ---- normalise and store: lane = query row, registers = head dims (4 consecutive dims per r>>2 group)
-    const float inv = 1.0f / lrow;
-    if (i0 + li < T) {
+    if (active && i0 + li < T) {
+        const float inv = 1.0f / lrow;
         float* orow = a.ctx + ((int64_t)b * T + i0 + li) * a.ldo + h * dh;
 #pragma unroll
         for (int n = 0; n < ND; ++n)
@@ -187,7 +255,7 @@ extern "C" int cfm_relpos_attention_fwd_f32(const float* q, const float* k, cons
     CFM_REQUIRE(dh <= 64, CFM_ERR_UNSUPPORTED);
     CFM_REQUIRE(CFM_ALIGNED16(q) && CFM_ALIGNED16(k) && CFM_ALIGNED16(v) && CFM_ALIGNED16(pos) && CFM_ALIGNED16(u) &&
                 CFM_ALIGNED16(vbias) && CFM_ALIGNED16(ctx), CFM_ERR_ALIGN);
-    CFM_REQUIRE((int64_t)B * H <= 65535, CFM_ERR_UNSUPPORTED);
+    CFM_REQUIRE((int64_t)B * H <= 65535 && T < (1 << 28), CFM_ERR_UNSUPPORTED);
     AttnArgs a{q, k, v, ld, pos, ldp, u, vbias, lengths_or_null, ctx, ldo, lse_or_null, B, T, H, dh, sqrtf((float)dh)};
     const dim3 grid((unsigned)((T + 127) / 128), (unsigned)(B * H)), block(256);
     hipStream_t s = static_cast<hipStream_t>(stream);
