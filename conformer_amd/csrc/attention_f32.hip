@@ -31,7 +31,7 @@ struct AttnArgs {
     const float* q; const float* k; const float* v; int64_t ld;
     const float* pos; int64_t ldp; const float* u; const float* vb;
     const int64_t* lengths; float* ctx; int64_t ldo; float* lse;
-    int B, T, H, dh; float sqrt_dh;
+    int B, T, H, dh; float inv_sqrt_dh;
 };
 
 template <int NC, int ND>
@@ -188,7 +188,7 @@ __global__ __launch_bounds__(256, 2) void relpos_attn_fwd_kernel(const AttnArgs 
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int kk = (r & 3) + 8 * (r >> 2) + 4 * hf;
-                float s = sc[r] / a.sqrt_dh;
+                float s = sc[r] * a.inv_sqrt_dh;
                 if (uniform) s = 0.f;
                 if (k0 + kk >= klen) s = -INFINITY;
                 p[r] = s;
@@ -196,10 +196,10 @@ __global__ __launch_bounds__(256, 2) void relpos_attn_fwd_kernel(const AttnArgs 
             }
             tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
             const float mnew = fmaxf(mrow, tmax);                   // finite: key k0 (< klen) is always valid
-            const float alpha = expf(mrow - mnew);
+            const float alpha = exp_fast(mrow - mnew);
             float psum = 0.f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { p[r] = expf(p[r] - mnew); psum += p[r]; }
+            for (int r = 0; r < 16; ++r) { p[r] = exp_fast(p[r] - mnew); psum += p[r]; }
             psum += __shfl_xor(psum, 32, 64);
             lrow = lrow * alpha + psum;
             mrow = mnew;
@@ -256,7 +256,7 @@ extern "C" int cfm_relpos_attention_fwd_f32(const float* q, const float* k, cons
     CFM_REQUIRE(CFM_ALIGNED16(q) && CFM_ALIGNED16(k) && CFM_ALIGNED16(v) && CFM_ALIGNED16(pos) && CFM_ALIGNED16(u) &&
                 CFM_ALIGNED16(vbias) && CFM_ALIGNED16(ctx), CFM_ERR_ALIGN);
     CFM_REQUIRE((int64_t)B * H <= 65535 && T < (1 << 28), CFM_ERR_UNSUPPORTED);
-    AttnArgs a{q, k, v, ld, pos, ldp, u, vbias, lengths_or_null, ctx, ldo, lse_or_null, B, T, H, dh, sqrtf((float)dh)};
+    AttnArgs a{q, k, v, ld, pos, ldp, u, vbias, lengths_or_null, ctx, ldo, lse_or_null, B, T, H, dh, 1.0f / sqrtf((float)dh)};
     const dim3 grid((unsigned)((T + 127) / 128), (unsigned)(B * H)), block(256);
     hipStream_t s = static_cast<hipStream_t>(stream);
 #define ATT_LAUNCH(NC, ND) hipLaunchKernelGGL((relpos_attn_fwd_kernel<NC, ND>), grid, block, 0, s, a)

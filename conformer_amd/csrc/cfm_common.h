@@ -28,7 +28,14 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
-__device__ __forceinline__ float sigmoidf_acc(float x) { return 1.0f / (1.0f + expf(-x)); }
+// exp / sigmoid / swish on the hardware transcendental pipe: v_exp_f32 (2^x, 1 ulp) and v_rcp_f32 (1 ulp) instead of the
+// ~15-instruction libm expf and the ~10-instruction IEEE divide.  exp(x) = 2^(x*log2e): the rounding of x*log2e adds
+// |x|*2^-24 to the exponent, i.e. a relative error <= ~1.2e-7*(1+|x|) -- 1e-6 at |x| = 8, far inside the 1e-5 per-op
+// budget.  These sit in GEMM epilogues and the attention inner loop, where the accurate forms cost
+// up to a quarter of a short-K GEMM's run time.
+__device__ __forceinline__ float exp_fast(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
+__device__ __forceinline__ float rcp_fast(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float sigmoidf_acc(float x) { return rcp_fast(1.0f + exp_fast(-x)); }
 __device__ __forceinline__ float swishf_acc(float x) { return x * sigmoidf_acc(x); }
 
 // Bijective XCD-aware remap of a 1-D block id: blocks that share an XCD (id % 8 under the observed
