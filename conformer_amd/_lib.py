@@ -26,7 +26,7 @@ SIGNATURES = {
     "cfm_gemm_bias_relu_f32": (c_int, [_P, _P, _P, _P, _L, _I, _I, _L, _L, _P]),
     "cfm_gemm_bias_glu_f32": (c_int, [_P, _P, _P, _P, _L, _I, _I, _L, _L, _P]),
     "cfm_gemm_bias_residual_f32": (c_int, [_P, _P, _P, _P, _F, _P, _L, _I, _I, _L, _L, _L, _P]),
-    "cfm_debug_gemm_cfg_f32": (c_int, [_I, _P, _P, _P, _P, _F, _P, _L, _I, _I, _P]),
+    "cfm_debug_gemm_cfg_f32": (c_int, [_I, _P, _P, _P, _P, _F, _P, _L, _I, _I, _P, _P]),
     "cfm_relpos_table_f32": (c_int, [_P, _P, _I, _I, _P]),
     "cfm_relpos_attention_fwd_f32": (c_int, [_P, _P, _P, _L, _P, _L, _P, _P, _P, _P, _L, _P, _I, _I, _I, _I, _P]),
     "cfm_dwconv_bn_swish_fwd_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, _F, _P, _I, _I, _I, _I, _P]),

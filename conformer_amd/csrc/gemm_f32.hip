@@ -25,6 +25,7 @@ struct GemmArgs {
     int n_out;                      // GLU: output columns (N = 2*n_out)
     int cT2, cF2, cT1, cF1, cC;     // conv mode geometry
     unsigned tiles_m, tiles_n;
+    unsigned long long* trace;      // diagnostics: per-block {start, end} s_memrealtime stamps + HW id, or NULL
 };
 
 // ---- shared pieces --------------------------------------------------------------------------------------------
@@ -66,42 +67,63 @@ __device__ __forceinline__ int64_t a_k_offset(const GemmArgs& g, int k) {   // k
     return k;
 }
 
-// C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+// The MFMAs are issued with W fragments as the A operand and activation fragments as the B operand, so an accumulator
+// tile is C^T: lane (li, hf) holds output ROW m = tile_row + li and, in registers 4q..4q+3, the four CONSECUTIVE
+// columns n = tile_col + 8q + 4hf + {0,1,2,3}.  The epilogue therefore moves 16 bytes per lane per instruction
+// (bias / residual loads and the C store): 4x fewer memory instructions than a dword-per-lane epilogue -- the
+// epilogue of a short-K GEMM is store-ISSUE bound (17-22 us of a 160 us FFN GEMM before this change; per-block
+// timeline in profiles/r01_gemm_timeline.txt).
 template <int BM, int BN, int EPI, int TM, int TN>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const f32x16 (&acc)[TM][TN], int64_t m0, int n0,
                                               int wr, int wc, int li, int hf) {
-    if (EPI == EPI_GLU) {
-        const int col = n0 + wc * 32 + li;
-        if (col < g.n_out) {
-            const float bv = g.bias[col], bg = g.bias[g.n_out + col];
+    const int ncols = EPI == EPI_GLU ? g.n_out : g.N;
+    const bool vec_ok = ((g.ldc & 3) == 0) && ((ncols & 3) == 0) && (EPI != EPI_RESID || (g.ldr & 3) == 0) &&
+                        ((reinterpret_cast<uintptr_t>(g.C) & 15) == 0) &&
+                        (EPI != EPI_RESID || (reinterpret_cast<uintptr_t>(g.R) & 15) == 0);
 #pragma unroll
-            for (int mt = 0; mt < TM; ++mt)
+    for (int mt = 0; mt < TM; ++mt) {
+        const int64_t row = m0 + wr * (BM / 2) + mt * 32 + li;
+        if (row >= g.M) continue;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int64_t row = m0 + wr * (BM / 2) + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hf;
-                    if (row < g.M)
-                        g.C[row * g.ldc + col] = (acc[mt][0][r] + bv) * sigmoidf_acc(acc[mt][TN - 1][r] + bg);
+        for (int nt = 0; nt < (EPI == EPI_GLU ? 1 : TN); ++nt)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int col = n0 + (EPI == EPI_GLU ? wc * 32 : wc * (BN / 2) + nt * 32) + 8 * q + 4 * hf;
+                if (col >= ncols) continue;
+                float v[4];
+                if (vec_ok) {                                                  // col + 3 < ncols because ncols % 4 == 0
+                    const f32x4 bb = *reinterpret_cast<const f32x4*>(g.bias + col);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = acc[mt][nt][4 * q + e] + bb[e];
+                    if (EPI == EPI_GLU) {
+                        const f32x4 bg = *reinterpret_cast<const f32x4*>(g.bias + g.n_out + col);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] *= sigmoidf_acc(acc[mt][TN - 1][4 * q + e] + bg[e]);
+                    }
+                    if (EPI == EPI_RESID) {
+                        const f32x4 rr = *reinterpret_cast<const f32x4*>(g.R + row * g.ldr + col);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = g.alpha * v[e] + rr[e];
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (EPI == EPI_SWISH) v[e] = swishf_acc(v[e]);
+                        if (EPI == EPI_RELU) v[e] = fmaxf(v[e], 0.f);
+                    }
+                    *reinterpret_cast<f32x4*>(g.C + row * g.ldc + col) = f32x4{v[0], v[1], v[2], v[3]};
+                } else {                                                       // odd leading dims / widths: scalar path
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (col + e >= ncols) continue;
+                        float x = acc[mt][nt][4 * q + e] + g.bias[col + e];
+                        if (EPI == EPI_GLU) x *= sigmoidf_acc(acc[mt][TN - 1][4 * q + e] + g.bias[g.n_out + col + e]);
+                        if (EPI == EPI_RESID) x = g.alpha * x + g.R[row * g.ldr + col + e];
+                        if (EPI == EPI_SWISH) x = swishf_acc(x);
+                        if (EPI == EPI_RELU) x = fmaxf(x, 0.f);
+                        g.C[row * g.ldc + col + e] = x;
+                    }
                 }
-        }
-    } else {
-#pragma unroll
-        for (int nt = 0; nt < TN; ++nt) {
-            const int col = n0 + wc * (BN / 2) + nt * 32 + li;
-            if (col >= g.N) continue;
-            const float bb = g.bias[col];
-#pragma unroll
-            for (int mt = 0; mt < TM; ++mt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int64_t row = m0 + wr * (BM / 2) + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hf;
-                    if (row >= g.M) continue;
-                    float v = acc[mt][nt][r] + bb;
-                    if (EPI == EPI_SWISH) v = swishf_acc(v);
-                    if (EPI == EPI_RELU) v = fmaxf(v, 0.f);
-                    if (EPI == EPI_RESID) v = g.alpha * v + g.R[row * g.ldr + col];
-                    g.C[row * g.ldc + col] = v;
-                }
-        }
+            }
     }
 }
 
@@ -109,7 +131,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const f32x16 (&
     _Pragma("unroll") for (int e = 0; e < 4; ++e)                                                           \
     _Pragma("unroll") for (int mt = 0; mt < TM; ++mt)                                                       \
     _Pragma("unroll") for (int nt = 0; nt < TN; ++nt)                                                       \
-        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA[mt][e], FB[nt][e], acc[mt][nt], 0, 0, 0)
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(FB[nt][e], FA[mt][e], acc[mt][nt], 0, 0, 0)
 
 // ---- the kernel: register staging, K-tile 16 (any K % 4 == 0) ---------------------------------------------------
 template <int BM, int BN, int EPI, bool CONV>
@@ -129,6 +151,11 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 128) ? 3 : 4) void gemm_f3
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
     const int li = lane & 31, hf = lane >> 5;
+    if (g.trace && tid == 0) {                             // diagnostics only (tools/gemm_tune.py trace)
+        g.trace[8 * blockIdx.x + 0] = __builtin_amdgcn_s_memrealtime();
+        g.trace[8 * blockIdx.x + 2] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_ID
+        g.trace[8 * blockIdx.x + 3] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));  // XCC_ID
+    }
 
     // ---- staging assignment: thread -> (row, 16-byte chunk) for TM rows of A and TN rows of W
     const int chunk = tid & 3, srow = tid >> 2;
@@ -209,8 +236,14 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 128) ? 3 : 4) void gemm_f3
         k_step(kt + 1, ra0, rb0);
     }
     if (kt < nkt) k_step(kt, ra1, rb1);
+    if (g.trace && tid == 0) g.trace[8 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();   // main loop done
 
     gemm_epilogue<BM, BN, EPI, TM, TN>(g, acc, m0, n0, wr, wc, li, hf);
+    if (g.trace && tid == 0) {
+        g.trace[8 * blockIdx.x + 4] = __builtin_amdgcn_s_memrealtime();                        // epilogue issued
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        g.trace[8 * blockIdx.x + 5] = __builtin_amdgcn_s_memrealtime();                        // ... and drained
+    }
 }
 
 // ---- tile-shape selection ---------------------------------------------------------------------------------------
@@ -329,12 +362,18 @@ extern "C" int cfm_subsample_conv2_relu_f32(const float* h1, const float* w2p, c
 
 // Tuning / diagnostics: the residual-epilogue GEMM with a forced block-tile shape
 // (cfg 0..3 = 128x128, 128x64, 64x128, 64x64; -1 = the built-in choice).  Same results for every cfg.
+// trace_or_null: device buffer of 8 x uint64 per block: {start, main-loop end, HW_ID, XCC_ID, epilogue issued, epilogue
+// drained, -, -}; times in 100 MHz s_memrealtime ticks.
 extern "C" int cfm_debug_gemm_cfg_f32(int cfg, const float* A, const float* W, const float* bias, const float* R,
-                                      float alpha, float* C, int64_t M, int N, int K, cfm_stream_t stream) {
+                                      float alpha, float* C, int64_t M, int N, int K, void* trace_or_null,
+                                      cfm_stream_t stream) {
     GemmArgs g{}; g.A = A; g.W = W; g.bias = bias; g.C = C; g.M = M; g.N = N; g.K = K; g.lda = K; g.ldc = N;
-    g.R = R; g.ldr = N; g.alpha = alpha;
+    g.R = R; g.ldr = N; g.alpha = alpha; g.trace = static_cast<unsigned long long*>(trace_or_null);
     int st = check(g); if (st) return st;
     CFM_REQUIRE(R != nullptr, CFM_ERR_NULL);
-    CFM_REQUIRE(cfg >= -1 && cfg <= 3, CFM_ERR_BAD_SHAPE);
-    return launch<EPI_RESID, false>(g, static_cast<hipStream_t>(stream), cfg);
+    CFM_REQUIRE(cfg >= -1 && (cfg & 15) <= 3 && cfg < 48, CFM_ERR_BAD_SHAPE);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (cfg >= 32) return launch<EPI_SWISH, false>(g, s, cfg & 15);     // cfg + 32: swish epilogue (no residual read)
+    if (cfg >= 16) return launch<EPI_BIAS, false>(g, s, cfg & 15);      // cfg + 16: bias epilogue
+    return launch<EPI_RESID, false>(g, s, cfg);
 }

@@ -116,9 +116,12 @@ int cfm_subsample_conv2_relu_f32(const float* h1, const float* w2p, const float*
 int cfm_pack_linear_weight_f32(const float* wl, float* wlp, int d_out, int C, int F2, cfm_stream_t stream);
 
 /* ---- tuning / diagnostics: the residual-epilogue GEMM with a forced block-tile shape
- *      (cfg 0..3 = 128x128, 128x64, 64x128, 64x64; -1 = built-in heuristic).  Same results for every cfg. */
+ *      (cfg 0..3 = 128x128, 128x64, 64x128, 64x64; -1 = built-in heuristic).  Same results for every cfg.
+ *      trace_or_null: 8 x uint64 per block {start, main-loop end, HW_ID, XCC_ID, epilogue issued,
+ *      epilogue drained, -, -}; times in 100 MHz ticks. */
 int cfm_debug_gemm_cfg_f32(int cfg, const float* A, const float* W, const float* bias, const float* R,
-                           float alpha, float* C, int64_t M, int N, int K, cfm_stream_t stream);
+                           float alpha, float* C, int64_t M, int N, int K, void* trace_or_null,
+                           cfm_stream_t stream);
 
 /* ---- integer helpers of the path (host-side, no device work) ---------------------------------
  *      frames after the stem: ((n-1)/2-1)/2, convolution.py:55 */

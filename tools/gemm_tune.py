@@ -26,45 +26,54 @@ def one(M, N, K, cfg, iters):
     b = torch.randn(N, device=dev); r = torch.randn(M, N, device=dev); c = torch.empty(M, N, device=dev)
     for _ in range(iters):
         assert lib.cfm_debug_gemm_cfg_f32(cfg, a.data_ptr(), w.data_ptr(), b.data_ptr(), r.data_ptr(), 0.5,
-                                          c.data_ptr(), M, N, K, st) == 0
+                                          c.data_ptr(), M, N, K, None, st) == 0
     torch.cuda.synchronize()
 
 
-def ablate():
-    """Prices the refill path of the LDS-DMA engine: real kernel vs the same kernel without refills."""
+def trace(M, N, K, cfg):
+    """Per-block timeline of one launch: when blocks start / finish their main loop, per CU."""
+    import numpy as np
     lib = _lib.load()
     dev = torch.device("cuda:0")
     st = torch.cuda.current_stream().cuda_stream
-    for (M, N, K) in [(7968, 2048, 512), (7968, 512, 2048), (31872, 2048, 2048)]:
-        a = torch.randn(M, K, device=dev); w = torch.randn(N, K, device=dev) / K ** 0.5
-        b = torch.randn(N, device=dev); r = torch.randn(M, N, device=dev); c = torch.empty(M, N, device=dev)
-        for tile in (0, 1, 3):
-            line = f"{M}x{N}x{K} tile {CFG[tile]:>7s}: "
-            for eng in (0, 1, 2):
-                cfg = tile + 4 * eng
-
-                def run():
-                    assert lib.cfm_debug_gemm_cfg_f32(cfg, a.data_ptr(), w.data_ptr(), b.data_ptr(), r.data_ptr(), 0.5,
-                                                      c.data_ptr(), M, N, K, st) == 0
-                for _ in range(3):
-                    run()
-                torch.cuda.synchronize()
-                best = 1e9
-                for _ in range(5):
-                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    e0.record()
-                    for _ in range(20):
-                        run()
-                    e1.record()
-                    torch.cuda.synchronize()
-                    best = min(best, e0.elapsed_time(e1) / 20)
-                line += f"| {ENG[eng]:>12s} {best * 1e3:7.1f}us {2.0 * M * N * K / best / 1e9:6.1f}TF "
-            print(line, flush=True)
+    a = torch.randn(M, K, device=dev); w = torch.randn(N, K, device=dev) / K ** 0.5
+    b = torch.randn(N, device=dev); r = torch.randn(M, N, device=dev); c = torch.empty(M, N, device=dev)
+    bm, bn = [(128, 128), (128, 64), (64, 128), (64, 64)][cfg & 15]
+    nblk = ((M + bm - 1) // bm) * ((N + bn - 1) // bn)
+    tr = torch.zeros(nblk, 8, dtype=torch.int64, device=dev)
+    for it in range(3):
+        assert lib.cfm_debug_gemm_cfg_f32(cfg, a.data_ptr(), w.data_ptr(), b.data_ptr(), r.data_ptr(), 0.5,
+                                          c.data_ptr(), M, N, K, tr.data_ptr(), st) == 0
+        torch.cuda.synchronize()
+    t = tr.cpu().numpy()
+    t0 = t[:, 0].min()
+    start = (t[:, 0] - t0) / 100.0      # us
+    end = (t[:, 1] - t0) / 100.0
+    hw = t[:, 2]; xcc = t[:, 3] & 0xF
+    cu = ((hw >> 8) & 0xF) | (((hw >> 12) & 1) << 4) | (((hw >> 13) & 7) << 5)   # CU_ID | SH_ID | SE_ID
+    key = xcc * 1024 + cu
+    print(f"{M}x{N}x{K} cfg {cfg}: {nblk} blocks; main loops end at {end.max():.1f} us after the first block start")
+    print(f"  block start: p0 {start.min():.1f} p50 {np.median(start):.1f} p90 {np.percentile(start, 90):.1f} max {start.max():.1f} us")
+    epi_i = (t[:, 4] - t0) / 100.0 - end
+    epi_d = (t[:, 5] - t0) / 100.0 - end
+    print(f"  epilogue (wave 0): issued after p50 {np.median(epi_i):.1f} p90 {np.percentile(epi_i, 90):.1f} max {epi_i.max():.1f} us; "
+          f"drained after p50 {np.median(epi_d):.1f} p90 {np.percentile(epi_d, 90):.1f} max {epi_d.max():.1f} us")
+    dur = end - start
+    print(f"  main-loop duration per block: min {dur.min():.1f} p50 {np.median(dur):.1f} p90 {np.percentile(dur, 90):.1f} max {dur.max():.1f} us")
+    hist, edges = np.histogram(end, bins=12)
+    print("  main-loop END histogram (us):", " ".join(f"{edges[i]:.0f}:{hist[i]}" for i in range(len(hist))))
+    hist, edges = np.histogram(start, bins=12)
+    print("  block START histogram (us):  ", " ".join(f"{edges[i]:.0f}:{hist[i]}" for i in range(len(hist))))
+    ucu, cnt = np.unique(key, return_counts=True)
+    print(f"  distinct (xcc,cu) ids seen: {len(ucu)}; blocks per CU: min {cnt.min()} max {cnt.max()}")
+    # concurrency over time: how many blocks are in their main loop
+    ts = np.linspace(0, end.max(), 16)
+    print("  blocks in main loop at t(us):", " ".join(f"{x:.0f}:{int(((start <= x) & (end > x)).sum())}" for x in ts))
 
 
 def main():
-    if len(sys.argv) == 2 and sys.argv[1] == "ablate":
-        return ablate()
+    if len(sys.argv) == 6 and sys.argv[1] == "trace":
+        return trace(int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]))
     if len(sys.argv) >= 5:
         return one(int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]),
                    int(sys.argv[5]) if len(sys.argv) > 5 else 10)
@@ -82,7 +91,7 @@ def main():
 
             def run():
                 s = lib.cfm_debug_gemm_cfg_f32(cfg, a.data_ptr(), w.data_ptr(), b.data_ptr(), r.data_ptr(), 0.5,
-                                               c.data_ptr(), M, N, K, st)
+                                               c.data_ptr(), M, N, K, None, st)
                 assert s == 0, s
             for _ in range(3):
                 run()
