@@ -25,6 +25,7 @@ struct GemmArgs {
     int n_out;                      // GLU: output columns (N = 2*n_out)
     int cT2, cF2, cT1, cF1, cC;     // conv mode geometry
     unsigned tiles_m, tiles_n;
+    int occ_cap;                    // 0 = natural; else blocks/CU cap enforced through a dynamic-LDS pad
     unsigned long long* trace;      // diagnostics: per-block {start, end} s_memrealtime stamps + HW id, or NULL
 };
 
@@ -257,6 +258,7 @@ inline int choose_tile(int64_t M, int ncols, bool glu) {
     const int64_t n128 = ((M + 127) / 128) * ((ncols + bn - 1) / bn);
     if (n128 >= 12 * 256) return 0;
     if (glu) return 2;
+    if (n128 > 690 && n128 <= 768) return 0;      // exactly one full round at 3 blocks/CU (fused QKV: 756 tiles)
     if (n128 >= 3 * 256) return 1;
     return 3;
 }
@@ -267,7 +269,15 @@ int launch_cfg(GemmArgs g, hipStream_t s) {
     const int bn = EPI == EPI_GLU ? BN / 2 : BN;
     g.tiles_m = (unsigned)((g.M + BM - 1) / BM);
     g.tiles_n = (unsigned)((ncols + bn - 1) / bn);
-    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, EPI, CONV>), dim3(g.tiles_m * g.tiles_n), dim3(256), 0, s, g);
+    // Occupancy control: a CU has 160 KiB of LDS; asking for extra (unused) dynamic LDS caps the resident blocks per
+    // CU so that tiles / (256 * blocks_per_CU) lands just under an integer number of rounds (no half-empty last round).
+    constexpr int kStatic = 2 * (BM + BN) * 20 * 4;
+    size_t pad = 0;
+    if (g.occ_cap > 0) {
+        const int per = (160 * 1024) / g.occ_cap;
+        pad = per > kStatic ? (size_t)((per - kStatic) & ~255) : 0;
+    }
+    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, EPI, CONV>), dim3(g.tiles_m * g.tiles_n), dim3(256), pad, s, g);
     return cfm_launch_status();
 }
 
@@ -371,6 +381,8 @@ extern "C" int cfm_debug_gemm_cfg_f32(int cfg, const float* A, const float* W, c
     g.R = R; g.ldr = N; g.alpha = alpha; g.trace = static_cast<unsigned long long*>(trace_or_null);
     int st = check(g); if (st) return st;
     CFM_REQUIRE(R != nullptr, CFM_ERR_NULL);
+    g.occ_cap = cfg >= 0 ? (cfg >> 8) : 0;            // cfg + 256*cap: blocks/CU cap
+    if (cfg >= 0) cfg &= 255;
     CFM_REQUIRE(cfg >= -1 && (cfg & 15) <= 3 && cfg < 48, CFM_ERR_BAD_SHAPE);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (cfg >= 32) return launch<EPI_SWISH, false>(g, s, cfg & 15);     // cfg + 32: swish epilogue (no residual read)

@@ -29,6 +29,7 @@ class Encoder(nn.Module):
         self.layers = nn.ModuleList([ConformerBlock(d_model=d_model, n_heads=n_heads, kernel_size=kernel_size,
                                                     dropout_rate=dropout_rate) for _ in range(n_blocks)])
         self._packs = PackCache()
+        self.cache_projected_positions = False
 
     def forward(self, x: torch.Tensor, lengths: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
         require_inference(self, "Encoder", x)
@@ -45,6 +46,24 @@ class Encoder(nn.Module):
             if STRICT and int(out_len.max()) != n_frames:
                 raise RuntimeError(f"lengths.max() after subsampling must equal T'={n_frames}")
         table = self.rel_pe.table(n_frames)
-        for layer in self.layers:
-            h = layer.fused(h, table, out_len)
+        pos_all = self._projected_positions(table)
+        for i, layer in enumerate(self.layers):
+            h = layer.fused(h, table, out_len, None if pos_all is None else pos_all[:, i * d:(i + 1) * d])
         return h, out_len
+
+    def _projected_positions(self, table: torch.Tensor) -> Optional[torch.Tensor]:
+        """pos_proj of every layer applied to the (2T'-1, d) table in ONE MFMA GEMM: (2T'-1, d) x (L*d, d)^T.
+        Layer i reads columns [i*d, (i+1)*d) through the attention kernel's `ldp` row stride -- no per-layer pos
+        GEMM, no copies.  The result depends only on T' and the pos_proj parameters; it is nevertheless recomputed
+        on every forward (the weight concatenation alone is cached) unless `cache_projected_positions` is set, which
+        an inference service with frozen weights may do (then it is keyed on the parameters' identity/version)."""
+        if len(self.layers) == 0:
+            return None
+        ws = [l.attention.attention.pos_proj.weight for l in self.layers]
+        bs = [l.attention.attention.pos_proj.bias for l in self.layers]
+
+        w = self._packs.get("pos_w", ws, lambda: torch.cat([t.detach() for t in ws], dim=0).contiguous())
+        b = self._packs.get("pos_b", bs, lambda: torch.cat([t.detach() for t in bs], dim=0).contiguous())
+        if self.cache_projected_positions:
+            return self._packs.get("pos_all", (w, b, table), lambda: ops.linear(table, w, b))
+        return ops.linear(table, w, b)

@@ -50,15 +50,20 @@ class RelativeMultiHeadAttention(nn.Module):
         b = self._packs.get("qkv_b", bs, lambda: torch.cat([t.detach() for t in bs], dim=0).contiguous())
         return w, b
 
-    def context(self, x: torch.Tensor, pos_table: torch.Tensor, lengths: Optional[torch.Tensor]) -> torch.Tensor:
-        """x: (B,T,d) already layer-normed; pos_table: (2T-1,d) un-projected; returns concat-head context."""
+    def context(self, x: torch.Tensor, pos_table: torch.Tensor, lengths: Optional[torch.Tensor],
+                pos_projected: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """x: (B,T,d) already layer-normed; pos_table: (2T-1,d) un-projected; returns concat-head context.
+        `pos_projected` (a (2T-1,d) view, any row stride) is this layer's slice of the encoder-wide batched
+        pos_proj GEMM (Encoder._projected_positions); without it the projection runs here."""
         w, b = self._qkv_params()
         qkv = ops.linear(x, w, b)
-        pos = ops.linear(pos_table, self.pos_proj.weight, self.pos_proj.bias)
+        pos = pos_projected if pos_projected is not None else \
+            ops.linear(pos_table, self.pos_proj.weight, self.pos_proj.bias)
         return ops.relpos_attention(qkv, pos, self.content_bias, self.position_bias, lengths, self.n_heads)
 
-    def fused(self, x, pos_table, lengths, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
-        ctx = self.context(x, pos_table, lengths)
+    def fused(self, x, pos_table, lengths, residual: Optional[torch.Tensor] = None,
+              pos_projected: Optional[torch.Tensor] = None) -> torch.Tensor:
+        ctx = self.context(x, pos_table, lengths, pos_projected)
         if residual is None:
             return ops.linear(ctx, self.out_proj.weight, self.out_proj.bias)
         return ops.linear_residual(ctx, self.out_proj.weight, self.out_proj.bias, residual, 1.0)
@@ -82,10 +87,11 @@ class MultiHeadSelfAttentionModule(nn.Module):
         self.attention = RelativeMultiHeadAttention(d_model=d_model, n_heads=n_heads, dropout_rate=dropout_rate)
         self.dropout = nn.Dropout(p=dropout_rate)
 
-    def fused(self, x, pos_table, lengths, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+    def fused(self, x, pos_table, lengths, residual: Optional[torch.Tensor] = None,
+              pos_projected: Optional[torch.Tensor] = None) -> torch.Tensor:
         require_inference(self, "MultiHeadSelfAttentionModule", x)
         xn = ops.layernorm(x, self.layer_norm.weight, self.layer_norm.bias, self.layer_norm.eps)
-        return self.attention.fused(xn, pos_table, lengths, residual)
+        return self.attention.fused(xn, pos_table, lengths, residual, pos_projected)
 
     def forward(self, x: torch.Tensor, pos_embedding: torch.Tensor, mask: Optional[torch.Tensor] = None):
         table = pos_embedding[0] if pos_embedding.dim() == 3 else pos_embedding

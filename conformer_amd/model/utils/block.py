@@ -25,9 +25,10 @@ class ConformerBlock(nn.Module):
         self.ffn_2 = FeedForwardModule(dim=d_model, dropout_rate=dropout_rate)
         self.layer_norm = nn.LayerNorm(normalized_shape=d_model)
 
-    def fused(self, x: torch.Tensor, pos_table: torch.Tensor, lengths: Optional[torch.Tensor]) -> torch.Tensor:
+    def fused(self, x: torch.Tensor, pos_table: torch.Tensor, lengths: Optional[torch.Tensor],
+              pos_projected: Optional[torch.Tensor] = None) -> torch.Tensor:
         y = self.ffn_1.fused(x, residual=x, alpha=0.5)
-        y = self.attention.fused(y, pos_table, lengths, residual=y)
+        y = self.attention.fused(y, pos_table, lengths, residual=y, pos_projected=pos_projected)
         y = self.conv.fused(y, residual=y)
         y = self.ffn_2.fused(y, residual=y, alpha=0.5)
         return ops.layernorm(y, self.layer_norm.weight, self.layer_norm.bias, self.layer_norm.eps)

@@ -100,15 +100,19 @@ def relpos_table(div_term: torch.Tensor, t: int) -> torch.Tensor:
 def relpos_attention(qkv: torch.Tensor, pos: torch.Tensor, u: torch.Tensor, v: torch.Tensor,
                      lengths: Optional[torch.Tensor], n_heads: int) -> torch.Tensor:
     """qkv: (B,T,3d) fused projections [q|k|v]; pos: (2T-1,d) projected table; returns ctx (B,T,d)."""
-    qkv = _req(qkv, "qkv"); pos = _req(pos, "pos"); u = _req(u, "content_bias"); v = _req(v, "position_bias")
+    qkv = _req(qkv, "qkv"); u = _req(u, "content_bias"); v = _req(v, "position_bias")
     B, T, d3 = qkv.shape
     d = d3 // 3
     dh = d // n_heads
+    if not (isinstance(pos, torch.Tensor) and pos.is_cuda and pos.dtype == torch.float32 and pos.dim() == 2
+            and pos.stride(1) == 1 and pos.shape == (2 * T - 1, d)):
+        raise _lib.ConformerHipError(f"pos: expected a ({2 * T - 1},{d}) fp32 HIP tensor with unit column stride")
+    ldp = pos.stride(0)
     if lengths is not None:
         lengths = _req(lengths, "lengths", torch.int64)
     ctx = torch.empty(B, T, d, device=qkv.device, dtype=qkv.dtype)
     base = qkv.data_ptr()
-    st = _lib.load().cfm_relpos_attention_fwd_f32(base, base + 4 * d, base + 8 * d, d3, pos.data_ptr(), d,
+    st = _lib.load().cfm_relpos_attention_fwd_f32(base, base + 4 * d, base + 8 * d, d3, pos.data_ptr(), ldp,
                                                   u.data_ptr(), v.data_ptr(), _p(lengths), ctx.data_ptr(), d, None,
                                                   B, T, n_heads, dh, _stream())
     _lib.check(st, "cfm_relpos_attention_fwd_f32")

@@ -71,7 +71,42 @@ def trace(M, N, K, cfg):
     print("  blocks in main loop at t(us):", " ".join(f"{x:.0f}:{int(((start <= x) & (end > x)).sum())}" for x in ts))
 
 
+def occ_sweep():
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    st = torch.cuda.current_stream().cuda_stream
+    for (M, N, K) in [(7968, 2048, 512), (7968, 512, 2048), (7968, 1536, 512), (7968, 512, 512), (7968, 1024, 512)]:
+        a = torch.randn(M, K, device=dev); w = torch.randn(N, K, device=dev) / K ** 0.5
+        b = torch.randn(N, device=dev); r = torch.randn(M, N, device=dev); c = torch.empty(M, N, device=dev)
+        for tile in (0, 1, 3):
+            bm, bn = [(128, 128), (128, 64), (64, 128), (64, 64)][tile]
+            tiles = ((M + bm - 1) // bm) * ((N + bn - 1) // bn)
+            line = f"{M}x{N}x{K} {CFG[tile]:>7s} ({tiles} tiles): "
+            for cap in (0, 2, 3, 4, 5, 6, 8):
+                cfg = tile + 256 * cap
+
+                def run():
+                    assert lib.cfm_debug_gemm_cfg_f32(cfg, a.data_ptr(), w.data_ptr(), b.data_ptr(), r.data_ptr(), 0.5,
+                                                      c.data_ptr(), M, N, K, None, st) == 0
+                for _ in range(3):
+                    run()
+                torch.cuda.synchronize()
+                best = 1e9
+                for _ in range(4):
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    for _ in range(20):
+                        run()
+                    e1.record()
+                    torch.cuda.synchronize()
+                    best = min(best, e0.elapsed_time(e1) / 20)
+                line += f"| cap{cap} {best * 1e3:6.1f}us {2.0 * M * N * K / best / 1e9:5.1f} "
+            print(line, flush=True)
+
+
 def main():
+    if len(sys.argv) == 2 and sys.argv[1] == "occ":
+        return occ_sweep()
     if len(sys.argv) == 6 and sys.argv[1] == "trace":
         return trace(int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]))
     if len(sys.argv) >= 5:
