@@ -26,6 +26,21 @@ SIGNATURES = {
     "cfm_gemm_bias_relu_f32": (c_int, [_P, _P, _P, _P, _L, _I, _I, _L, _L, _P]),
     "cfm_gemm_bias_glu_f32": (c_int, [_P, _P, _P, _P, _L, _I, _I, _L, _L, _P]),
     "cfm_gemm_bias_residual_f32": (c_int, [_P, _P, _P, _P, _F, _P, _L, _I, _I, _L, _L, _L, _P]),
+    "cfm_gemm_bias_swish_save_f32": (c_int, [_P, _P, _P, _P, _P, _L, _I, _I, _L, _L, _P]),
+    "cfm_gemm_bwd_f32": (c_int, [_P, _I, _L, _P, _I, _L, _P, _L, _F, _P, _L, _I, _I, _L, _I, _P]),
+    "cfm_gemm_bwd_batched_f32": (c_int, [_P, _I, _L, _P, _I, _L, _P, _L, _F, _P, _L, _I, _I, _L, _I, _I, _I, _I,
+                                         _L, _L, _L, _L, _L, _L, _P]),
+    "cfm_layernorm_bwd_dx_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, _L, _I, _P]),
+    "cfm_layernorm_bwd_params_f32": (c_int, [_P, _P, _P, _P, _P, _P, _L, _I, _P]),
+    "cfm_colsum_f32": (c_int, [_P, _L, _L, _I, _F, _P, _P]),
+    "cfm_glu_fwd_f32": (c_int, [_P, _P, _L, _I, _P]),
+    "cfm_glu_bwd_f32": (c_int, [_P, _P, _P, _L, _I, _P]),
+    "cfm_dwconv_bn_swish_bwd_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _P,
+                                            _I, _I, _I, _I, _P]),
+    "cfm_attn_qbias_f32": (c_int, [_P, _L, _P, _P, _P, _P, _L, _I, _P]),
+    "cfm_attn_rowdot_f32": (c_int, [_P, _P, _P, _I, _I, _I, _I, _P]),
+    "cfm_attn_softmax_bwd_f32": (c_int, [_P, _P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _I, _P]),
+    "cfm_add_strided_f32": (c_int, [_P, _L, _P, _L, _L, _I, _P]),
     "cfm_debug_gemm_cfg_f32": (c_int, [_I, _P, _P, _P, _P, _F, _P, _L, _I, _I, _P, _P]),
     "cfm_relpos_table_f32": (c_int, [_P, _P, _I, _I, _P]),
     "cfm_relpos_attention_fwd_f32": (c_int, [_P, _P, _P, _L, _P, _L, _P, _P, _P, _P, _L, _P, _I, _I, _I, _I, _P]),

@@ -1,0 +1,145 @@
+"""torch.autograd.Function wrappers: one Function per residual sub-layer of the Conformer block, so the backward of
+`alpha*module(LN(x)) + x` is computed by explicit gfx950 kernels end to end (no autograd-side adds, no eager ops).
+
+The reference relies on plain autograd over ~50 eager ops per block (train.py:239); here every Function saves the
+handful of activations its backward kernels need and returns the input gradient -- residual
+path already folded in -- plus all parameter gradients.  fp32 only; dropout p = 0; BatchNorm uses fixed (running)
+statistics in the backward provided here (train-mode batch statistics: not built yet, refused by the modules).
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+from torch.autograd import Function
+
+from . import ops
+
+
+def _flat(t: torch.Tensor) -> torch.Tensor:
+    return t.reshape(-1, t.shape[-1])
+
+
+class LayerNormFn(Function):
+    """y = LayerNorm(x) -- the block's closing norm (block.py:27)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps):
+        y, mean, rstd = ops.layernorm_train(x, weight, bias, eps)
+        ctx.save_for_backward(x, weight, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, mean, rstd = ctx.saved_tensors
+        dx, dw, db = ops.layernorm_bwd(x, weight, dy.contiguous(), mean, rstd)
+        return dx, dw, db, None
+
+
+class LinearFn(Function):
+    """y = x @ w.T + b with x needing no gradient (the batched positional projection, attention.py:81)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w)
+        return ops.linear(x, w, b)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        _, dw, db = ops.linear_bwd(_flat(x), w, _flat(dy.contiguous()), need_dx=False)
+        return None, dw, db
+
+
+class FeedForwardFn(Function):
+    """out = alpha * (W2 . swish(W1 . LN(x) + b1) + b2) + x        (ffn.py:15-23 + block.py:19,25)"""
+
+    @staticmethod
+    def forward(ctx, x, ln_w, ln_b, w1, b1, w2, b2, alpha, eps):
+        h0, mean, rstd = ops.layernorm_train(x, ln_w, ln_b, eps)
+        h, z = ops.linear_swish_save(h0, w1, b1)
+        out = ops.linear_residual(h, w2, b2, x, alpha)
+        ctx.save_for_backward(x, ln_w, mean, rstd, h0, z, h, w1, w2)
+        ctx.alpha = alpha
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, ln_w, mean, rstd, h0, z, h, w1, w2 = ctx.saved_tensors
+        dout = dout.contiguous()
+        d2 = _flat(dout)
+        # out-projection: d(pre-activation) = alpha * (dout . W2) * swish'(z); dW2 = alpha * dout^T . h
+        dz, dw2, db2 = ops.linear_bwd(_flat(h), w2, d2, alpha=ctx.alpha, Z=_flat(z))
+        dh0, dw1, db1 = ops.linear_bwd(_flat(h0), w1, dz)
+        dx, dlw, dlb = ops.layernorm_bwd(x, ln_w, dh0.view_as(x), mean, rstd, dres=dout)
+        return dx, dlw, dlb, dw1, db1, dw2, db2, None, None
+
+
+class SelfAttentionFn(Function):
+    """out = Wo . RelPosAttention(LN(x)) + bo + x                  (attention.py:14-18,47-102 + block.py:21)
+    `pos` is this layer's (2T-1, d) slice of the projected position table (it has its own graph through LinearFn)."""
+
+    @staticmethod
+    def forward(ctx, x, ln_w, ln_b, wq, bq, wk, bk, wv, bv, pos, u, vb, wo, bo, lengths, n_heads, eps):
+        h0, mean, rstd = ops.layernorm_train(x, ln_w, ln_b, eps)
+        wqkv = torch.cat([wq, wk, wv], dim=0)
+        bqkv = torch.cat([bq, bk, bv], dim=0)
+        qkv = ops.linear(h0, wqkv, bqkv)
+        att, lse = ops.relpos_attention_train(qkv, pos, u, vb, lengths, n_heads)
+        out = ops.linear_residual(att, wo, bo, x, 1.0)
+        ctx.save_for_backward(x, ln_w, mean, rstd, h0, wqkv, qkv, pos, u, vb, att, lse, wo,
+                              lengths if lengths is not None else torch.empty(0))
+        ctx.has_len = lengths is not None
+        ctx.n_heads = n_heads
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, ln_w, mean, rstd, h0, wqkv, qkv, pos, u, vb, att, lse, wo, lengths = ctx.saved_tensors
+        lengths = lengths if ctx.has_len else None
+        dout = dout.contiguous()
+        d = x.shape[-1]
+        datt, dwo, dbo = ops.linear_bwd(_flat(att), wo, _flat(dout))
+        dqkv, dpos, du, dvb = ops.relpos_attention_bwd(qkv, pos, u, vb, lengths, ctx.n_heads, att,
+                                                       lse, datt.view_as(att))
+        dh0, dwqkv, dbqkv = ops.linear_bwd(_flat(h0), wqkv, _flat(dqkv))
+        dx, dlw, dlb = ops.layernorm_bwd(x, ln_w, dh0.view_as(x), mean, rstd, dres=dout)
+        dwq, dwk, dwv = dwqkv[:d], dwqkv[d:2 * d], dwqkv[2 * d:]
+        dbq, dbk, dbv = dbqkv[:d], dbqkv[d:2 * d], dbqkv[2 * d:]
+        return dx, dlw, dlb, dwq, dbq, dwk, dbk, dwv, dbv, dpos, du, dvb, dwo, dbo, None, None, None
+
+
+class ConvModuleFn(Function):
+    """out = Wpw2 . swish(BN(dwconv(GLU(Wpw1 . LN(x))))) + x       (convolution.py:21-32 + block.py:23)
+    BatchNorm uses the FIXED statistics (bn_mean, bn_var) in forward and backward."""
+
+    @staticmethod
+    def forward(ctx, x, ln_w, ln_b, w1, b1, wd, bd, bn_w, bn_b, bn_mean, bn_var, w2, b2, eps_ln, eps_bn):
+        h0, mean, rstd = ops.layernorm_train(x, ln_w, ln_b, eps_ln)
+        z = ops.linear(h0, w1, b1)                                  # (B,T,2C) pre-activation kept for GLU'
+        g = ops.glu_fwd(z)
+        s = ops.dwconv_bn_swish(g, wd, bd, bn_w, bn_b, bn_mean, bn_var, eps_bn)
+        out = ops.linear_residual(s, w2, b2, x, 1.0)
+        ctx.save_for_backward(x, ln_w, mean, rstd, h0, z, g, s, w1, wd, bd, bn_w, bn_b, bn_mean, bn_var, w2)
+        ctx.eps_bn = eps_bn
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, ln_w, mean, rstd, h0, z, g, s, w1, wd, bd, bn_w, bn_b, bn_mean, bn_var, w2 = ctx.saved_tensors
+        dout = dout.contiguous()
+        ds, dw2, db2 = ops.linear_bwd(_flat(s), w2, _flat(dout))
+        dg, dwd, dbd, dbnw, dbnb = ops.dwconv_bn_swish_bwd(g, ds.view_as(g), wd, bd, bn_w, bn_b, bn_mean, bn_var,
+                                                           ctx.eps_bn)
+        dz = ops.glu_bwd(z, dg)
+        dh0, dw1, db1 = ops.linear_bwd(_flat(h0), w1, _flat(dz))
+        dx, dlw, dlb = ops.layernorm_bwd(x, ln_w, dh0.view_as(x), mean, rstd, dres=dout)
+        return dx, dlw, dlb, dw1, db1, dwd, dbd, dbnw, dbnb, None, None, dw2, db2, None, None
+
+
+def needs_grad(module: torch.nn.Module, *tensors: Optional[torch.Tensor]) -> bool:
+    """True when the call must go through the autograd Functions (grad mode on and something requires grad)."""
+    if not torch.is_grad_enabled():
+        return False
+    return any(isinstance(t, torch.Tensor) and t.requires_grad for t in tensors) or \
+        any(p.requires_grad for p in module.parameters())

@@ -1,0 +1,317 @@
+// Bandwidth-bound backward kernels of the Conformer block: LayerNorm, column sums (bias gradients), GLU, and the
+// depthwise-conv + BatchNorm(eval) + Swish core.  All fp32, (rows, channels) row-major, lanes along channels.
+// Parameter gradients are accumulated with fp32 atomics into caller-zeroed buffers (one atomic per wave-partial per
+// channel: contention is negligible next to the streaming reads).
+#include "cfm_common.h"
+
+namespace {
+
+// ---- LayerNorm backward, input gradient: one wave per row (same mapping as the forward kernel) --------------------
+//   xhat = (x-mean)*rstd, g = dy*gamma;  dx = rstd*(g - mean_d(g) - xhat*mean_d(g*xhat)) [+ dres]
+template <int VPL>
+__global__ __launch_bounds__(256) void layernorm_bwd_dx_kernel(
+    const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ dy,
+    const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ dres,
+    float* __restrict__ dx, int64_t rows, int d) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nvec = d >> 2;
+    const f32x4* xr = reinterpret_cast<const f32x4*>(x + row * d);
+    const f32x4* dyr = reinterpret_cast<const f32x4*>(dy + row * d);
+    const f32x4* g4 = reinterpret_cast<const f32x4*>(gamma);
+    const float mu = mean[row], rs = rstd[row];
+    f32x4 xh[VPL], gg[VPL];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        const int c = lane + i * 64;
+        if (c < nvec) {
+            xh[i] = (xr[c] - mu) * rs;
+            gg[i] = dyr[c] * g4[c];
+            s1 += (gg[i].x + gg[i].y) + (gg[i].z + gg[i].w);
+            s2 += (gg[i].x * xh[i].x + gg[i].y * xh[i].y) + (gg[i].z * xh[i].z + gg[i].w * xh[i].w);
+        }
+    }
+    s1 = wave_sum(s1) / (float)d;
+    s2 = wave_sum(s2) / (float)d;
+    f32x4* dxr = reinterpret_cast<f32x4*>(dx + row * d);
+    const f32x4* rr = dres ? reinterpret_cast<const f32x4*>(dres + row * d) : nullptr;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        const int c = lane + i * 64;
+        if (c < nvec) {
+            f32x4 v = (gg[i] - s1 - xh[i] * s2) * rs;
+            if (rr) v = v + rr[c];
+            dxr[c] = v;
+        }
+    }
+}
+
+// ---- LayerNorm backward, parameter gradients; also the generic column-sum (MODE 0) --------------------------------
+//   MODE 0: out0[c] += alpha * sum_r X[r][c]
+//   MODE 1: out0[c] (dgamma) += sum_r dy*xhat ; out1[c] (dbeta) += sum_r dy       (X = x, Y = dy)
+// block = 64 columns x 4 row-lanes; each block walks `rows_per_block` rows; LDS combine; one atomic per column per block.
+template <int MODE>
+__global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict__ X, const float* __restrict__ Y,
+                                                        const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                        int64_t ld, int64_t rows, int cols, int rows_per_block,
+                                                        float alpha, float* __restrict__ out0, float* __restrict__ out1) {
+    __shared__ float red[2][4][64];
+    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cx;
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
+    const int64_t r1 = min(rows, r0 + rows_per_block);
+    float a0 = 0.f, a1 = 0.f;
+    if (c < cols) {
+        for (int64_t r = r0 + ry; r < r1; r += 4) {
+            if (MODE == 0) {
+                a0 += X[r * ld + c];
+            } else {
+                const float dyv = Y[r * ld + c];
+                a0 += dyv * (X[r * ld + c] - mean[r]) * rstd[r];
+                a1 += dyv;
+            }
+        }
+    }
+    red[0][ry][cx] = a0;
+    red[1][ry][cx] = a1;
+    __syncthreads();
+    if (ry == 0 && c < cols) {
+        const float s0 = (red[0][0][cx] + red[0][1][cx]) + (red[0][2][cx] + red[0][3][cx]);
+        atomicAdd(out0 + c, (MODE == 0 ? alpha : 1.0f) * s0);
+        if (MODE == 1) atomicAdd(out1 + c, (red[1][0][cx] + red[1][1][cx]) + (red[1][2][cx] + red[1][3][cx]));
+    }
+}
+
+// ---- GLU forward on a stored pre-activation (training path: z is kept for the backward) --------------------------------
+__global__ __launch_bounds__(256) void glu_fwd_kernel(const float* __restrict__ z, float* __restrict__ y, int64_t rows,
+                                                      int n) {
+    const int nv = n >> 2;
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= rows * nv) return;
+    const int64_t r = idx / nv;
+    const int c = (int)(idx - r * nv) * 4;
+    const f32x4 a = *reinterpret_cast<const f32x4*>(z + r * 2 * n + c);
+    const f32x4 gt = *reinterpret_cast<const f32x4*>(z + r * 2 * n + n + c);
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = a[e] * sigmoidf_acc(gt[e]);
+    *reinterpret_cast<f32x4*>(y + r * n + c) = o;
+}
+
+// ---- GLU backward: y = a * sigmoid(g), z = [a | g] (rows, 2n) -> dz (rows, 2n) ----------------------------------------
+__global__ __launch_bounds__(256) void glu_bwd_kernel(const float* __restrict__ z, const float* __restrict__ dy,
+                                                      float* __restrict__ dz, int64_t rows, int n) {
+    const int nv = n >> 2;
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= rows * nv) return;
+    const int64_t r = idx / nv;
+    const int c = (int)(idx - r * nv) * 4;
+    const f32x4 a = *reinterpret_cast<const f32x4*>(z + r * 2 * n + c);
+    const f32x4 gt = *reinterpret_cast<const f32x4*>(z + r * 2 * n + n + c);
+    const f32x4 d = *reinterpret_cast<const f32x4*>(dy + r * n + c);
+    f32x4 da, dg;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float sg = sigmoidf_acc(gt[e]);
+        da[e] = d[e] * sg;
+        dg[e] = d[e] * a[e] * sg * (1.0f - sg);
+    }
+    *reinterpret_cast<f32x4*>(dz + r * 2 * n + c) = da;
+    *reinterpret_cast<f32x4*>(dz + r * 2 * n + n + c) = dg;
+}
+
+// ---- depthwise conv + BN(affine with fixed statistics) + Swish, backward ------------------------------------------------
+// forward: c = b + sum_j w[j] g[t+j-H];  u = (c - mu)*inv*gamma + beta;  y = u*sigmoid(u)
+// pass 1 (this kernel): recompute c,u from g; du = dy*swish'(u); dc = du*inv*gamma -> dc tensor;
+//                       per channel: dbeta += sum du, dgamma += sum du*(c-mu)*inv, dbias += sum dc,
+//                       dw[j] += sum_t dc[t]*g[t+j-H]
+// pass 2 (dwconv_plain_kernel with flipped taps): dg[t] = sum_j w[j] dc[t-j+H]
+template <int K, int TT>
+__global__ __launch_bounds__(256) void dwconv_bn_swish_bwd1_kernel(
+    const float* __restrict__ g, const float* __restrict__ dy, const float* __restrict__ w,
+    const float* __restrict__ bias, const float* __restrict__ bn_w, const float* __restrict__ bn_b,
+    const float* __restrict__ bn_mean, const float* __restrict__ bn_var, float eps, float* __restrict__ dc,
+    float* __restrict__ dw, float* __restrict__ dbias, float* __restrict__ dgamma, float* __restrict__ dbeta,
+    int T, int C) {
+    constexpr int HALF = (K - 1) / 2;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    const int t0 = (blockIdx.y * 4 + wave) * TT;
+    const int b = blockIdx.z;
+    if (t0 >= T) return;
+    const bool cok = c < C;
+    const int cc = cok ? c : C - 1;
+    float wr[K], dwacc[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) { wr[j] = w[(int64_t)cc * K + j]; dwacc[j] = 0.f; }
+    const float inv = 1.0f / sqrtf(bn_var[cc] + eps);
+    const float mu = bn_mean[cc], ga = bn_w[cc], be = bn_b[cc], bi = bias[cc];
+    const float* gb = g + (int64_t)b * T * C + cc;
+    const float* dyb = dy + (int64_t)b * T * C + cc;
+    float* dcb = dc + (int64_t)b * T * C + cc;
+    float gwin[TT + K - 1];
+#pragma unroll
+    for (int tau = 0; tau < TT + K - 1; ++tau) {
+        const int t = t0 + tau - HALF;
+        gwin[tau] = (t >= 0 && t < T) ? gb[(int64_t)t * C] : 0.f;
+    }
+    float s_du = 0.f, s_dux = 0.f, s_dc = 0.f;
+#pragma unroll
+    for (int o = 0; o < TT; ++o) {
+        const int t = t0 + o;
+        float cv = bi;
+#pragma unroll
+        for (int j = 0; j < K; ++j) cv = fmaf(wr[j], gwin[o + j], cv);
+        const float xh = (cv - mu) * inv;
+        const float u = xh * ga + be;
+        const float sg = sigmoidf_acc(u);
+        const float dyv = (t < T) ? dyb[(int64_t)t * C] : 0.f;
+        const float du = dyv * sg * (1.0f + u * (1.0f - sg));
+        const float dcv = du * inv * ga;
+        if (t < T && cok) dcb[(int64_t)t * C] = dcv;
+        s_du += du; s_dux += du * xh; s_dc += dcv;
+#pragma unroll
+        for (int j = 0; j < K; ++j) dwacc[j] = fmaf(dcv, gwin[o + j], dwacc[j]);
+    }
+    if (cok) {
+        atomicAdd(dbeta + c, s_du);
+        atomicAdd(dgamma + c, s_dux);
+        atomicAdd(dbias + c, s_dc);
+#pragma unroll
+        for (int j = 0; j < K; ++j) atomicAdd(dw + (int64_t)c * K + j, dwacc[j]);
+    }
+}
+
+// plain depthwise correlation y[t] = sum_j w[FLIP ? K-1-j : j] x[t+j-H] (no bias): the input-gradient pass
+template <int K, int TT, bool FLIP>
+__global__ __launch_bounds__(256) void dwconv_plain_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                           float* __restrict__ y, int T, int C) {
+    constexpr int HALF = (K - 1) / 2;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    const int t0 = (blockIdx.y * 4 + wave) * TT;
+    const int b = blockIdx.z;
+    if (t0 >= T) return;
+    const bool cok = c < C;
+    const int cc = cok ? c : C - 1;
+    float wr[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) wr[j] = w[(int64_t)cc * K + (FLIP ? K - 1 - j : j)];
+    float acc[TT];
+#pragma unroll
+    for (int o = 0; o < TT; ++o) acc[o] = 0.f;
+    const float* xb = x + (int64_t)b * T * C + cc;
+#pragma unroll
+    for (int tau = 0; tau < TT + K - 1; ++tau) {
+        const int t = t0 + tau - HALF;
+        const float v = (t >= 0 && t < T) ? xb[(int64_t)t * C] : 0.f;
+#pragma unroll
+        for (int o = 0; o < TT; ++o) {
+            const int j = tau - o;
+            if (j >= 0 && j < K) acc[o] = fmaf(wr[j], v, acc[o]);
+        }
+    }
+    float* yb = y + (int64_t)b * T * C + cc;
+#pragma unroll
+    for (int o = 0; o < TT; ++o) {
+        const int t = t0 + o;
+        if (t < T && cok) yb[(int64_t)t * C] = acc[o];
+    }
+}
+
+}  // namespace
+
+// dx = LayerNorm-backward(dy) [+ dres].  mean/rstd are the forward's saved per-row statistics.
+extern "C" int cfm_layernorm_bwd_dx_f32(const float* x, const float* gamma, const float* dy, const float* mean,
+                                        const float* rstd, const float* dres_or_null, float* dx, int64_t rows, int d,
+                                        cfm_stream_t stream) {
+    CFM_REQUIRE(x && gamma && dy && mean && rstd && dx, CFM_ERR_NULL);
+    CFM_REQUIRE(rows > 0 && d > 0 && (d & 3) == 0, CFM_ERR_BAD_SHAPE);
+    CFM_REQUIRE(d <= 8192, CFM_ERR_UNSUPPORTED);
+    CFM_REQUIRE(CFM_ALIGNED16(x) && CFM_ALIGNED16(dy) && CFM_ALIGNED16(dx) && CFM_ALIGNED16(gamma), CFM_ERR_ALIGN);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+#define LNB(V) hipLaunchKernelGGL(layernorm_bwd_dx_kernel<V>, grid, block, 0, s, x, gamma, dy, mean, rstd, dres_or_null, dx, rows, d)
+    if (d <= 256) LNB(1);
+    else if (d <= 512) LNB(2);
+    else if (d <= 1024) LNB(4);
+    else if (d <= 2048) LNB(8);
+    else LNB(32);
+#undef LNB
+    return cfm_launch_status();
+}
+
+// dgamma[c] += sum_r dy*xhat, dbeta[c] += sum_r dy   (caller zero-fills both)
+extern "C" int cfm_layernorm_bwd_params_f32(const float* x, const float* dy, const float* mean, const float* rstd,
+                                            float* dgamma, float* dbeta, int64_t rows, int d, cfm_stream_t stream) {
+    CFM_REQUIRE(x && dy && mean && rstd && dgamma && dbeta, CFM_ERR_NULL);
+    CFM_REQUIRE(rows > 0 && d > 0, CFM_ERR_BAD_SHAPE);
+    const int rpb = 128;
+    const dim3 grid((unsigned)((d + 63) / 64), (unsigned)((rows + rpb - 1) / rpb));
+    hipLaunchKernelGGL(colreduce_kernel<1>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), x, dy, mean, rstd,
+                       (int64_t)d, rows, d, rpb, 1.0f, dgamma, dbeta);
+    return cfm_launch_status();
+}
+
+// out[c] += alpha * sum_r X[r][c]   (bias gradients; caller zero-fills out)
+extern "C" int cfm_colsum_f32(const float* X, int64_t ld, int64_t rows, int cols, float alpha, float* out,
+                              cfm_stream_t stream) {
+    CFM_REQUIRE(X && out, CFM_ERR_NULL);
+    CFM_REQUIRE(rows > 0 && cols > 0 && ld >= cols, CFM_ERR_BAD_SHAPE);
+    const int rpb = 128;
+    const dim3 grid((unsigned)((cols + 63) / 64), (unsigned)((rows + rpb - 1) / rpb));
+    hipLaunchKernelGGL(colreduce_kernel<0>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), X, nullptr, nullptr,
+                       nullptr, ld, rows, cols, rpb, alpha, out, nullptr);
+    return cfm_launch_status();
+}
+
+extern "C" int cfm_glu_fwd_f32(const float* z, float* y, int64_t rows, int n, cfm_stream_t stream) {
+    CFM_REQUIRE(z && y, CFM_ERR_NULL);
+    CFM_REQUIRE(rows > 0 && n > 0 && (n & 3) == 0, CFM_ERR_BAD_SHAPE);
+    CFM_REQUIRE(CFM_ALIGNED16(z) && CFM_ALIGNED16(y), CFM_ERR_ALIGN);
+    const int64_t total = rows * (n / 4);
+    hipLaunchKernelGGL(glu_fwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), z, y, rows, n);
+    return cfm_launch_status();
+}
+
+extern "C" int cfm_glu_bwd_f32(const float* z, const float* dy, float* dz, int64_t rows, int n, cfm_stream_t stream) {
+    CFM_REQUIRE(z && dy && dz, CFM_ERR_NULL);
+    CFM_REQUIRE(rows > 0 && n > 0 && (n & 3) == 0, CFM_ERR_BAD_SHAPE);
+    CFM_REQUIRE(CFM_ALIGNED16(z) && CFM_ALIGNED16(dy) && CFM_ALIGNED16(dz), CFM_ERR_ALIGN);
+    const int64_t total = rows * (n / 4);
+    hipLaunchKernelGGL(glu_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), z, dy, dz, rows, n);
+    return cfm_launch_status();
+}
+
+// Backward of cfm_dwconv_bn_swish_fwd_f32 (BatchNorm with FIXED statistics bn_mean/bn_var -- eval mode, or train mode
+// once the batch statistics have been computed and the mean/var coupling terms are added by the caller).
+// Outputs: dg (B,T,C); dc_ws (B,T,C) workspace; dw (C,K), dbias, dgamma, dbeta (C) accumulated (caller zero-fills).
+extern "C" int cfm_dwconv_bn_swish_bwd_f32(const float* g, const float* dy, const float* w, const float* bias,
+                                           const float* bn_weight, const float* bn_bias, const float* bn_mean,
+                                           const float* bn_var, float bn_eps, float* dc_ws, float* dg, float* dw,
+                                           float* dbias, float* dgamma, float* dbeta, int B, int T, int C, int K,
+                                           cfm_stream_t stream) {
+    CFM_REQUIRE(g && dy && w && bias && bn_weight && bn_bias && bn_mean && bn_var && dc_ws && dg && dw && dbias &&
+                dgamma && dbeta, CFM_ERR_NULL);
+    CFM_REQUIRE(B > 0 && T > 0 && C > 0 && K > 0 && (K & 1) == 1, CFM_ERR_BAD_SHAPE);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    constexpr int TT = 8;
+    const dim3 grid((unsigned)((C + 63) / 64), (unsigned)((T + 4 * TT - 1) / (4 * TT)), (unsigned)B), block(256);
+#define DWB(KK)                                                                                                     \
+    hipLaunchKernelGGL((dwconv_bn_swish_bwd1_kernel<KK, TT>), grid, block, 0, s, g, dy, w, bias, bn_weight, bn_bias, \
+                       bn_mean, bn_var, bn_eps, dc_ws, dw, dbias, dgamma, dbeta, T, C);                              \
+    hipLaunchKernelGGL((dwconv_plain_kernel<KK, TT, true>), grid, block, 0, s, dc_ws, w, dg, T, C)
+    switch (K) {
+        case 31: DWB(31); break;
+        case 15: DWB(15); break;
+        case 7: DWB(7); break;
+        case 3: DWB(3); break;
+        default: return CFM_ERR_UNSUPPORTED;
+    }
+#undef DWB
+    return cfm_launch_status();
+}

@@ -21,6 +21,7 @@ enum Epi { EPI_BIAS = 0, EPI_SWISH = 1, EPI_RELU = 2, EPI_GLU = 3, EPI_RESID = 4
 
 struct GemmArgs {
     const float* A; const float* W; const float* bias; const float* R; float* C;
+    float* Zsave;                   // swish epilogue, training: also store the pre-activation (same ldc), or NULL
     int64_t M; int N; int K; int64_t lda, ldr, ldc; float alpha;
     int n_out;                      // GLU: output columns (N = 2*n_out)
     int cT2, cF2, cT1, cF1, cC;     // conv mode geometry
@@ -106,6 +107,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const f32x16 (&
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = g.alpha * v[e] + rr[e];
                     }
+                    if (EPI == EPI_SWISH && g.Zsave)
+                        *reinterpret_cast<f32x4*>(g.Zsave + row * g.ldc + col) = f32x4{v[0], v[1], v[2], v[3]};
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         if (EPI == EPI_SWISH) v[e] = swishf_acc(v[e]);
@@ -119,6 +122,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const f32x16 (&
                         float x = acc[mt][nt][4 * q + e] + g.bias[col + e];
                         if (EPI == EPI_GLU) x *= sigmoidf_acc(acc[mt][TN - 1][4 * q + e] + g.bias[g.n_out + col + e]);
                         if (EPI == EPI_RESID) x = g.alpha * x + g.R[row * g.ldr + col + e];
+                        if (EPI == EPI_SWISH && g.Zsave) g.Zsave[row * g.ldc + col + e] = x;
                         if (EPI == EPI_SWISH) x = swishf_acc(x);
                         if (EPI == EPI_RELU) x = fmaxf(x, 0.f);
                         g.C[row * g.ldc + col + e] = x;
@@ -323,6 +327,17 @@ extern "C" int cfm_gemm_bias_swish_f32(const float* A, const float* W, const flo
                                        int N, int K, int64_t lda, int64_t ldc, cfm_stream_t stream) {
     GEMM_ARGS_PLAIN(N);
     int st = check(g); if (st) return st;
+    CFM_REQUIRE(ldc >= N, CFM_ERR_BAD_SHAPE);
+    return launch<EPI_SWISH, false>(g, static_cast<hipStream_t>(stream));
+}
+
+// training forward of ffn.py:17-18: C = swish(Z), Z = A.W^T + bias is stored too (needed by swish' in the backward)
+extern "C" int cfm_gemm_bias_swish_save_f32(const float* A, const float* W, const float* bias, float* C, float* Z,
+                                            int64_t M, int N, int K, int64_t lda, int64_t ldc, cfm_stream_t stream) {
+    GEMM_ARGS_PLAIN(N);
+    g.Zsave = Z;
+    int st = check(g); if (st) return st;
+    CFM_REQUIRE(Z != nullptr, CFM_ERR_NULL);
     CFM_REQUIRE(ldc >= N, CFM_ERR_BAD_SHAPE);
     return launch<EPI_SWISH, false>(g, static_cast<hipStream_t>(stream));
 }

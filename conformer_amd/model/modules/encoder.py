@@ -10,8 +10,9 @@ from typing import Optional, Tuple
 import torch
 import torch.nn as nn
 
+from ... import autograd as ag
 from ... import ops
-from ..utils._guard import STRICT, PackCache, require_inference
+from ..utils._guard import STRICT, PackCache, refuse_dropout
 from ..utils.block import ConformerBlock
 from ..utils.convolution import ConvolutionSubsampling
 from ..utils.position import RelativePositionalEncoding
@@ -32,13 +33,18 @@ class Encoder(nn.Module):
         self.cache_projected_positions = False
 
     def forward(self, x: torch.Tensor, lengths: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
-        require_inference(self, "Encoder", x)
+        refuse_dropout(self, "Encoder")
         d = self.linear.out_features
-        h = self.downsampling_conv.channel_last(x)                                   # (B, T', F'*C)
+        h = self.downsampling_conv.channel_last(x)                                   # (B, T', F'*C); no grad path yet
         out_len = ConvolutionSubsampling.out_lengths(lengths)
-        wlp = self._packs.get("wlp", (self.linear.weight,),
-                              lambda: ops.pack_linear_weight(self.linear.weight, d, self.n_freq_out))
-        h = ops.linear(h, wlp, self.linear.bias)                                     # (B, T', d)
+        if ag.needs_grad(self.linear):
+            # differentiable re-layout of the weight (columns c*F'+f -> f*C+c) so .grad lands in the reference layout
+            wlp = self.linear.weight.view(d, d, self.n_freq_out).transpose(1, 2).reshape(d, -1)
+            h = ag.LinearFn.apply(h, wlp, self.linear.bias)
+        else:
+            wlp = self._packs.get("wlp", (self.linear.weight,),
+                                  lambda: ops.pack_linear_weight(self.linear.weight, d, self.n_freq_out))
+            h = ops.linear(h, wlp, self.linear.bias)                                 # (B, T', d)
         n_frames = h.shape[1]
         if out_len is not None:
             if out_len.device != h.device:
@@ -62,6 +68,8 @@ class Encoder(nn.Module):
         ws = [l.attention.attention.pos_proj.weight for l in self.layers]
         bs = [l.attention.attention.pos_proj.bias for l in self.layers]
 
+        if ag.needs_grad(self.layers):
+            return ag.LinearFn.apply(table, torch.cat(ws, dim=0), torch.cat(bs, dim=0))   # cat is differentiable glue
         w = self._packs.get("pos_w", ws, lambda: torch.cat([t.detach() for t in ws], dim=0).contiguous())
         b = self._packs.get("pos_b", bs, lambda: torch.cat([t.detach() for t in bs], dim=0).contiguous())
         if self.cache_projected_positions:

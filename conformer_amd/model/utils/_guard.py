@@ -9,14 +9,24 @@ import torch
 STRICT = os.environ.get("CONFORMER_AMD_STRICT", "0") == "1"
 
 
-def require_inference(module: torch.nn.Module, what: str, *tensors: torch.Tensor) -> None:
-    """Round-1 scope: the HIP path implements the forward pass.  Refuse (loudly) anything that would
-    silently produce non-differentiable or train-mode-incorrect results."""
+def refuse_dropout(module: torch.nn.Module, what: str) -> None:
+    """Dropout masks (Philox regeneration in the backward) are not built yet: refuse p > 0 in training mode
+    instead of silently skipping it."""
+    if module.training:
+        for m in module.modules():
+            if isinstance(m, torch.nn.Dropout) and m.p > 0:
+                raise NotImplementedError(f"{what}: dropout p={m.p} in training mode is not built yet "
+                                          "(use dropout_rate=0.0 or .eval())")
+
+
+def refuse_grad(module: torch.nn.Module, what: str, *tensors: torch.Tensor) -> None:
+    """For pieces whose backward kernels do not exist yet (the conv-subsampling stem): refuse a call that would
+    need gradients rather than return a silently non-differentiable result."""
     if torch.is_grad_enabled() and (any(t.requires_grad for t in tensors if isinstance(t, torch.Tensor))
                                     or any(p.requires_grad for p in module.parameters())):
         raise NotImplementedError(
-            f"{what}: the gfx950 backward kernels are not part of this build yet; call under torch.no_grad() "
-            "/ torch.inference_mode().  (No autograd fallback exists on purpose.)")
+            f"{what}: backward kernels for this piece are not built yet; freeze it (requires_grad_(False)) or call "
+            "under torch.no_grad().  (No autograd fallback exists on purpose.)")
 
 
 class PackCache:

@@ -14,8 +14,9 @@ from typing import Optional
 import torch
 import torch.nn as nn
 
+from ... import autograd as ag
 from ... import ops
-from ._guard import PackCache, require_inference
+from ._guard import PackCache, refuse_dropout
 from .masking import lengths_from_key_padding_mask
 
 
@@ -71,7 +72,10 @@ class RelativeMultiHeadAttention(nn.Module):
     # ---- reference-compatible entry (attention.py:74) ------------------------------------------
     def forward(self, q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, pos_embedding: torch.Tensor,
                 mask: Optional[torch.Tensor] = None) -> torch.Tensor:
-        require_inference(self, "RelativeMultiHeadAttention", q)
+        refuse_dropout(self, "RelativeMultiHeadAttention")
+        if ag.needs_grad(self, q):
+            raise NotImplementedError("RelativeMultiHeadAttention.forward: the differentiable path lives one level up "
+                                      "(MultiHeadSelfAttentionModule folds the LayerNorm and the residual)")
         if not (k is q and v is q):
             raise NotImplementedError("the fused gfx950 kernel implements SELF-attention (q is k is v), which is "
                                       "the only way the reference calls it (attention.py:16)")
@@ -89,7 +93,18 @@ class MultiHeadSelfAttentionModule(nn.Module):
 
     def fused(self, x, pos_table, lengths, residual: Optional[torch.Tensor] = None,
               pos_projected: Optional[torch.Tensor] = None) -> torch.Tensor:
-        require_inference(self, "MultiHeadSelfAttentionModule", x)
+        refuse_dropout(self, "MultiHeadSelfAttentionModule")
+        if ag.needs_grad(self, x, pos_projected):
+            a = self.attention
+            if residual is not None and residual is not x:
+                raise NotImplementedError("MultiHeadSelfAttentionModule.fused: pass residual=x (block.py:21)")
+            if pos_projected is None:
+                pos_projected = ag.LinearFn.apply(pos_table, a.pos_proj.weight, a.pos_proj.bias)
+            out = ag.SelfAttentionFn.apply(x, self.layer_norm.weight, self.layer_norm.bias, a.query_proj.weight,
+                                           a.query_proj.bias, a.key_proj.weight, a.key_proj.bias, a.value_proj.weight,
+                                           a.value_proj.bias, pos_projected, a.content_bias, a.position_bias,
+                                           a.out_proj.weight, a.out_proj.bias, lengths, a.n_heads, self.layer_norm.eps)
+            return out if residual is not None else out - x
         xn = ops.layernorm(x, self.layer_norm.weight, self.layer_norm.bias, self.layer_norm.eps)
         return self.attention.fused(xn, pos_table, lengths, residual, pos_projected)
 

@@ -9,6 +9,7 @@ from typing import Optional
 import torch
 import torch.nn as nn
 
+from ... import autograd as ag
 from ... import ops
 from .attention import MultiHeadSelfAttentionModule
 from .convolution import ConvolutionModule
@@ -31,6 +32,8 @@ class ConformerBlock(nn.Module):
         y = self.attention.fused(y, pos_table, lengths, residual=y, pos_projected=pos_projected)
         y = self.conv.fused(y, residual=y)
         y = self.ffn_2.fused(y, residual=y, alpha=0.5)
+        if ag.needs_grad(self.layer_norm, y):
+            return ag.LayerNormFn.apply(y, self.layer_norm.weight, self.layer_norm.bias, self.layer_norm.eps)
         return ops.layernorm(y, self.layer_norm.weight, self.layer_norm.bias, self.layer_norm.eps)
 
     def forward(self, x: torch.Tensor, pos_embedding: torch.Tensor, mask: Optional[torch.Tensor] = None) -> torch.Tensor:

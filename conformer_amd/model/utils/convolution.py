@@ -16,8 +16,9 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from ... import autograd as ag
 from ... import ops
-from ._guard import PackCache, require_inference
+from ._guard import PackCache, refuse_dropout, refuse_grad
 from .activation import GLU, Swish
 
 
@@ -35,11 +36,20 @@ class ConvolutionModule(nn.Module):
         self.dropout = nn.Dropout(p=dropout_rate)
 
     def fused(self, x: torch.Tensor, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
-        require_inference(self, "ConvolutionModule", x)
+        refuse_dropout(self, "ConvolutionModule")
         if self.training:
             raise NotImplementedError("ConvolutionModule: train-mode BatchNorm (batch statistics) is not built yet; "
-                                      "call .eval()")
+                                      "call .eval() (gradients flow in eval mode with the running statistics)")
         bn = self.batch_norm
+        if ag.needs_grad(self, x, residual):
+            if residual is not None and residual is not x:
+                raise NotImplementedError("ConvolutionModule.fused: pass residual=x (block.py:23)")
+            out = ag.ConvModuleFn.apply(x, self.layer_norm.weight, self.layer_norm.bias, self.pointwise_conv_1.weight,
+                                        self.pointwise_conv_1.bias, self.deepwise_conv.weight, self.deepwise_conv.bias,
+                                        bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                                        self.pointwise_conv_2.weight, self.pointwise_conv_2.bias,
+                                        self.layer_norm.eps, bn.eps)
+            return out if residual is not None else out - x
         h = ops.layernorm(x, self.layer_norm.weight, self.layer_norm.bias, self.layer_norm.eps)
         g = ops.linear_glu(h, self.pointwise_conv_1.weight, self.pointwise_conv_1.bias)
         s = ops.dwconv_bn_swish(g, self.deepwise_conv.weight, self.deepwise_conv.bias, bn.weight, bn.bias,
@@ -69,7 +79,7 @@ class ConvolutionSubsampling(nn.Module):
 
     def channel_last(self, x: torch.Tensor) -> torch.Tensor:
         """(B, n_mel, T) -> (B, T', F'*C) with feature index f*C + c (the hot-path layout)."""
-        require_inference(self, "ConvolutionSubsampling", x)
+        refuse_grad(self, "ConvolutionSubsampling", x)
         w2p = self._packs.get("w2p", (self.conv_2.weight,), lambda: ops.pack_conv2_weight(self.conv_2.weight))
         return ops.subsample_stem(x, self.conv_1.weight, self.conv_1.bias, w2p, self.conv_2.bias)
 

@@ -9,8 +9,9 @@ from typing import Optional
 import torch
 import torch.nn as nn
 
+from ... import autograd as ag
 from ... import ops
-from ._guard import require_inference
+from ._guard import refuse_dropout
 from .activation import Swish
 
 
@@ -25,7 +26,16 @@ class FeedForwardModule(nn.Module):
         self.dropout_2 = nn.Dropout(p=dropout_rate)
 
     def fused(self, x: torch.Tensor, residual: Optional[torch.Tensor] = None, alpha: float = 1.0) -> torch.Tensor:
-        require_inference(self, "FeedForwardModule", x)
+        refuse_dropout(self, "FeedForwardModule")
+        if ag.needs_grad(self, x, residual):
+            if residual is not None and residual is not x:
+                raise NotImplementedError("FeedForwardModule.fused: the differentiable path folds the residual of its "
+                                          "own input (block.py:19,25); pass residual=x")
+            out = ag.FeedForwardFn.apply(x, self.layer_norm.weight, self.layer_norm.bias, self.hidden_linear.weight,
+                                         self.hidden_linear.bias, self.out_linear.weight, self.out_linear.bias,
+                                         float(alpha), self.layer_norm.eps)
+            # the Function always folds `+ x`; a stand-alone call (no residual) removes it again
+            return out if residual is not None else out - x
         h = ops.layernorm(x, self.layer_norm.weight, self.layer_norm.bias, self.layer_norm.eps)
         h = ops.linear(h, self.hidden_linear.weight, self.hidden_linear.bias, act="swish")
         if residual is None:

@@ -164,3 +164,219 @@ def subsample_stem(x: torch.Tensor, w1, b1, w2p, b2) -> torch.Tensor:
     _lib.check(lib.cfm_subsample_conv2_relu_f32(h1.data_ptr(), w2p.data_ptr(), b2.data_ptr(), h2.data_ptr(), B, F1, T1,
                                                 C, _stream()), "cfm_subsample_conv2_relu_f32")
     return h2
+
+
+# ======================================================================================================
+# training forward variants + backward ops (fp32).  Same rules: HIP tensors only, no eager fallback.
+# ======================================================================================================
+def layernorm_train(x, weight, bias, eps: float = 1e-5):
+    """LayerNorm forward that also returns the per-row mean / rstd the backward needs."""
+    x = _req(x, "x"); weight = _req(weight, "weight"); bias = _req(bias, "bias")
+    d = x.shape[-1]
+    rows = x.numel() // d
+    y = torch.empty_like(x)
+    mean = torch.empty(rows, device=x.device, dtype=x.dtype)
+    rstd = torch.empty(rows, device=x.device, dtype=x.dtype)
+    st = _lib.load().cfm_layernorm_fwd_f32(x.data_ptr(), weight.data_ptr(), bias.data_ptr(), y.data_ptr(),
+                                           mean.data_ptr(), rstd.data_ptr(), rows, d, eps, _stream())
+    _lib.check(st, "cfm_layernorm_fwd_f32")
+    return y, mean, rstd
+
+
+def layernorm_bwd(x, weight, dy, mean, rstd, dres=None):
+    """Returns (dx [+ dres], dweight, dbias)."""
+    x = _req(x, "x"); dy = _req(dy, "dy"); weight = _req(weight, "weight")
+    d = x.shape[-1]
+    rows = x.numel() // d
+    lib = _lib.load()
+    dx = torch.empty_like(x)
+    if dres is not None:
+        dres = _req(dres, "dres")
+    _lib.check(lib.cfm_layernorm_bwd_dx_f32(x.data_ptr(), weight.data_ptr(), dy.data_ptr(), mean.data_ptr(),
+                                            rstd.data_ptr(), _p(dres), dx.data_ptr(), rows, d, _stream()),
+               "cfm_layernorm_bwd_dx_f32")
+    dw = torch.zeros(d, device=x.device, dtype=x.dtype)
+    db = torch.zeros(d, device=x.device, dtype=x.dtype)
+    _lib.check(lib.cfm_layernorm_bwd_params_f32(x.data_ptr(), dy.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                                dw.data_ptr(), db.data_ptr(), rows, d, _stream()),
+               "cfm_layernorm_bwd_params_f32")
+    return dx, dw, db
+
+
+def linear_swish_save(a, w, b):
+    """Returns (swish(z), z) with z = a @ w.T + b."""
+    a, w2, b, m, n, k = _gemm_common(a, w, b)
+    c = torch.empty(*a.shape[:-1], n, device=a.device, dtype=a.dtype)
+    z = torch.empty_like(c)
+    st = _lib.load().cfm_gemm_bias_swish_save_f32(a.data_ptr(), w2.data_ptr(), b.data_ptr(), c.data_ptr(), z.data_ptr(),
+                                                  m, n, k, k, n, _stream())
+    _lib.check(st, "cfm_gemm_bias_swish_save_f32")
+    return c, z
+
+
+def glu_fwd(z):
+    z = _req(z, "z")
+    n = z.shape[-1] // 2
+    rows = z.numel() // (2 * n)
+    y = torch.empty(*z.shape[:-1], n, device=z.device, dtype=z.dtype)
+    _lib.check(_lib.load().cfm_glu_fwd_f32(z.data_ptr(), y.data_ptr(), rows, n, _stream()), "cfm_glu_fwd_f32")
+    return y
+
+
+def glu_bwd(z, dy):
+    z = _req(z, "z"); dy = _req(dy, "dy")
+    n = dy.shape[-1]
+    rows = dy.numel() // n
+    dz = torch.empty_like(z)
+    _lib.check(_lib.load().cfm_glu_bwd_f32(z.data_ptr(), dy.data_ptr(), dz.data_ptr(), rows, n, _stream()),
+               "cfm_glu_bwd_f32")
+    return dz
+
+
+def colsum(x2d, alpha: float = 1.0, rows=None, cols=None, ld=None):
+    """alpha * column sums of a (rows, cols) fp32 matrix with row stride ld (bias gradients)."""
+    rows = x2d.shape[0] if rows is None else rows
+    cols = x2d.shape[1] if cols is None else cols
+    ld = x2d.stride(0) if ld is None else ld
+    out = torch.zeros(cols, device=x2d.device, dtype=x2d.dtype)
+    _lib.check(_lib.load().cfm_colsum_f32(x2d.data_ptr(), ld, rows, cols, alpha, out.data_ptr(), _stream()),
+               "cfm_colsum_f32")
+    return out
+
+
+def gemm_bwd(A, a_col: bool, B, b_col: bool, I: int, J: int, Kc: int, *, alpha: float = 1.0, Z=None, out=None,
+             lda=None, ldb=None, ldc=None, ldz=None, allow_split: bool = False, accumulate: bool = False,
+             nbatch: int = 1, nb1: int = 1, sa=(0, 0), sb=(0, 0), sc=(0, 0), a_ptr=None, b_ptr=None, c_ptr=None):
+    """C (I,J) (+)= alpha * sum_k A(i,k) B(j,k) [* swish'(Z)]; *_col selects the contraction-major layout.
+    Pointers default to the tensors' data_ptr(); explicit *_ptr / ld* let callers address sub-blocks (head slices)."""
+    lda = A.stride(-2) if lda is None else lda
+    ldb = B.stride(-2) if ldb is None else ldb
+    if out is None:
+        out = (torch.zeros if allow_split else torch.empty)(I, J, device=A.device, dtype=A.dtype)
+    ldc = out.stride(-2) if ldc is None else ldc
+    ldz = 0 if Z is None else (Z.stride(-2) if ldz is None else ldz)
+    st = _lib.load().cfm_gemm_bwd_batched_f32(
+        A.data_ptr() if a_ptr is None else a_ptr, int(a_col), lda, B.data_ptr() if b_ptr is None else b_ptr, int(b_col),
+        ldb, _p(Z), ldz, alpha, out.data_ptr() if c_ptr is None else c_ptr, ldc, I, J, Kc, int(allow_split),
+        int(accumulate), nbatch, nb1, sa[0], sa[1], sb[0], sb[1], sc[0], sc[1], _stream())
+    _lib.check(st, "cfm_gemm_bwd_batched_f32")
+    return out
+
+
+def linear_bwd(x2d, w, dy2d, *, alpha: float = 1.0, Z=None, need_dx: bool = True):
+    """Backward of y = x @ w.T + b for 2-D views: returns (dx or None, dw, db), all scaled by alpha;
+    dx is additionally multiplied by swish'(Z) when Z is given (then it is d/d(pre-activation))."""
+    m, k = x2d.shape
+    n = w.shape[0]
+    w2 = w.reshape(n, -1)
+    dx = None
+    if need_dx:
+        dx = gemm_bwd(dy2d, False, w2, True, m, k, n, alpha=alpha, Z=Z)
+    dw = gemm_bwd(dy2d, True, x2d, True, n, k, m, alpha=alpha, allow_split=True)
+    db = colsum(dy2d, alpha)
+    return dx, dw.view_as(w), db
+
+
+def dwconv_bn_swish_bwd(g, dy, w, b, bn_w, bn_b, bn_mean, bn_var, eps: float = 1e-5):
+    """Returns (dg, dw, db, dbn_weight, dbn_bias) for the fixed-statistics BatchNorm form."""
+    g = _req(g, "g"); dy = _req(dy, "dy")
+    B, T, C = g.shape
+    K = w.shape[-1]
+    dc = torch.empty_like(g)
+    dg = torch.empty_like(g)
+    dw = torch.zeros_like(w)
+    db = torch.zeros(C, device=g.device, dtype=g.dtype)
+    dga = torch.zeros(C, device=g.device, dtype=g.dtype)
+    dbe = torch.zeros(C, device=g.device, dtype=g.dtype)
+    st = _lib.load().cfm_dwconv_bn_swish_bwd_f32(g.data_ptr(), dy.data_ptr(), w.data_ptr(), b.data_ptr(), bn_w.data_ptr(),
+                                                 bn_b.data_ptr(), bn_mean.data_ptr(), bn_var.data_ptr(), eps,
+                                                 dc.data_ptr(), dg.data_ptr(), dw.data_ptr(), db.data_ptr(),
+                                                 dga.data_ptr(), dbe.data_ptr(), B, T, C, K, _stream())
+    _lib.check(st, "cfm_dwconv_bn_swish_bwd_f32")
+    return dg, dw, db, dga, dbe
+
+
+def relpos_attention_train(qkv, pos, u, v, lengths, n_heads):
+    """Forward that also returns the per-row log-sum-exp (B,H,T) for the backward."""
+    qkv = _req(qkv, "qkv"); u = _req(u, "content_bias"); v = _req(v, "position_bias")
+    B, T, d3 = qkv.shape
+    d = d3 // 3
+    dh = d // n_heads
+    ctx = torch.empty(B, T, d, device=qkv.device, dtype=qkv.dtype)
+    lse = torch.empty(B, n_heads, T, device=qkv.device, dtype=qkv.dtype)
+    base = qkv.data_ptr()
+    st = _lib.load().cfm_relpos_attention_fwd_f32(base, base + 4 * d, base + 8 * d, d3, pos.data_ptr(), pos.stride(0),
+                                                  u.data_ptr(), v.data_ptr(), _p(lengths), ctx.data_ptr(), d,
+                                                  lse.data_ptr(), B, T, n_heads, dh, _stream())
+    _lib.check(st, "cfm_relpos_attention_fwd_f32")
+    return ctx, lse
+
+
+def relpos_attention_bwd(qkv, pos, u, v, lengths, n_heads, ctx, lse, dctx):
+    """Backward of the attention core.  Returns (dqkv (B,T,3d), dpos (2T-1,d), du (H,dh), dv (H,dh)).
+    Round-1 form: batched MFMA GEMMs over re-materialised (B,H,T,T) tensors (attention_bwd_f32.hip)."""
+    lib = _lib.load()
+    B, T, d3 = qkv.shape
+    d = d3 // 3
+    H = n_heads
+    dh = d // H
+    N = B * T
+    P = 2 * T - 1
+    T4, P4 = (T + 3) // 4 * 4, (P + 3) // 4 * 4
+    dev, dt = qkv.device, qkv.dtype
+    dctx = _req(dctx, "dctx")
+    f = 4  # bytes
+    qp = qkv.data_ptr(); kp = qp + f * d; vp = qp + 2 * f * d
+    ldp = pos.stride(0)
+    scale = 1.0 / float(dh) ** 0.5
+    qu = torch.empty(N, d, device=dev, dtype=dt)
+    qv = torch.empty(N, d, device=dev, dtype=dt)
+    _lib.check(lib.cfm_attn_qbias_f32(qp, d3, u.data_ptr(), v.data_ptr(), qu.data_ptr(), qv.data_ptr(), N, d, _stream()),
+               "cfm_attn_qbias_f32")
+    Dr = torch.empty(B, H, T, device=dev, dtype=dt)
+    _lib.check(lib.cfm_attn_rowdot_f32(dctx.data_ptr(), ctx.data_ptr(), Dr.data_ptr(), B, T, H, dh, _stream()),
+               "cfm_attn_rowdot_f32")
+    content = torch.empty(B, H, T, T4, device=dev, dtype=dt)
+    dP = torch.empty(B, H, T, T4, device=dev, dtype=dt)
+    posfull = torch.empty(H, B, T, P4, device=dev, dtype=dt)
+    sBH_rows = (T * d, dh)            # (b,h) offsets into an (N, d) row-major tensor: b*T*d + h*dh
+    sBH_qkv = (T * d3, dh)            # same for a slot of the fused (N, 3d) tensor
+    sBH_sq = (H * T * T4, T * T4)     # (b,h) offsets into (B,H,T,T4)
+    sBH_pf = (T * P4, B * T * P4)     # (b,h) offsets into (H,B,T,P4)
+    nb = B * H
+    # content[b,h] = Qu_bh . K_bh^T        (T x T4; padded columns read clamped K rows, masked later)
+    gemm_bwd(qu, False, qkv, False, T, T4, dh, out=content, lda=d, ldb=d3, ldc=T4, nbatch=nb, nb1=H,
+             sa=sBH_rows, sb=sBH_qkv, sc=sBH_sq, b_ptr=kp)
+    # posfull[h,b] = Qv_bh . Pm_h^T        (T x P4)
+    gemm_bwd(qv, False, pos, False, T, P4, dh, out=posfull, lda=d, ldb=ldp, ldc=P4, nbatch=nb, nb1=H,
+             sa=sBH_rows, sb=(0, dh), sc=sBH_pf)
+    # dP[b,h] = dO_bh . V_bh^T
+    gemm_bwd(dctx, False, qkv, False, T, T4, dh, out=dP, lda=d, ldb=d3, ldc=T4, nbatch=nb, nb1=H,
+             sa=sBH_rows, sb=sBH_qkv, sc=sBH_sq, b_ptr=vp)
+    _lib.check(lib.cfm_attn_softmax_bwd_f32(content.data_ptr(), posfull.data_ptr(), dP.data_ptr(), lse.data_ptr(),
+                                            Dr.data_ptr(), _p(lengths), scale, B, T, H, T4, P4, _stream()),
+               "cfm_attn_softmax_bwd_f32")
+    Pm, dS, dpf = content, dP, posfull                      # in-place results
+    dqkv = torch.empty(B, T, d3, device=dev, dtype=dt)
+    dq_p = dqkv.data_ptr(); dk_p = dq_p + f * d; dv_p = dq_p + 2 * f * d
+    # dV_bh = P_bh^T . dO_bh               (A = P contraction-major over queries; B = dO contraction-major)
+    gemm_bwd(Pm, True, dctx, True, T, dh, T, out=dqkv, lda=T4, ldb=d, ldc=d3, nbatch=nb, nb1=H,
+             sa=sBH_sq, sb=sBH_rows, sc=sBH_qkv, c_ptr=dv_p)
+    # dK_bh = dS_bh^T . Qu_bh
+    gemm_bwd(dS, True, qu, True, T, dh, T, out=dqkv, lda=T4, ldb=d, ldc=d3, nbatch=nb, nb1=H,
+             sa=sBH_sq, sb=sBH_rows, sc=sBH_qkv, c_ptr=dk_p)
+    # dQu_bh = dS_bh . K_bh                (contraction over keys: dS index-major, K contraction-major)
+    gemm_bwd(dS, False, qkv, True, T, dh, T, out=dqkv, lda=T4, ldb=d3, ldc=d3, nbatch=nb, nb1=H,
+             sa=sBH_sq, sb=sBH_qkv, sc=sBH_qkv, b_ptr=kp, c_ptr=dq_p)
+    du = colsum(dqkv, rows=N, cols=d, ld=d3).view(H, dh)
+    # dQv_bh = dposfull_hb . Pm_h          (contraction over the 2T-1 relative positions)
+    dqv = torch.empty(N, d, device=dev, dtype=dt)
+    gemm_bwd(dpf, False, pos, True, T, dh, P, out=dqv, lda=P4, ldb=ldp, ldc=d, nbatch=nb, nb1=H,
+             sa=sBH_pf, sb=(0, dh), sc=sBH_rows)
+    dvb = colsum(dqv).view(H, dh)
+    _lib.check(lib.cfm_add_strided_f32(dq_p, d3, dqv.data_ptr(), d, N, d, _stream()), "cfm_add_strided_f32")
+    # dPm_h = sum_{b,i} dposfull_h[(b,i), :]^T . Qv_h[(b,i), :]     (contraction over B*T rows, split + atomics)
+    dpos = torch.zeros(P, d, device=dev, dtype=dt)
+    gemm_bwd(dpf, True, qv, True, P, dh, N, out=dpos, lda=P4, ldb=d, ldc=d, allow_split=True, nbatch=H, nb1=H,
+             sa=(0, B * T * P4), sb=(0, dh), sc=(0, dh))
+    return dqkv, dpos, du, dvb

@@ -115,6 +115,70 @@ int cfm_subsample_conv2_relu_f32(const float* h1, const float* w2p, const float*
                                  int B, int F1, int T1, int C, cfm_stream_t stream);
 int cfm_pack_linear_weight_f32(const float* wl, float* wlp, int d_out, int C, int F2, cfm_stream_t stream);
 
+/* =============================== backward pass (fp32) =========================================
+ * The reference relies on autograd (train.py:239); these are the explicit kernels behind the
+ * torch.autograd.Function wrappers in conformer_amd/autograd.py.  Parameter-gradient outputs that
+ * are documented as "accumulated" must be zero-filled by the caller (they are summed with fp32
+ * atomics).  Layout conventions as in the forward section. */
+
+/* training forward of ffn.py:17-18: C = swish(Z) and Z = A.W^T + bias are both stored. */
+int cfm_gemm_bias_swish_save_f32(const float* A, const float* W, const float* bias, float* C, float* Z,
+                                 int64_t M, int N, int K, int64_t lda, int64_t ldc, cfm_stream_t stream);
+
+/* General MFMA GEMM of the backward pass: C (I x J) (+)= alpha * sum_k A(i,k) B(j,k) [* swish'(Z)].
+ * a_col / b_col = 0: operand stored index-major X[idx*ld + k]; = 1: contraction-major X[k*ld + idx].
+ *   dX = dY.W    : A = dY (a_col 0), B = W (b_col 1), I = M, J = K_in, Kc = N_out
+ *   dW = dY^T.X  : A = dY (a_col 1), B = X (b_col 1), I = N_out, J = K_in, Kc = M  (allow_split: fp32 atomics
+ *                  over contraction slices into a ZERO-FILLED C)
+ * lda, ldb, ldc (and batch strides) multiples of 4; pointers 16-byte aligned.  Z only with (a_col 0, b_col 1). */
+int cfm_gemm_bwd_f32(const float* A, int a_col, int64_t lda, const float* B, int b_col, int64_t ldb,
+                     const float* Z_or_null, int64_t ldz, float alpha, float* C, int64_t ldc,
+                     int I, int J, int64_t Kc, int allow_split, cfm_stream_t stream);
+int cfm_gemm_bwd_batched_f32(const float* A, int a_col, int64_t lda, const float* B, int b_col, int64_t ldb,
+                             const float* Z_or_null, int64_t ldz, float alpha, float* C, int64_t ldc,
+                             int I, int J, int64_t Kc, int allow_split, int accumulate, int nbatch, int nb1,
+                             int64_t sa0, int64_t sa1, int64_t sb0, int64_t sb1, int64_t sc0, int64_t sc1,
+                             cfm_stream_t stream);
+
+/* LayerNorm backward (mean/rstd = the forward's saved row statistics).  dx = LN'(dy) [+ dres];
+ * dgamma/dbeta accumulated. */
+int cfm_layernorm_bwd_dx_f32(const float* x, const float* gamma, const float* dy, const float* mean,
+                             const float* rstd, const float* dres_or_null, float* dx, int64_t rows, int d,
+                             cfm_stream_t stream);
+int cfm_layernorm_bwd_params_f32(const float* x, const float* dy, const float* mean, const float* rstd,
+                                 float* dgamma, float* dbeta, int64_t rows, int d, cfm_stream_t stream);
+
+/* out[c] += alpha * sum_r X[r][c]  (bias gradients; out accumulated). */
+int cfm_colsum_f32(const float* X, int64_t ld, int64_t rows, int cols, float alpha, float* out,
+                   cfm_stream_t stream);
+
+/* GLU on a stored pre-activation z = [a | g] (rows, 2n): y = a*sigmoid(g); and its backward dz. */
+int cfm_glu_fwd_f32(const float* z, float* y, int64_t rows, int n, cfm_stream_t stream);
+int cfm_glu_bwd_f32(const float* z, const float* dy, float* dz, int64_t rows, int n, cfm_stream_t stream);
+
+/* Backward of cfm_dwconv_bn_swish_fwd_f32 (BatchNorm with fixed statistics).  dc_ws: (B,T,C) workspace;
+ * dg: (B,T,C); dw (C,K), dbias, dgamma, dbeta (C): accumulated.  K in {3,7,15,31}. */
+int cfm_dwconv_bn_swish_bwd_f32(const float* g, const float* dy, const float* w, const float* bias,
+                                const float* bn_weight, const float* bn_bias, const float* bn_mean,
+                                const float* bn_var, float bn_eps, float* dc_ws, float* dg, float* dw,
+                                float* dbias, float* dgamma, float* dbeta, int B, int T, int C, int K,
+                                cfm_stream_t stream);
+
+/* Glue kernels of the attention backward (attention_bwd_f32.hip; the products are cfm_gemm_bwd_batched_f32):
+ *   qbias      : qu = q + u_h, qv = q + vbias_h                  (rows = B*T, d = H*dh; u/vbias flattened (d))
+ *   rowdot     : D[b,h,i] = sum_c dO*O
+ *   softmax_bwd: in place  content (B,H,T,T4) -> P;  posfull (H,B,T,P4) -> dposfull;  dP (B,H,T,T4) -> dS
+ *   add_strided: dst += src                                                                        */
+int cfm_attn_qbias_f32(const float* q, int64_t ld, const float* u, const float* vbias, float* qu, float* qv,
+                       int64_t rows, int d, cfm_stream_t stream);
+int cfm_attn_rowdot_f32(const float* dO, const float* O, float* D, int B, int T, int H, int dh,
+                        cfm_stream_t stream);
+int cfm_attn_softmax_bwd_f32(float* content_to_p, float* posfull_to_dposfull, float* dp_to_ds,
+                             const float* lse, const float* D, const int64_t* lengths_or_null, float scale,
+                             int B, int T, int H, int T4, int P4, cfm_stream_t stream);
+int cfm_add_strided_f32(float* dst, int64_t ld_dst, const float* src, int64_t ld_src, int64_t rows, int cols,
+                        cfm_stream_t stream);
+
 /* ---- tuning / diagnostics: the residual-epilogue GEMM with a forced block-tile shape
  *      (cfg 0..3 = 128x128, 128x64, 64x128, 64x64; -1 = built-in heuristic).  Same results for every cfg.
  *      trace_or_null: 8 x uint64 per block {start, main-loop end, HW_ID, XCC_ID, epilogue issued,
