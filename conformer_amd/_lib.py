@@ -35,8 +35,9 @@ SIGNATURES = {
     "cfm_colsum_f32": (c_int, [_P, _L, _L, _I, _F, _P, _P]),
     "cfm_glu_fwd_f32": (c_int, [_P, _P, _L, _I, _P]),
     "cfm_glu_bwd_f32": (c_int, [_P, _P, _P, _L, _I, _P]),
-    "cfm_dwconv_bn_swish_bwd_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _P,
+    "cfm_dwconv_bn_swish_bwd_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _F, _I, _P, _P, _P, _P, _P, _P,
                                             _I, _I, _I, _I, _P]),
+    "cfm_dwconv_bn_stats_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _P]),
     "cfm_attn_qbias_f32": (c_int, [_P, _L, _P, _P, _P, _P, _L, _I, _P]),
     "cfm_attn_rowdot_f32": (c_int, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "cfm_attn_softmax_bwd_f32": (c_int, [_P, _P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _I, _P]),

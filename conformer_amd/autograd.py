@@ -3,8 +3,8 @@
 
 The reference relies on plain autograd over ~50 eager ops per block (train.py:239); here every Function saves the
 handful of activations its backward kernels need and returns the input gradient -- residual
-path already folded in -- plus all parameter gradients.  fp32 only; dropout p = 0; BatchNorm uses fixed (running)
-statistics in the backward provided here (train-mode batch statistics: not built yet, refused by the modules).
+path already folded in -- plus all parameter gradients.  fp32 only; dropout p = 0 (p > 0 is refused by the modules);
+BatchNorm1d in both modes (running statistics in eval, batch statistics + running update + coupled backward in train).
 """
 from __future__ import annotations
 
@@ -111,17 +111,23 @@ class SelfAttentionFn(Function):
 
 class ConvModuleFn(Function):
     """out = Wpw2 . swish(BN(dwconv(GLU(Wpw1 . LN(x))))) + x       (convolution.py:21-32 + block.py:23)
-    BatchNorm uses the FIXED statistics (bn_mean, bn_var) in forward and backward."""
+    train_bn = False: BatchNorm uses the fixed (running) statistics in forward and backward (eval).
+    train_bn = True : batch statistics over all B*T positions (padded frames included); the running buffers are
+                      updated in place (momentum) and the backward carries the mean/variance coupling."""
 
     @staticmethod
-    def forward(ctx, x, ln_w, ln_b, w1, b1, wd, bd, bn_w, bn_b, bn_mean, bn_var, w2, b2, eps_ln, eps_bn):
+    def forward(ctx, x, ln_w, ln_b, w1, b1, wd, bd, bn_w, bn_b, bn_mean, bn_var, w2, b2, eps_ln, eps_bn, train_bn,
+                momentum):
         h0, mean, rstd = ops.layernorm_train(x, ln_w, ln_b, eps_ln)
         z = ops.linear(h0, w1, b1)                                  # (B,T,2C) pre-activation kept for GLU'
         g = ops.glu_fwd(z)
+        if train_bn:
+            bn_mean, bn_var = ops.dwconv_bn_batch_stats(g, wd, bd, bn_mean, bn_var, momentum)
         s = ops.dwconv_bn_swish(g, wd, bd, bn_w, bn_b, bn_mean, bn_var, eps_bn)
         out = ops.linear_residual(s, w2, b2, x, 1.0)
         ctx.save_for_backward(x, ln_w, mean, rstd, h0, z, g, s, w1, wd, bd, bn_w, bn_b, bn_mean, bn_var, w2)
         ctx.eps_bn = eps_bn
+        ctx.train_bn = bool(train_bn)
         return out
 
     @staticmethod
@@ -130,11 +136,11 @@ class ConvModuleFn(Function):
         dout = dout.contiguous()
         ds, dw2, db2 = ops.linear_bwd(_flat(s), w2, _flat(dout))
         dg, dwd, dbd, dbnw, dbnb = ops.dwconv_bn_swish_bwd(g, ds.view_as(g), wd, bd, bn_w, bn_b, bn_mean, bn_var,
-                                                           ctx.eps_bn)
+                                                           ctx.eps_bn, ctx.train_bn)
         dz = ops.glu_bwd(z, dg)
         dh0, dw1, db1 = ops.linear_bwd(_flat(h0), w1, _flat(dz))
         dx, dlw, dlb = ops.layernorm_bwd(x, ln_w, dh0.view_as(x), mean, rstd, dres=dout)
-        return dx, dlw, dlb, dw1, db1, dwd, dbd, dbnw, dbnb, None, None, dw2, db2, None, None
+        return dx, dlw, dlb, dw1, db1, dwd, dbd, dbnw, dbnb, None, None, dw2, db2, None, None, None, None
 
 
 def needs_grad(module: torch.nn.Module, *tensors: Optional[torch.Tensor]) -> bool:

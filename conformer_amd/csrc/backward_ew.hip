@@ -122,19 +122,20 @@ __global__ __launch_bounds__(256) void glu_bwd_kernel(const float* __restrict__ 
     *reinterpret_cast<f32x4*>(dz + r * 2 * n + n + c) = dg;
 }
 
-// ---- depthwise conv + BN(affine with fixed statistics) + Swish, backward ------------------------------------------------
-// forward: c = b + sum_j w[j] g[t+j-H];  u = (c - mu)*inv*gamma + beta;  y = u*sigmoid(u)
-// pass 1 (this kernel): recompute c,u from g; du = dy*swish'(u); dc = du*inv*gamma -> dc tensor;
-//                       per channel: dbeta += sum du, dgamma += sum du*(c-mu)*inv, dbias += sum dc,
-//                       dw[j] += sum_t dc[t]*g[t+j-H]
-// pass 2 (dwconv_plain_kernel with flipped taps): dg[t] = sum_j w[j] dc[t-j+H]
-template <int K, int TT>
-__global__ __launch_bounds__(256) void dwconv_bn_swish_bwd1_kernel(
+// ---- depthwise conv + BatchNorm + Swish, backward ---------------------------------------------------------------------
+// forward: c = b + sum_j w[j] g[t+j-H];  xhat = (c - mu)*inv;  u = xhat*gamma + beta;  y = u*sigmoid(u)
+// (mu, inv) are either the running statistics (eval) or the batch statistics (train).
+// pass A: recompute c,u from g; du = dy*swish'(u); dcf = du*inv*gamma -> dc tensor; dbeta += sum du, dgamma += sum du*xhat
+// pass B: train only: dc = dcf - gamma*inv/n * (dbeta + xhat*dgamma)   (the batch-statistics coupling), in place;
+//         both modes: dbias += sum dc, dw[j] += sum_t dc[t]*g[t+j-H]
+// pass C (dwconv_plain_kernel with flipped taps): dg[t] = sum_j w[j] dc[t-j+H]
+template <int K, int TT, int PASS>
+__global__ __launch_bounds__(256) void dwconv_bn_swish_bwd_kernel(
     const float* __restrict__ g, const float* __restrict__ dy, const float* __restrict__ w,
     const float* __restrict__ bias, const float* __restrict__ bn_w, const float* __restrict__ bn_b,
     const float* __restrict__ bn_mean, const float* __restrict__ bn_var, float eps, float* __restrict__ dc,
     float* __restrict__ dw, float* __restrict__ dbias, float* __restrict__ dgamma, float* __restrict__ dbeta,
-    int T, int C) {
+    int T, int C, float inv_n /* 0 = fixed statistics */) {
     constexpr int HALF = (K - 1) / 2;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + lane;
@@ -148,6 +149,8 @@ __global__ __launch_bounds__(256) void dwconv_bn_swish_bwd1_kernel(
     for (int j = 0; j < K; ++j) { wr[j] = w[(int64_t)cc * K + j]; dwacc[j] = 0.f; }
     const float inv = 1.0f / sqrtf(bn_var[cc] + eps);
     const float mu = bn_mean[cc], ga = bn_w[cc], be = bn_b[cc], bi = bias[cc];
+    const float k1 = PASS == 1 ? ga * inv * inv_n * dbeta[cc] : 0.f;      // sums are complete: pass A has finished
+    const float k2 = PASS == 1 ? ga * inv * inv_n * dgamma[cc] : 0.f;
     const float* gb = g + (int64_t)b * T * C + cc;
     const float* dyb = dy + (int64_t)b * T * C + cc;
     float* dcb = dc + (int64_t)b * T * C + cc;
@@ -161,27 +164,93 @@ __global__ __launch_bounds__(256) void dwconv_bn_swish_bwd1_kernel(
 #pragma unroll
     for (int o = 0; o < TT; ++o) {
         const int t = t0 + o;
+        const bool tok = t < T;
         float cv = bi;
 #pragma unroll
         for (int j = 0; j < K; ++j) cv = fmaf(wr[j], gwin[o + j], cv);
         const float xh = (cv - mu) * inv;
-        const float u = xh * ga + be;
-        const float sg = sigmoidf_acc(u);
-        const float dyv = (t < T) ? dyb[(int64_t)t * C] : 0.f;
-        const float du = dyv * sg * (1.0f + u * (1.0f - sg));
-        const float dcv = du * inv * ga;
-        if (t < T && cok) dcb[(int64_t)t * C] = dcv;
-        s_du += du; s_dux += du * xh; s_dc += dcv;
+        if (PASS == 0) {
+            const float u = xh * ga + be;
+            const float sg = sigmoidf_acc(u);
+            const float dyv = tok ? dyb[(int64_t)t * C] : 0.f;
+            const float du = dyv * sg * (1.0f + u * (1.0f - sg));
+            if (tok && cok) dcb[(int64_t)t * C] = du * inv * ga;
+            s_du += du; s_dux += du * xh;
+        } else {
+            float dcv = tok ? dcb[(int64_t)t * C] : 0.f;
+            if (tok) dcv -= k1 + xh * k2;
+            if (tok && cok && inv_n != 0.f) dcb[(int64_t)t * C] = dcv;
+            s_dc += dcv;
 #pragma unroll
-        for (int j = 0; j < K; ++j) dwacc[j] = fmaf(dcv, gwin[o + j], dwacc[j]);
+            for (int j = 0; j < K; ++j) dwacc[j] = fmaf(dcv, gwin[o + j], dwacc[j]);
+        }
     }
     if (cok) {
-        atomicAdd(dbeta + c, s_du);
-        atomicAdd(dgamma + c, s_dux);
-        atomicAdd(dbias + c, s_dc);
+        if (PASS == 0) {
+            atomicAdd(dbeta + c, s_du);
+            atomicAdd(dgamma + c, s_dux);
+        } else {
+            atomicAdd(dbias + c, s_dc);
 #pragma unroll
-        for (int j = 0; j < K; ++j) atomicAdd(dw + (int64_t)c * K + j, dwacc[j]);
+            for (int j = 0; j < K; ++j) atomicAdd(dw + (int64_t)c * K + j, dwacc[j]);
+        }
     }
+}
+
+// ---- train-mode BatchNorm statistics of c = dwconv(g) + bias, two passes (mean, then centred second moment) --------------
+//   PASS 0: sum0[c] += sum c ;  PASS 1: sum0[c] += sum (c - mean[c])^2     (the conv is recomputed, c is never stored)
+template <int K, int TT, int PASS>
+__global__ __launch_bounds__(256) void dwconv_stats_kernel(const float* __restrict__ g, const float* __restrict__ w,
+                                                           const float* __restrict__ bias, const float* __restrict__ mean,
+                                                           float* __restrict__ sum0, int T, int C) {
+    constexpr int HALF = (K - 1) / 2;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    const int t0 = (blockIdx.y * 4 + wave) * TT;
+    const int b = blockIdx.z;
+    if (t0 >= T) return;
+    const bool cok = c < C;
+    const int cc = cok ? c : C - 1;
+    float wr[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) wr[j] = w[(int64_t)cc * K + j];
+    const float bi = bias[cc];
+    const float mu = PASS == 1 ? mean[cc] : 0.f;
+    const float* gb = g + (int64_t)b * T * C + cc;
+    float acc[TT];
+#pragma unroll
+    for (int o = 0; o < TT; ++o) acc[o] = bi;
+#pragma unroll
+    for (int tau = 0; tau < TT + K - 1; ++tau) {
+        const int t = t0 + tau - HALF;
+        const float v = (t >= 0 && t < T) ? gb[(int64_t)t * C] : 0.f;
+#pragma unroll
+        for (int o = 0; o < TT; ++o) {
+            const int j = tau - o;
+            if (j >= 0 && j < K) acc[o] = fmaf(wr[j], v, acc[o]);
+        }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int o = 0; o < TT; ++o)
+        if (t0 + o < T) s += PASS == 0 ? acc[o] : (acc[o] - mu) * (acc[o] - mu);
+    if (cok) atomicAdd(sum0 + c, s);
+}
+
+// mean = sum/n; var = m2/n (biased); running <- (1-mom)*running + mom*{mean, var*n/(n-1)}   (convolution.py:16 defaults)
+__global__ void bn_finalize_kernel(float* __restrict__ sum_to_mean, float inv_n, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < C) sum_to_mean[c] *= inv_n;
+}
+__global__ void bn_update_kernel(float* __restrict__ m2_to_var, const float* __restrict__ mean,
+                                 float* __restrict__ run_mean, float* __restrict__ run_var, float inv_n, float unbias,
+                                 float momentum, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float var = m2_to_var[c] * inv_n;
+    m2_to_var[c] = var;
+    if (run_mean) run_mean[c] = (1.0f - momentum) * run_mean[c] + momentum * mean[c];
+    if (run_var) run_var[c] = (1.0f - momentum) * run_var[c] + momentum * var * unbias;
 }
 
 // plain depthwise correlation y[t] = sum_j w[FLIP ? K-1-j : j] x[t+j-H] (no bias): the input-gradient pass
@@ -287,23 +356,27 @@ extern "C" int cfm_glu_bwd_f32(const float* z, const float* dy, float* dz, int64
     return cfm_launch_status();
 }
 
-// Backward of cfm_dwconv_bn_swish_fwd_f32 (BatchNorm with FIXED statistics bn_mean/bn_var -- eval mode, or train mode
-// once the batch statistics have been computed and the mean/var coupling terms are added by the caller).
-// Outputs: dg (B,T,C); dc_ws (B,T,C) workspace; dw (C,K), dbias, dgamma, dbeta (C) accumulated (caller zero-fills).
+// Backward of cfm_dwconv_bn_swish_fwd_f32.  train_stats = 0: bn_mean/bn_var are constants (eval);
+// train_stats = 1: they are the BATCH statistics (biased variance) and the mean/variance coupling of BatchNorm's
+// backward is applied (n = B*T).  Outputs: dg (B,T,C); dc_ws (B,T,C) workspace; dw (C,K), dbias, dgamma, dbeta (C)
+// accumulated (caller zero-fills).
 extern "C" int cfm_dwconv_bn_swish_bwd_f32(const float* g, const float* dy, const float* w, const float* bias,
                                            const float* bn_weight, const float* bn_bias, const float* bn_mean,
-                                           const float* bn_var, float bn_eps, float* dc_ws, float* dg, float* dw,
-                                           float* dbias, float* dgamma, float* dbeta, int B, int T, int C, int K,
-                                           cfm_stream_t stream) {
+                                           const float* bn_var, float bn_eps, int train_stats, float* dc_ws, float* dg,
+                                           float* dw, float* dbias, float* dgamma, float* dbeta, int B, int T, int C,
+                                           int K, cfm_stream_t stream) {
     CFM_REQUIRE(g && dy && w && bias && bn_weight && bn_bias && bn_mean && bn_var && dc_ws && dg && dw && dbias &&
                 dgamma && dbeta, CFM_ERR_NULL);
     CFM_REQUIRE(B > 0 && T > 0 && C > 0 && K > 0 && (K & 1) == 1, CFM_ERR_BAD_SHAPE);
     hipStream_t s = static_cast<hipStream_t>(stream);
     constexpr int TT = 8;
+    const float inv_n = train_stats ? 1.0f / ((float)B * (float)T) : 0.f;
     const dim3 grid((unsigned)((C + 63) / 64), (unsigned)((T + 4 * TT - 1) / (4 * TT)), (unsigned)B), block(256);
-#define DWB(KK)                                                                                                     \
-    hipLaunchKernelGGL((dwconv_bn_swish_bwd1_kernel<KK, TT>), grid, block, 0, s, g, dy, w, bias, bn_weight, bn_bias, \
-                       bn_mean, bn_var, bn_eps, dc_ws, dw, dbias, dgamma, dbeta, T, C);                              \
+#define DWB(KK)                                                                                                      \
+    hipLaunchKernelGGL((dwconv_bn_swish_bwd_kernel<KK, TT, 0>), grid, block, 0, s, g, dy, w, bias, bn_weight, bn_bias, \
+                       bn_mean, bn_var, bn_eps, dc_ws, dw, dbias, dgamma, dbeta, T, C, inv_n);                        \
+    hipLaunchKernelGGL((dwconv_bn_swish_bwd_kernel<KK, TT, 1>), grid, block, 0, s, g, dy, w, bias, bn_weight, bn_bias, \
+                       bn_mean, bn_var, bn_eps, dc_ws, dw, dbias, dgamma, dbeta, T, C, inv_n);                        \
     hipLaunchKernelGGL((dwconv_plain_kernel<KK, TT, true>), grid, block, 0, s, dc_ws, w, dg, T, C)
     switch (K) {
         case 31: DWB(31); break;
@@ -313,5 +386,37 @@ extern "C" int cfm_dwconv_bn_swish_bwd_f32(const float* g, const float* dy, cons
         default: return CFM_ERR_UNSUPPORTED;
     }
 #undef DWB
+    return cfm_launch_status();
+}
+
+// Train-mode BatchNorm statistics of the depthwise-conv output (convolution.py:26-27 in .train()): batch_mean,
+// batch_var (biased) over all B*T positions (padded frames included); running_mean/var (may be NULL)
+// updated in place with `momentum` and the unbiased variance.  The conv output is recomputed, never stored.
+extern "C" int cfm_dwconv_bn_stats_f32(const float* g, const float* w, const float* bias, float* batch_mean,
+                                       float* batch_var, float* running_mean_or_null, float* running_var_or_null,
+                                       float momentum, int B, int T, int C, int K, cfm_stream_t stream) {
+    CFM_REQUIRE(g && w && bias && batch_mean && batch_var, CFM_ERR_NULL);
+    CFM_REQUIRE(B > 0 && T > 0 && C > 0 && K > 0 && (K & 1) == 1, CFM_ERR_BAD_SHAPE);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    constexpr int TT = 16;
+    const int64_t n = (int64_t)B * T;
+    const dim3 grid((unsigned)((C + 63) / 64), (unsigned)((T + 4 * TT - 1) / (4 * TT)), (unsigned)B), block(256);
+    const unsigned cb = (unsigned)((C + 255) / 256);
+    if (hipMemsetAsync(batch_mean, 0, sizeof(float) * C, s) != hipSuccess) return CFM_ERR_LAUNCH;
+    if (hipMemsetAsync(batch_var, 0, sizeof(float) * C, s) != hipSuccess) return CFM_ERR_LAUNCH;
+#define DWS(KK)                                                                                                        \
+    hipLaunchKernelGGL((dwconv_stats_kernel<KK, TT, 0>), grid, block, 0, s, g, w, bias, nullptr, batch_mean, T, C);     \
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cb), dim3(256), 0, s, batch_mean, 1.0f / (float)n, C);                  \
+    hipLaunchKernelGGL((dwconv_stats_kernel<KK, TT, 1>), grid, block, 0, s, g, w, bias, batch_mean, batch_var, T, C)
+    switch (K) {
+        case 31: DWS(31); break;
+        case 15: DWS(15); break;
+        case 7: DWS(7); break;
+        case 3: DWS(3); break;
+        default: return CFM_ERR_UNSUPPORTED;
+    }
+#undef DWS
+    hipLaunchKernelGGL(bn_update_kernel, dim3(cb), dim3(256), 0, s, batch_var, batch_mean, running_mean_or_null,
+                       running_var_or_null, 1.0f / (float)n, n > 1 ? (float)n / (float)(n - 1) : 1.0f, momentum, C);
     return cfm_launch_status();
 }

@@ -37,10 +37,23 @@ class ConvolutionModule(nn.Module):
 
     def fused(self, x: torch.Tensor, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
         refuse_dropout(self, "ConvolutionModule")
-        if self.training:
-            raise NotImplementedError("ConvolutionModule: train-mode BatchNorm (batch statistics) is not built yet; "
-                                      "call .eval() (gradients flow in eval mode with the running statistics)")
         bn = self.batch_norm
+        train_bn = self.training or bn.running_mean is None
+        if train_bn and (bn.momentum is None or not bn.track_running_stats):
+            raise NotImplementedError("ConvolutionModule: only the default BatchNorm1d(momentum=0.1, "
+                                      "track_running_stats=True) is built")
+        if train_bn and not ag.needs_grad(self, x, residual):
+            # .train() under no_grad: still batch statistics + running-stat update (nn.BatchNorm1d semantics)
+            h = ops.layernorm(x, self.layer_norm.weight, self.layer_norm.bias, self.layer_norm.eps)
+            g = ops.linear_glu(h, self.pointwise_conv_1.weight, self.pointwise_conv_1.bias)
+            bm, bv = ops.dwconv_bn_batch_stats(g, self.deepwise_conv.weight, self.deepwise_conv.bias, bn.running_mean,
+                                               bn.running_var, bn.momentum)
+            bn.num_batches_tracked += 1
+            s = ops.dwconv_bn_swish(g, self.deepwise_conv.weight, self.deepwise_conv.bias, bn.weight, bn.bias, bm, bv,
+                                    bn.eps)
+            if residual is None:
+                return ops.linear(s, self.pointwise_conv_2.weight, self.pointwise_conv_2.bias)
+            return ops.linear_residual(s, self.pointwise_conv_2.weight, self.pointwise_conv_2.bias, residual, 1.0)
         if ag.needs_grad(self, x, residual):
             if residual is not None and residual is not x:
                 raise NotImplementedError("ConvolutionModule.fused: pass residual=x (block.py:23)")
@@ -48,7 +61,9 @@ class ConvolutionModule(nn.Module):
                                         self.pointwise_conv_1.bias, self.deepwise_conv.weight, self.deepwise_conv.bias,
                                         bn.weight, bn.bias, bn.running_mean, bn.running_var,
                                         self.pointwise_conv_2.weight, self.pointwise_conv_2.bias,
-                                        self.layer_norm.eps, bn.eps)
+                                        self.layer_norm.eps, bn.eps, train_bn, bn.momentum if train_bn else 0.0)
+            if train_bn:
+                bn.num_batches_tracked += 1
             return out if residual is not None else out - x
         h = ops.layernorm(x, self.layer_norm.weight, self.layer_norm.bias, self.layer_norm.eps)
         g = ops.linear_glu(h, self.pointwise_conv_1.weight, self.pointwise_conv_1.bias)

@@ -277,8 +277,22 @@ def linear_bwd(x2d, w, dy2d, *, alpha: float = 1.0, Z=None, need_dx: bool = True
     return dx, dw.view_as(w), db
 
 
-def dwconv_bn_swish_bwd(g, dy, w, b, bn_w, bn_b, bn_mean, bn_var, eps: float = 1e-5):
-    """Returns (dg, dw, db, dbn_weight, dbn_bias) for the fixed-statistics BatchNorm form."""
+def dwconv_bn_batch_stats(g, w, b, running_mean, running_var, momentum: float = 0.1):
+    """Train-mode BatchNorm statistics of dwconv(g)+b: returns (batch_mean, batch_var_biased) and updates the running
+    buffers in place (momentum 0.1, unbiased variance), as nn.BatchNorm1d does in .train()."""
+    g = _req(g, "g")
+    B, T, C = g.shape
+    K = w.shape[-1]
+    mean = torch.empty(C, device=g.device, dtype=g.dtype)
+    var = torch.empty(C, device=g.device, dtype=g.dtype)
+    st = _lib.load().cfm_dwconv_bn_stats_f32(g.data_ptr(), w.data_ptr(), b.data_ptr(), mean.data_ptr(), var.data_ptr(),
+                                             _p(running_mean), _p(running_var), momentum, B, T, C, K, _stream())
+    _lib.check(st, "cfm_dwconv_bn_stats_f32")
+    return mean, var
+
+
+def dwconv_bn_swish_bwd(g, dy, w, b, bn_w, bn_b, bn_mean, bn_var, eps: float = 1e-5, train_stats: bool = False):
+    """Returns (dg, dw, db, dbn_weight, dbn_bias); train_stats: bn_mean/bn_var are batch statistics."""
     g = _req(g, "g"); dy = _req(dy, "dy")
     B, T, C = g.shape
     K = w.shape[-1]
@@ -290,7 +304,7 @@ def dwconv_bn_swish_bwd(g, dy, w, b, bn_w, bn_b, bn_mean, bn_var, eps: float = 1
     dbe = torch.zeros(C, device=g.device, dtype=g.dtype)
     st = _lib.load().cfm_dwconv_bn_swish_bwd_f32(g.data_ptr(), dy.data_ptr(), w.data_ptr(), b.data_ptr(), bn_w.data_ptr(),
                                                  bn_b.data_ptr(), bn_mean.data_ptr(), bn_var.data_ptr(), eps,
-                                                 dc.data_ptr(), dg.data_ptr(), dw.data_ptr(), db.data_ptr(),
+                                                 int(train_stats), dc.data_ptr(), dg.data_ptr(), dw.data_ptr(), db.data_ptr(),
                                                  dga.data_ptr(), dbe.data_ptr(), B, T, C, K, _stream())
     _lib.check(st, "cfm_dwconv_bn_swish_bwd_f32")
     return dg, dw, db, dga, dbe

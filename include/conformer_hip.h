@@ -156,13 +156,22 @@ int cfm_colsum_f32(const float* X, int64_t ld, int64_t rows, int cols, float alp
 int cfm_glu_fwd_f32(const float* z, float* y, int64_t rows, int n, cfm_stream_t stream);
 int cfm_glu_bwd_f32(const float* z, const float* dy, float* dz, int64_t rows, int n, cfm_stream_t stream);
 
-/* Backward of cfm_dwconv_bn_swish_fwd_f32 (BatchNorm with fixed statistics).  dc_ws: (B,T,C) workspace;
- * dg: (B,T,C); dw (C,K), dbias, dgamma, dbeta (C): accumulated.  K in {3,7,15,31}. */
+/* Backward of cfm_dwconv_bn_swish_fwd_f32.  train_stats = 0: bn_mean/bn_var are constants (eval);
+ * 1: they are the batch statistics and BatchNorm's mean/variance coupling is applied (n = B*T).
+ * dc_ws: (B,T,C) workspace; dg: (B,T,C); dw (C,K), dbias, dgamma, dbeta (C): accumulated.  K in {3,7,15,31}. */
 int cfm_dwconv_bn_swish_bwd_f32(const float* g, const float* dy, const float* w, const float* bias,
                                 const float* bn_weight, const float* bn_bias, const float* bn_mean,
-                                const float* bn_var, float bn_eps, float* dc_ws, float* dg, float* dw,
-                                float* dbias, float* dgamma, float* dbeta, int B, int T, int C, int K,
-                                cfm_stream_t stream);
+                                const float* bn_var, float bn_eps, int train_stats, float* dc_ws, float* dg,
+                                float* dw, float* dbias, float* dgamma, float* dbeta, int B, int T, int C,
+                                int K, cfm_stream_t stream);
+
+/* Train-mode BatchNorm1d statistics of the depthwise-conv output (convolution.py:26-27 under .train()):
+ * batch_mean / batch_var (biased) over all B*T positions, padded frames included; running_mean/var (or NULL)
+ * updated in place: running = (1-momentum)*running + momentum*{mean, unbiased var}.  Feed batch_mean/var to
+ * cfm_dwconv_bn_swish_fwd_f32 as bn_mean/bn_var for the train-mode forward. */
+int cfm_dwconv_bn_stats_f32(const float* g, const float* w, const float* bias, float* batch_mean,
+                            float* batch_var, float* running_mean_or_null, float* running_var_or_null,
+                            float momentum, int B, int T, int C, int K, cfm_stream_t stream);
 
 /* Glue kernels of the attention backward (attention_bwd_f32.hip; the products are cfm_gemm_bwd_batched_f32):
  *   qbias      : qu = q + u_h, qv = q + vbias_h                  (rows = B*T, d = H*dh; u/vbias flattened (d))

@@ -134,6 +134,16 @@ def test_module_grads_vs_reference_golden(dev, case):
     assert rel_l2(y, g["conv_eval_y"]) < 2e-5
     _check_grads(conv, y, x, w, g, "conv_eval")
 
+    # train-mode BatchNorm: batch statistics, running-stat update, coupled backward (convolution.py:27 under .train())
+    convt = _load_sub(ConvolutionModule(d, K), P, blk + "conv.", dev).train()
+    x = fresh_x(); y = convt(x)
+    assert rel_l2(y, g["conv_train_y"]) < 2e-5
+    assert rel_l2(convt.batch_norm.running_mean, g["conv_train_running_mean"]) < 2e-5
+    assert rel_l2(convt.batch_norm.running_var, g["conv_train_running_var"]) < 2e-5
+    assert int(convt.batch_norm.num_batches_tracked) == 4
+    if meta["T"] * g["x"].shape[0] > 2:          # B*T = 2 (d32_t1): rstd ~ 1/sqrt(eps) amplifies fp32 noise 300x
+        _check_grads(convt, y, x, w, g, "conv_train")
+
     block = _load_sub(ConformerBlock(d, H, K), P, blk, dev)
     x = fresh_x(); y = block(x, pe, mask)
     assert rel_l2(y, g["block_y"]) < 2e-5
