@@ -129,19 +129,24 @@ __global__ __launch_bounds__(256) void glu_bwd_kernel(const float* __restrict__ 
 // pass B: train only: dc = dcf - gamma*inv/n * (dbeta + xhat*dgamma)   (the batch-statistics coupling), in place;
 //         both modes: dbias += sum dc, dw[j] += sum_t dc[t]*g[t+j-H]
 // pass C (dwconv_plain_kernel with flipped taps): dg[t] = sum_j w[j] dc[t-j+H]
+// Work split: grid (C/64, time segments, B); a workgroup owns 64 channels x one segment of one utterance, its 4 waves
+// stride over the segment in TT-frame chunks keeping the per-channel partial sums (and the K tap gradients) in
+// registers; the 4 waves are combined through LDS and ONE atomic per (channel[, tap]) per workgroup is issued --
+// the first version issued one per wave per chunk and spent 0.9 ms per layer in atomic contention.
 template <int K, int TT, int PASS>
 __global__ __launch_bounds__(256) void dwconv_bn_swish_bwd_kernel(
     const float* __restrict__ g, const float* __restrict__ dy, const float* __restrict__ w,
     const float* __restrict__ bias, const float* __restrict__ bn_w, const float* __restrict__ bn_b,
     const float* __restrict__ bn_mean, const float* __restrict__ bn_var, float eps, float* __restrict__ dc,
     float* __restrict__ dw, float* __restrict__ dbias, float* __restrict__ dgamma, float* __restrict__ dbeta,
-    int T, int C, float inv_n /* 0 = fixed statistics */) {
+    int T, int C, int seg_len, float inv_n /* 0 = fixed statistics */) {
     constexpr int HALF = (K - 1) / 2;
+    constexpr int NRED = PASS == 0 ? 2 : K + 1;
+    __shared__ float red[4][NRED][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + lane;
-    const int t0 = (blockIdx.y * 4 + wave) * TT;
     const int b = blockIdx.z;
-    if (t0 >= T) return;
+    const int seg0 = blockIdx.y * seg_len, seg1 = min(T, seg0 + seg_len);
     const bool cok = c < C;
     const int cc = cok ? c : C - 1;
     float wr[K], dwacc[K];
@@ -154,46 +159,53 @@ __global__ __launch_bounds__(256) void dwconv_bn_swish_bwd_kernel(
     const float* gb = g + (int64_t)b * T * C + cc;
     const float* dyb = dy + (int64_t)b * T * C + cc;
     float* dcb = dc + (int64_t)b * T * C + cc;
-    float gwin[TT + K - 1];
-#pragma unroll
-    for (int tau = 0; tau < TT + K - 1; ++tau) {
-        const int t = t0 + tau - HALF;
-        gwin[tau] = (t >= 0 && t < T) ? gb[(int64_t)t * C] : 0.f;
-    }
     float s_du = 0.f, s_dux = 0.f, s_dc = 0.f;
+    for (int t0 = seg0 + wave * TT; t0 < seg1; t0 += 4 * TT) {
+        float gwin[TT + K - 1];
 #pragma unroll
-    for (int o = 0; o < TT; ++o) {
-        const int t = t0 + o;
-        const bool tok = t < T;
-        float cv = bi;
+        for (int tau = 0; tau < TT + K - 1; ++tau) {
+            const int t = t0 + tau - HALF;
+            gwin[tau] = (t >= 0 && t < T) ? gb[(int64_t)t * C] : 0.f;
+        }
 #pragma unroll
-        for (int j = 0; j < K; ++j) cv = fmaf(wr[j], gwin[o + j], cv);
-        const float xh = (cv - mu) * inv;
-        if (PASS == 0) {
-            const float u = xh * ga + be;
-            const float sg = sigmoidf_acc(u);
-            const float dyv = tok ? dyb[(int64_t)t * C] : 0.f;
-            const float du = dyv * sg * (1.0f + u * (1.0f - sg));
-            if (tok && cok) dcb[(int64_t)t * C] = du * inv * ga;
-            s_du += du; s_dux += du * xh;
-        } else {
-            float dcv = tok ? dcb[(int64_t)t * C] : 0.f;
-            if (tok) dcv -= k1 + xh * k2;
-            if (tok && cok && inv_n != 0.f) dcb[(int64_t)t * C] = dcv;
-            s_dc += dcv;
+        for (int o = 0; o < TT; ++o) {
+            const int t = t0 + o;
+            const bool tok = t < seg1;
+            float cv = bi;
 #pragma unroll
-            for (int j = 0; j < K; ++j) dwacc[j] = fmaf(dcv, gwin[o + j], dwacc[j]);
+            for (int j = 0; j < K; ++j) cv = fmaf(wr[j], gwin[o + j], cv);
+            const float xh = (cv - mu) * inv;
+            if (PASS == 0) {
+                const float u = xh * ga + be;
+                const float sg = sigmoidf_acc(u);
+                const float dyv = tok ? dyb[(int64_t)t * C] : 0.f;
+                const float du = dyv * sg * (1.0f + u * (1.0f - sg));
+                if (tok && cok) dcb[(int64_t)t * C] = du * inv * ga;
+                s_du += du; s_dux += du * xh;
+            } else {
+                float dcv = tok ? dcb[(int64_t)t * C] : 0.f;
+                if (tok) dcv -= k1 + xh * k2;
+                if (tok && cok && inv_n != 0.f) dcb[(int64_t)t * C] = dcv;
+                s_dc += dcv;
+#pragma unroll
+                for (int j = 0; j < K; ++j) dwacc[j] = fmaf(dcv, gwin[o + j], dwacc[j]);
+            }
         }
     }
-    if (cok) {
-        if (PASS == 0) {
-            atomicAdd(dbeta + c, s_du);
-            atomicAdd(dgamma + c, s_dux);
-        } else {
-            atomicAdd(dbias + c, s_dc);
+    if (PASS == 0) { red[wave][0][lane] = s_du; red[wave][1][lane] = s_dux; }
+    else {
+        red[wave][K][lane] = s_dc;
 #pragma unroll
-            for (int j = 0; j < K; ++j) atomicAdd(dw + (int64_t)c * K + j, dwacc[j]);
-        }
+        for (int j = 0; j < K; ++j) red[wave][j][lane] = dwacc[j];
+    }
+    __syncthreads();
+    // NRED x 64 sums, 256 threads: thread -> (quantity q = tid/64 + 4*i, channel lane)
+    for (int q = wave; q < NRED; q += 4) {
+        const float v = (red[0][q][lane] + red[1][q][lane]) + (red[2][q][lane] + red[3][q][lane]);
+        if (!cok) continue;
+        if (PASS == 0) atomicAdd((q == 0 ? dbeta : dgamma) + c, v);
+        else if (q == K) atomicAdd(dbias + c, v);
+        else atomicAdd(dw + (int64_t)c * K + q, v);
     }
 }
 
@@ -371,12 +383,20 @@ extern "C" int cfm_dwconv_bn_swish_bwd_f32(const float* g, const float* dy, cons
     hipStream_t s = static_cast<hipStream_t>(stream);
     constexpr int TT = 8;
     const float inv_n = train_stats ? 1.0f / ((float)B * (float)T) : 0.f;
-    const dim3 grid((unsigned)((C + 63) / 64), (unsigned)((T + 4 * TT - 1) / (4 * TT)), (unsigned)B), block(256);
-#define DWB(KK)                                                                                                      \
-    hipLaunchKernelGGL((dwconv_bn_swish_bwd_kernel<KK, TT, 0>), grid, block, 0, s, g, dy, w, bias, bn_weight, bn_bias, \
-                       bn_mean, bn_var, bn_eps, dc_ws, dw, dbias, dgamma, dbeta, T, C, inv_n);                        \
-    hipLaunchKernelGGL((dwconv_bn_swish_bwd_kernel<KK, TT, 1>), grid, block, 0, s, g, dy, w, bias, bn_weight, bn_bias, \
-                       bn_mean, bn_var, bn_eps, dc_ws, dw, dbias, dgamma, dbeta, T, C, inv_n);                        \
+    // enough workgroups to fill the chip (>= ~4 per CU) but as few partial-sum atomics as possible
+    const int cblocks = (C + 63) / 64;
+    int nseg = (1024 + cblocks * B - 1) / (cblocks * B);
+    nseg = nseg < 1 ? 1 : nseg;
+    int seg_len = (T + nseg - 1) / nseg;
+    seg_len = (seg_len + 4 * TT - 1) / (4 * TT) * (4 * TT);
+    nseg = (T + seg_len - 1) / seg_len;
+    const dim3 rgrid((unsigned)cblocks, (unsigned)nseg, (unsigned)B), block(256);
+    const dim3 grid((unsigned)cblocks, (unsigned)((T + 4 * TT - 1) / (4 * TT)), (unsigned)B);
+#define DWB(KK)                                                                                                       \
+    hipLaunchKernelGGL((dwconv_bn_swish_bwd_kernel<KK, TT, 0>), rgrid, block, 0, s, g, dy, w, bias, bn_weight, bn_bias, \
+                       bn_mean, bn_var, bn_eps, dc_ws, dw, dbias, dgamma, dbeta, T, C, seg_len, inv_n);                \
+    hipLaunchKernelGGL((dwconv_bn_swish_bwd_kernel<KK, TT, 1>), rgrid, block, 0, s, g, dy, w, bias, bn_weight, bn_bias, \
+                       bn_mean, bn_var, bn_eps, dc_ws, dw, dbias, dgamma, dbeta, T, C, seg_len, inv_n);                \
     hipLaunchKernelGGL((dwconv_plain_kernel<KK, TT, true>), grid, block, 0, s, dc_ws, w, dg, T, C)
     switch (K) {
         case 31: DWB(31); break;

@@ -169,6 +169,19 @@ def subsample_stem(x: torch.Tensor, w1, b1, w2p, b2) -> torch.Tensor:
 # ======================================================================================================
 # training forward variants + backward ops (fp32).  Same rules: HIP tensors only, no eager fallback.
 # ======================================================================================================
+def _zeros_split(device, dtype, *shapes):
+    """One zero-filled allocation (one fill kernel) carved into 16-byte-aligned views: the accumulate-with-atomics
+    outputs (weight/bias gradients) of one backward call."""
+    sizes = [int(torch.Size(sh).numel()) for sh in shapes]
+    padded = [(n + 3) // 4 * 4 for n in sizes]
+    buf = torch.zeros(sum(padded), device=device, dtype=dtype)
+    outs, off = [], 0
+    for sh, n, pn in zip(shapes, sizes, padded):
+        outs.append(buf[off:off + n].view(sh))
+        off += pn
+    return outs
+
+
 def layernorm_train(x, weight, bias, eps: float = 1e-5):
     """LayerNorm forward that also returns the per-row mean / rstd the backward needs."""
     x = _req(x, "x"); weight = _req(weight, "weight"); bias = _req(bias, "bias")
@@ -195,8 +208,7 @@ def layernorm_bwd(x, weight, dy, mean, rstd, dres=None):
     _lib.check(lib.cfm_layernorm_bwd_dx_f32(x.data_ptr(), weight.data_ptr(), dy.data_ptr(), mean.data_ptr(),
                                             rstd.data_ptr(), _p(dres), dx.data_ptr(), rows, d, _stream()),
                "cfm_layernorm_bwd_dx_f32")
-    dw = torch.zeros(d, device=x.device, dtype=x.dtype)
-    db = torch.zeros(d, device=x.device, dtype=x.dtype)
+    dw, db = _zeros_split(x.device, x.dtype, (d,), (d,))
     _lib.check(lib.cfm_layernorm_bwd_params_f32(x.data_ptr(), dy.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
                                                 dw.data_ptr(), db.data_ptr(), rows, d, _stream()),
                "cfm_layernorm_bwd_params_f32")
@@ -233,12 +245,13 @@ def glu_bwd(z, dy):
     return dz
 
 
-def colsum(x2d, alpha: float = 1.0, rows=None, cols=None, ld=None):
-    """alpha * column sums of a (rows, cols) fp32 matrix with row stride ld (bias gradients)."""
+def colsum(x2d, alpha: float = 1.0, rows=None, cols=None, ld=None, out=None):
+    """alpha * column sums of a (rows, cols) fp32 matrix with row stride ld (bias gradients); `out` must be zeroed."""
     rows = x2d.shape[0] if rows is None else rows
     cols = x2d.shape[1] if cols is None else cols
     ld = x2d.stride(0) if ld is None else ld
-    out = torch.zeros(cols, device=x2d.device, dtype=x2d.dtype)
+    if out is None:
+        out = torch.zeros(cols, device=x2d.device, dtype=x2d.dtype)
     _lib.check(_lib.load().cfm_colsum_f32(x2d.data_ptr(), ld, rows, cols, alpha, out.data_ptr(), _stream()),
                "cfm_colsum_f32")
     return out
@@ -272,8 +285,9 @@ def linear_bwd(x2d, w, dy2d, *, alpha: float = 1.0, Z=None, need_dx: bool = True
     dx = None
     if need_dx:
         dx = gemm_bwd(dy2d, False, w2, True, m, k, n, alpha=alpha, Z=Z)
-    dw = gemm_bwd(dy2d, True, x2d, True, n, k, m, alpha=alpha, allow_split=True)
-    db = colsum(dy2d, alpha)
+    dw, db = _zeros_split(x2d.device, x2d.dtype, (n, k), (n,))
+    gemm_bwd(dy2d, True, x2d, True, n, k, m, alpha=alpha, allow_split=True, out=dw)
+    colsum(dy2d, alpha, out=db)
     return dx, dw.view_as(w), db
 
 
@@ -298,10 +312,7 @@ def dwconv_bn_swish_bwd(g, dy, w, b, bn_w, bn_b, bn_mean, bn_var, eps: float = 1
     K = w.shape[-1]
     dc = torch.empty_like(g)
     dg = torch.empty_like(g)
-    dw = torch.zeros_like(w)
-    db = torch.zeros(C, device=g.device, dtype=g.dtype)
-    dga = torch.zeros(C, device=g.device, dtype=g.dtype)
-    dbe = torch.zeros(C, device=g.device, dtype=g.dtype)
+    dw, db, dga, dbe = _zeros_split(g.device, g.dtype, tuple(w.shape), (C,), (C,), (C,))
     st = _lib.load().cfm_dwconv_bn_swish_bwd_f32(g.data_ptr(), dy.data_ptr(), w.data_ptr(), b.data_ptr(), bn_w.data_ptr(),
                                                  bn_b.data_ptr(), bn_mean.data_ptr(), bn_var.data_ptr(), eps,
                                                  int(train_stats), dc.data_ptr(), dg.data_ptr(), dw.data_ptr(), db.data_ptr(),
@@ -382,15 +393,15 @@ def relpos_attention_bwd(qkv, pos, u, v, lengths, n_heads, ctx, lse, dctx):
     # dQu_bh = dS_bh . K_bh                (contraction over keys: dS index-major, K contraction-major)
     gemm_bwd(dS, False, qkv, True, T, dh, T, out=dqkv, lda=T4, ldb=d3, ldc=d3, nbatch=nb, nb1=H,
              sa=sBH_sq, sb=sBH_qkv, sc=sBH_qkv, b_ptr=kp, c_ptr=dq_p)
-    du = colsum(dqkv, rows=N, cols=d, ld=d3).view(H, dh)
+    du, dvb, dpos = _zeros_split(dev, dt, (H, dh), (H, dh), (P, d))
+    colsum(dqkv, rows=N, cols=d, ld=d3, out=du)
     # dQv_bh = dposfull_hb . Pm_h          (contraction over the 2T-1 relative positions)
     dqv = torch.empty(N, d, device=dev, dtype=dt)
     gemm_bwd(dpf, False, pos, True, T, dh, P, out=dqv, lda=P4, ldb=ldp, ldc=d, nbatch=nb, nb1=H,
              sa=sBH_pf, sb=(0, dh), sc=sBH_rows)
-    dvb = colsum(dqv).view(H, dh)
+    colsum(dqv, out=dvb)
     _lib.check(lib.cfm_add_strided_f32(dq_p, d3, dqv.data_ptr(), d, N, d, _stream()), "cfm_add_strided_f32")
     # dPm_h = sum_{b,i} dposfull_h[(b,i), :]^T . Qv_h[(b,i), :]     (contraction over B*T rows, split + atomics)
-    dpos = torch.zeros(P, d, device=dev, dtype=dt)
     gemm_bwd(dpf, True, qv, True, P, dh, N, out=dpos, lda=P4, ldb=d, ldc=d, allow_split=True, nbatch=H, nb1=H,
              sa=(0, B * T * P4), sb=(0, dh), sc=(0, dh))
     return dqkv, dpos, du, dvb
