@@ -42,6 +42,12 @@ SIGNATURES = {
     "cfm_attn_rowdot_f32": (c_int, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "cfm_attn_softmax_bwd_f32": (c_int, [_P, _P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _I, _P]),
     "cfm_add_strided_f32": (c_int, [_P, _L, _P, _L, _L, _I, _P]),
+    "cfm_relu_bwd_f32": (c_int, [_P, _P, _P, _L, _P]),
+    "cfm_subsample_conv2_bwd_weight_f32": (c_int, [_P, _P, _P, _I, _I, _I, _I, _P]),
+    "cfm_pack_conv2_weight_t_f32": (c_int, [_P, _P, _I, _P]),
+    "cfm_subsample_conv2_bwd_input_f32": (c_int, [_P, _P, _P, _I, _I, _I, _I, _P]),
+    "cfm_subsample_conv1_bwd_f32": (c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "cfm_debug_set_bwd_tile": (c_int, [_I]),
     "cfm_debug_gemm_cfg_f32": (c_int, [_I, _P, _P, _P, _P, _F, _P, _L, _I, _I, _P, _P]),
     "cfm_relpos_table_f32": (c_int, [_P, _P, _I, _I, _P]),
     "cfm_relpos_attention_fwd_f32": (c_int, [_P, _P, _P, _L, _P, _L, _P, _P, _P, _P, _L, _P, _I, _I, _I, _I, _P]),

@@ -37,7 +37,8 @@ class LayerNormFn(Function):
 
 
 class LinearFn(Function):
-    """y = x @ w.T + b with x needing no gradient (the batched positional projection, attention.py:81)."""
+    """y = x @ w.T + b (the batched positional projection, attention.py:81, and the encoder's input Linear, encoder.py:23).
+    dx is produced only when x requires grad."""
 
     @staticmethod
     def forward(ctx, x, w, b):
@@ -47,8 +48,26 @@ class LinearFn(Function):
     @staticmethod
     def backward(ctx, dy):
         x, w = ctx.saved_tensors
-        _, dw, db = ops.linear_bwd(_flat(x), w, _flat(dy.contiguous()), need_dx=False)
-        return None, dw, db
+        dx, dw, db = ops.linear_bwd(_flat(x), w, _flat(dy.contiguous()), need_dx=ctx.needs_input_grad[0])
+        return (dx.view_as(x) if dx is not None else None), dw, db
+
+
+class SubsampleStemFn(Function):
+    """h2 (B,T',F'*C) = relu(conv2(relu(conv1(x)))) in the channel-last hot-path layout (convolution.py:42-52).
+    The packed conv2 weight is rebuilt per call in training (weights change every step)."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2):
+        w2p = ops.pack_conv2_weight(w2)
+        h2, h1 = ops.subsample_stem_train(x, w1, b1, w2p, b2)
+        ctx.save_for_backward(x, w1, b1, w2, h1, h2)
+        return h2
+
+    @staticmethod
+    def backward(ctx, dh2):
+        x, w1, b1, w2, h1, h2 = ctx.saved_tensors
+        dw1, db1, dw2, db2 = ops.subsample_stem_bwd(x, w1, b1, w2, h1, h2, dh2.contiguous())
+        return None, dw1, db1, dw2, db2
 
 
 class FeedForwardFn(Function):

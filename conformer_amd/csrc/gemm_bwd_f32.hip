@@ -25,6 +25,11 @@ struct BwdArgs {
     int accumulate;                      // C += ... (non-atomic read-modify-write; not combined with splits)
     int nbatch, nb1;                     // batched: blockIdx.z = b0*nb1 + b1; operand offset = b0*s?0 + b1*s?1
     int64_t sa0, sa1, sb0, sb1, sc0, sc1;
+    // stem-convolution gathers (GATHER != 0): geometry of the 3x3 / stride-2 conv over the channel-last h1
+    int cT1, cF1, cT2, cF2, cC;          // h1: (B,T1,F1,C); h2: (B,T2,F2,C)
+    int pA, pC;                          // GATHER 2: class grid (rows per utterance = pA*pC: a < pA, c < pC)
+    int pt, pf;                          // GATHER 2: parity class: t1 = 2a+pt, f1 = 2c+pf
+    int tap_dt[4], tap_df[4];            // GATHER 2: per class tap: t2 = a + dt, f2 = c + df
 };
 
 template <int BT, bool ROW>
@@ -32,7 +37,11 @@ struct OperandTile {                                    // LDS image of one oper
     static constexpr int FLOATS = ROW ? BT * 20 : 16 * (BT + 4);
 };
 
-template <int BM, int BN, bool AROW, bool BROW, int EPI>
+// GATHER (stem backward, implicit GEMMs -- nothing is im2col'ed in memory):
+//   1: B operand = im2col(h1) read contraction-major: B(kidx, m) = h1[row(m) + tap(kidx)]   (dW2 = dz2^T . im2col(h1))
+//   2: A operand = rows of dz2 selected per (class row, tap), zero when the tap falls outside h2; C rows are scattered
+//      to the class's positions of dh1                                             (dh1 = conv-transpose(dz2, W2))
+template <int BM, int BN, bool AROW, bool BROW, int EPI, int GATHER = 0>
 __global__ __launch_bounds__(256, (BM == 128 && BN == 128) ? 3 : 4) void gemm_bwd_kernel(const BwdArgs g) {
     constexpr int TM = BM / 64, TN = BN / 64, BK = 16;
     constexpr int AF = OperandTile<BM, AROW>::FLOATS, BF = OperandTile<BN, BROW>::FLOATS;
@@ -58,12 +67,49 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 128) ? 3 : 4) void gemm_bw
 
     // ---- staging.  ROW: thread -> (row tid>>2 (+64 p), k-chunk tid&3).  COL: thread -> (k row, 16-byte index chunk).
     f32x4 ra0[TM], rb0[TN], ra1[TM], rb1[TN];
-    auto load_operand = [&](auto& regs, const float* X, int64_t ld, int idx0, int IDX, bool row, int bt, int64_t k0) {
+    // GATHER 2: the TM class rows this thread stages, decoded once: (b, a, c) -> dz2 row base of the (dt,df)=(0,0) tap
+    int g2_b[TM], g2_a[TM], g2_c[TM];
+    if (GATHER == 2) {
+#pragma unroll
+        for (int p = 0; p < TM; ++p) {
+            int idx = i0 + (tid >> 2) + 64 * p;
+            if (idx >= g.I) idx = g.I - 1;
+            const int per = g.pA * g.pC;
+            g2_b[p] = idx / per;
+            const int r = idx - g2_b[p] * per;
+            g2_a[p] = r / g.pC;
+            g2_c[p] = r - g2_a[p] * g.pC;
+        }
+    }
+    auto load_operand = [&](auto& regs, const float* X, int64_t ld, int idx0, int IDX, bool row, int bt, int64_t k0,
+                            int gather) {
         constexpr int NV = sizeof(regs) / sizeof(f32x4);
 #pragma unroll
         for (int p = 0; p < NV; ++p) {
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (row) {
+            if (gather == 2) {                                         // A rows of dz2 per (class row, tap); C % 16 == 0
+                const int tap = (int)(k0 / g.cC);
+                const int co = (int)(k0 - (int64_t)tap * g.cC) + (tid & 3) * 4;
+                const int t2 = g2_a[p] + g.tap_dt[tap], f2 = g2_c[p] + g.tap_df[tap];
+                if (t2 >= 0 && t2 < g.cT2 && f2 >= 0 && f2 < g.cF2)
+                    v = *reinterpret_cast<const f32x4*>(X + (((int64_t)g2_b[p] * g.cT2 + t2) * g.cF2 + f2) * g.cC + co);
+            } else if (gather == 1) {                                  // B = im2col(h1), contraction-major
+                const int cpr = bt >> 2;
+                const int slot = tid + 256 * p;
+                const int kk = slot / cpr, ch = slot - kk * cpr;
+                const int64_t m = k0 + kk;
+                const int idx = idx0 + 4 * ch;                         // K index (tap, ci); a chunk never straddles taps
+                if (m < kend && idx < IDX) {
+                    const int f2 = (int)(m % g.cF2);
+                    const int64_t bt2 = m / g.cF2;
+                    const int t2 = (int)(bt2 % g.cT2);
+                    const int64_t b = bt2 / g.cT2;
+                    const int tap = idx / g.cC, ci = idx - tap * g.cC;
+                    const int kf = tap / 3, ktp = tap - 3 * kf;
+                    v = *reinterpret_cast<const f32x4*>(
+                        X + (((b * g.cT1 + 2 * t2 + ktp) * g.cF1 + 2 * f2 + kf) * (int64_t)g.cC) + ci);
+                }
+            } else if (row) {
                 int idx = idx0 + (tid >> 2) + 64 * p;
                 const int64_t k = k0 + (tid & 3) * 4;
                 if (idx >= IDX) idx = IDX - 1;
@@ -109,8 +155,8 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 128) ? 3 : 4) void gemm_bw
     };
     auto load_tile = [&](f32x4 (&ra)[TM], f32x4 (&rb)[TN], int kt) {
         const int64_t k0 = kbeg + (int64_t)kt * BK;
-        load_operand(ra, Ab, g.lda, i0, g.I, AROW, BM, k0);
-        load_operand(rb, Bb, g.ldb, j0, g.J, BROW, BN, k0);
+        load_operand(ra, Ab, g.lda, i0, g.I, AROW, BM, k0, GATHER == 2 ? 2 : 0);
+        load_operand(rb, Bb, g.ldb, j0, g.J, BROW, BN, k0, GATHER == 1 ? 1 : 0);
     };
     auto store_tile = [&](const f32x4 (&ra)[TM], const f32x4 (&rb)[TN], int buf) {
         store_operand(ra, As + buf * AF, AROW, BM);
@@ -204,7 +250,14 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 128) ? 3 : 4) void gemm_bw
                         v[e] *= sg * (1.0f + z * (1.0f - sg));
                     }
                 }
-                float* dst = Cb + (int64_t)row * g.ldc + col;
+                int64_t crow = row;
+                if (GATHER == 2) {                                         // class row -> position (b, 2a+pt, 2c+pf) of dh1
+                    const int per = g.pA * g.pC;
+                    const int b = row / per, r = row - b * per;
+                    const int a = r / g.pC, c = r - a * g.pC;
+                    crow = ((int64_t)b * g.cT1 + 2 * a + g.pt) * g.cF1 + 2 * c + g.pf;
+                }
+                float* dst = Cb + crow * g.ldc + col;
                 if (full && !atomic) {
                     if (g.accumulate) {
                         const f32x4 o = *reinterpret_cast<const f32x4*>(dst);
@@ -224,7 +277,7 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 128) ? 3 : 4) void gemm_bw
     }
 }
 
-template <int BM, int BN, bool AROW, bool BROW, int EPI>
+template <int BM, int BN, bool AROW, bool BROW, int EPI, int GATHER = 0>
 int launch_one(BwdArgs g, hipStream_t s) {
     g.tiles_i = (unsigned)((g.I + BM - 1) / BM);
     g.tiles_j = (unsigned)((g.J + BN - 1) / BN);
@@ -237,14 +290,23 @@ int launch_one(BwdArgs g, hipStream_t s) {
     g.splits = splits;
     const int64_t per = (g.Kc + splits - 1) / splits;
     g.k_per_split = (per + 15) / 16 * 16;
-    hipLaunchKernelGGL((gemm_bwd_kernel<BM, BN, AROW, BROW, EPI>), dim3(tiles, (unsigned)splits, (unsigned)g.nbatch), dim3(256), 0, s, g);
+    hipLaunchKernelGGL((gemm_bwd_kernel<BM, BN, AROW, BROW, EPI, GATHER>), dim3(tiles, (unsigned)splits, (unsigned)g.nbatch), dim3(256), 0, s, g);
     return cfm_launch_status();
 }
+
+int g_debug_tile = -1;   // diagnostics only (tools/gemm_tune.py bwd): -1 = heuristic, 0 = 128x128, 1 = 128x64, 3 = 64x64
 
 template <bool AROW, bool BROW, int EPI>
 int launch_layout(const BwdArgs& g, hipStream_t s) {
     const int64_t t128 = (int64_t)((g.I + 127) / 128) * ((g.J + 127) / 128) * g.nbatch;
-    if (t128 >= 3 * 256 && g.I >= 96 && g.J >= 96) return launch_one<128, 128, AROW, BROW, EPI>(g, s);
+    int tile = g_debug_tile;
+    if (tile < 0) {
+        if (t128 >= 12 * 256 && g.I >= 96 && g.J >= 96) tile = 0;
+        else if (t128 >= 3 * 256 && g.I >= 96 && g.J >= 48) tile = 1;
+        else tile = 3;
+    }
+    if (tile == 0) return launch_one<128, 128, AROW, BROW, EPI>(g, s);
+    if (tile == 1) return launch_one<128, 64, AROW, BROW, EPI>(g, s);
     return launch_one<64, 64, AROW, BROW, EPI>(g, s);
 }
 
@@ -286,6 +348,53 @@ extern "C" int cfm_gemm_bwd_batched_f32(const float* A, int a_col, int64_t lda, 
     if (a_col && b_col) return launch_layout<false, false, BEPI_SCALE>(g, s);
     return launch_layout<false, true, BEPI_SCALE>(g, s);
 }
+
+// ---- backward of the stem's second convolution (convolution.py:46, 3x3 stride 2, channel-last) ------------------------
+// dw2p (C, 9C) [packed (co, kf, kt, ci) layout of cfm_pack_conv2_weight_f32] += dz2^T . im2col(h1); caller zero-fills.
+extern "C" int cfm_subsample_conv2_bwd_weight_f32(const float* dz2, const float* h1, float* dw2p, int B, int F1, int T1,
+                                                  int C, cfm_stream_t stream) {
+    CFM_REQUIRE(dz2 && h1 && dw2p, CFM_ERR_NULL);
+    CFM_REQUIRE(B > 0 && F1 >= 3 && T1 >= 3 && C > 0 && (C & 3) == 0, CFM_ERR_BAD_SHAPE);
+    CFM_REQUIRE(CFM_ALIGNED16(dz2) && CFM_ALIGNED16(h1) && CFM_ALIGNED16(dw2p), CFM_ERR_ALIGN);
+    BwdArgs g{};
+    g.cT1 = T1; g.cF1 = F1; g.cT2 = (T1 - 1) / 2; g.cF2 = (F1 - 1) / 2; g.cC = C;
+    g.A = dz2; g.B = h1; g.C = dw2p; g.I = C; g.J = 9 * C; g.Kc = (int64_t)B * g.cT2 * g.cF2;
+    g.lda = C; g.ldb = 0; g.ldc = 9 * C; g.alpha = 1.f; g.splits = 0; g.nbatch = 1; g.nb1 = 1;
+    return launch_one<64, 64, false, false, BEPI_SCALE, 1>(g, static_cast<hipStream_t>(stream));
+}
+
+// dh1 (B,T1,F1,C) = conv-transpose(dz2 (B,T2,F2,C), w2): four parity classes of (t1,f1), each a regular implicit GEMM
+// over the 1, 2, 2 or 4 taps that reach it.  w2c: class-packed weights from cfm_pack_conv2_weight_t_f32: for class
+// q = 2*pt+pf a (C_in, ntap_q*C_out) block at offset C*C*{0,4,6,8}[q] floats (9*C*C floats in total).
+extern "C" int cfm_subsample_conv2_bwd_input_f32(const float* dz2, const float* w2c, float* dh1, int B, int F1, int T1,
+                                                 int C, cfm_stream_t stream) {
+    CFM_REQUIRE(dz2 && w2c && dh1, CFM_ERR_NULL);
+    CFM_REQUIRE(B > 0 && F1 >= 3 && T1 >= 3 && C > 0 && (C % 16) == 0, CFM_ERR_BAD_SHAPE);
+    CFM_REQUIRE(CFM_ALIGNED16(dz2) && CFM_ALIGNED16(w2c) && CFM_ALIGNED16(dh1), CFM_ERR_ALIGN);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int T2 = (T1 - 1) / 2, F2 = (F1 - 1) / 2;
+    const int64_t woff[4] = {0, 4, 6, 8};
+    for (int pt = 0; pt < 2; ++pt)
+        for (int pf = 0; pf < 2; ++pf) {
+            BwdArgs g{};
+            g.cT1 = T1; g.cF1 = F1; g.cT2 = T2; g.cF2 = F2; g.cC = C; g.pt = pt; g.pf = pf;
+            g.pA = (T1 - pt + 1) / 2; g.pC = (F1 - pf + 1) / 2;
+            if (g.pA <= 0 || g.pC <= 0) continue;
+            int nt = 0;                                   // taps (kt,kf) with kt = pt (mod 2), kf = pf (mod 2); t2 = a - (kt-pt)/2
+            for (int kt = pt; kt < 3; kt += 2)
+                for (int kf = pf; kf < 3; kf += 2) { g.tap_dt[nt] = -(kt - pt) / 2; g.tap_df[nt] = -(kf - pf) / 2; ++nt; }
+            const int q = 2 * pt + pf;
+            g.A = dz2; g.B = w2c + woff[q] * C * C; g.C = dh1;
+            g.I = B * g.pA * g.pC; g.J = C; g.Kc = (int64_t)nt * C;
+            g.lda = 0; g.ldb = (int64_t)nt * C; g.ldc = C; g.alpha = 1.f; g.splits = 1; g.nbatch = 1; g.nb1 = 1;
+            int st = launch_one<128, 128, true, true, BEPI_SCALE, 2>(g, s);
+            if (st) return st;
+        }
+    return CFM_OK;
+}
+
+// diagnostics only: force the block tile of every later cfm_gemm_bwd* call in this process (-1 restores the heuristic)
+extern "C" int cfm_debug_set_bwd_tile(int tile) { g_debug_tile = tile; return CFM_OK; }
 
 extern "C" int cfm_gemm_bwd_f32(const float* A, int a_col, int64_t lda, const float* B, int b_col, int64_t ldb,
                                 const float* Z_or_null, int64_t ldz, float alpha, float* C, int64_t ldc,

@@ -67,7 +67,128 @@ __global__ __launch_bounds__(256) void pack_linear_kernel(const float* __restric
     wlp[idx] = wl[n * kk + (int64_t)c * F2 + f];
 }
 
+// ---- backward pieces ----------------------------------------------------------------------------------------------
+// class-packed transpose-conv weights: class q = 2*pt+pf, taps (kt,kf) with kt=pt, kf=pf (mod 2) in (kt outer, kf inner)
+// order; w2c[q][ci][tap*C + co] = w2[co][ci][kf][kt]
+__global__ __launch_bounds__(256) void pack_conv2_t_kernel(const float* __restrict__ w2, float* __restrict__ w2c, int C) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t cc = (int64_t)C * C;
+    if (idx >= 9 * cc) return;
+    const int64_t blk = idx / cc;                       // 0..8 in units of C*C
+    const int q = blk < 4 ? 0 : (blk < 6 ? 1 : (blk < 8 ? 2 : 3));
+    const int64_t qoff = (q == 0 ? 0 : (q == 1 ? 4 : (q == 2 ? 6 : 8))) * cc;
+    const int pt = q >> 1, pf = q & 1;
+    const int nkt = pt == 0 ? 2 : 1, nkf = pf == 0 ? 2 : 1, nt = nkt * nkf;
+    const int64_t r = idx - qoff;                       // within the class block: [ci][tap][co]
+    const int co = (int)(r % C);
+    const int tap = (int)((r / C) % nt);
+    const int64_t ci = r / ((int64_t)C * nt);
+    const int kt = pt + 2 * (tap / nkf), kf = pf + 2 * (tap % nkf);
+    w2c[idx] = w2[((co * (int64_t)C + ci) * 3 + kf) * 3 + kt];
+}
+
+// dz = dy where y > 0 else 0 (ReLU backward on the stored OUTPUT), float4
+__global__ __launch_bounds__(256) void relu_bwd_kernel(const float* __restrict__ y, const float* __restrict__ dy,
+                                                       float* __restrict__ dz, int64_t n4) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    const f32x4 a = reinterpret_cast<const f32x4*>(y)[i];
+    f32x4 d = reinterpret_cast<const f32x4*>(dy)[i];
+    d.x = a.x > 0.f ? d.x : 0.f; d.y = a.y > 0.f ? d.y : 0.f; d.z = a.z > 0.f ? d.z : 0.f; d.w = a.w > 0.f ? d.w : 0.f;
+    reinterpret_cast<f32x4*>(dz)[i] = d;
+}
+
+// conv1 parameter gradients: dw1[c][kf][kt] += sum dz1 * x[b][2f1+kf][2t1+kt], db1[c] += sum dz1 with
+// dz1 = dh1 where relu(conv1) > 0 (the pre-activation is recomputed from x: 9 FMAs, h1 need not be re-read).
+// Same thread mapping as the forward kernel (4 channels per thread); block partials through LDS, one atomic per value.
+__global__ __launch_bounds__(256) void conv1_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w1,
+                                                        const float* __restrict__ b1, const float* __restrict__ dh1,
+                                                        float* __restrict__ dw1, float* __restrict__ db1, int B, int F,
+                                                        int T, int C, int F1, int T1, int ppb) {
+    const int c4n = C >> 2;
+    const int c4 = threadIdx.x % c4n;
+    const int pl = threadIdx.x / c4n;
+    const bool act = pl < ppb;
+    float w[4][9], acc[4][10];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int j = 0; j < 9; ++j) { w[i][j] = act ? w1[(c4 * 4 + i) * 9 + j] : 0.f; acc[i][j] = 0.f; }
+        acc[i][9] = 0.f;
+    }
+    const f32x4 bb = act ? *reinterpret_cast<const f32x4*>(b1 + c4 * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    const int64_t npos = (int64_t)B * T1 * F1;
+    if (act)
+        for (int64_t pos = (int64_t)blockIdx.x * ppb + pl; pos < npos; pos += (int64_t)gridDim.x * ppb) {
+            const int f1 = (int)(pos % F1);
+            const int64_t bt = pos / F1;
+            const int t1 = (int)(bt % T1);
+            const int64_t b = bt / T1;
+            const float* xp = x + (b * F + 2 * f1) * (int64_t)T + 2 * t1;
+            float xv[9];
+#pragma unroll
+            for (int kf = 0; kf < 3; ++kf)
+#pragma unroll
+                for (int kt = 0; kt < 3; ++kt) xv[kf * 3 + kt] = xp[(int64_t)kf * T + kt];
+            const f32x4 d = *reinterpret_cast<const f32x4*>(dh1 + pos * C + c4 * 4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float pre = bb[i];
+#pragma unroll
+                for (int j = 0; j < 9; ++j) pre = fmaf(w[i][j], xv[j], pre);
+                const float dz = pre > 0.f ? d[i] : 0.f;
+#pragma unroll
+                for (int j = 0; j < 9; ++j) acc[i][j] = fmaf(dz, xv[j], acc[i][j]);
+                acc[i][9] += dz;
+            }
+        }
+    // threads with the same c4 (different pl) hold partials of the same channels: combine via atomics on global
+    if (act) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int j = 0; j < 9; ++j) atomicAdd(dw1 + (c4 * 4 + i) * 9 + j, acc[i][j]);
+            atomicAdd(db1 + c4 * 4 + i, acc[i][9]);
+        }
+    }
+}
+
 }  // namespace
+
+extern "C" int cfm_pack_conv2_weight_t_f32(const float* w2, float* w2c, int C, cfm_stream_t stream) {
+    CFM_REQUIRE(w2 && w2c, CFM_ERR_NULL);
+    CFM_REQUIRE(C > 0, CFM_ERR_BAD_SHAPE);
+    const int64_t total = 9 * (int64_t)C * C;
+    hipLaunchKernelGGL(pack_conv2_t_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), w2, w2c, C);
+    return cfm_launch_status();
+}
+
+extern "C" int cfm_relu_bwd_f32(const float* y, const float* dy, float* dz, int64_t n, cfm_stream_t stream) {
+    CFM_REQUIRE(y && dy && dz, CFM_ERR_NULL);
+    CFM_REQUIRE(n > 0 && (n & 3) == 0, CFM_ERR_BAD_SHAPE);
+    CFM_REQUIRE(CFM_ALIGNED16(y) && CFM_ALIGNED16(dy) && CFM_ALIGNED16(dz), CFM_ERR_ALIGN);
+    const int64_t n4 = n / 4;
+    hipLaunchKernelGGL(relu_bwd_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), y, dy, dz, n4);
+    return cfm_launch_status();
+}
+
+// dw1 (C,1,3,3), db1 (C) accumulated (caller zero-fills); dh1: gradient w.r.t. h1 = relu(conv1(x)) (B,T1,F1,C)
+extern "C" int cfm_subsample_conv1_bwd_f32(const float* x, const float* w1, const float* b1, const float* dh1, float* dw1,
+                                           float* db1, int B, int F, int T, int C, cfm_stream_t stream) {
+    CFM_REQUIRE(x && w1 && b1 && dh1 && dw1 && db1, CFM_ERR_NULL);
+    CFM_REQUIRE(B > 0 && F >= 3 && T >= 3 && C > 0 && (C & 3) == 0, CFM_ERR_BAD_SHAPE);
+    CFM_REQUIRE(C <= 1024, CFM_ERR_UNSUPPORTED);
+    const int F1 = (F - 1) / 2, T1 = (T - 1) / 2;
+    const int ppb = 256 / (C / 4);
+    const int64_t npos = (int64_t)B * T1 * F1;
+    int64_t blocks = (npos + ppb - 1) / ppb;
+    if (blocks > 512) blocks = 512;                     // few blocks: 40 atomics per thread at the end
+    hipLaunchKernelGGL(conv1_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), x, w1, b1,
+                       dh1, dw1, db1, B, F, T, C, F1, T1, ppb);
+    return cfm_launch_status();
+}
 
 extern "C" int cfm_subsample_conv1_relu_f32(const float* x, const float* w1, const float* b1, float* h1, int B, int F,
                                             int T, int C, cfm_stream_t stream) {

@@ -35,7 +35,7 @@ class Encoder(nn.Module):
     def forward(self, x: torch.Tensor, lengths: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
         refuse_dropout(self, "Encoder")
         d = self.linear.out_features
-        h = self.downsampling_conv.channel_last(x)                                   # (B, T', F'*C); no grad path yet
+        h = self.downsampling_conv.channel_last(x)                                   # (B, T', F'*C)
         out_len = ConvolutionSubsampling.out_lengths(lengths)
         if ag.needs_grad(self.linear):
             # differentiable re-layout of the weight (columns c*F'+f -> f*C+c) so .grad lands in the reference layout

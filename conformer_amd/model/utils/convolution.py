@@ -18,7 +18,7 @@ import torch.nn.functional as F
 
 from ... import autograd as ag
 from ... import ops
-from ._guard import PackCache, refuse_dropout, refuse_grad
+from ._guard import PackCache, refuse_dropout
 from .activation import GLU, Swish
 
 
@@ -94,7 +94,11 @@ class ConvolutionSubsampling(nn.Module):
 
     def channel_last(self, x: torch.Tensor) -> torch.Tensor:
         """(B, n_mel, T) -> (B, T', F'*C) with feature index f*C + c (the hot-path layout)."""
-        refuse_grad(self, "ConvolutionSubsampling", x)
+        if ag.needs_grad(self, x):
+            if x.requires_grad:
+                raise NotImplementedError("ConvolutionSubsampling: the gradient w.r.t. the input spectrogram is not "
+                                          "built (the reference never needs it: the input is data)")
+            return ag.SubsampleStemFn.apply(x, self.conv_1.weight, self.conv_1.bias, self.conv_2.weight, self.conv_2.bias)
         w2p = self._packs.get("w2p", (self.conv_2.weight,), lambda: ops.pack_conv2_weight(self.conv_2.weight))
         return ops.subsample_stem(x, self.conv_1.weight, self.conv_1.bias, w2p, self.conv_2.bias)
 

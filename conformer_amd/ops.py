@@ -405,3 +405,47 @@ def relpos_attention_bwd(qkv, pos, u, v, lengths, n_heads, ctx, lse, dctx):
     gemm_bwd(dpf, True, qv, True, P, dh, N, out=dpos, lda=P4, ldb=d, ldc=d, allow_split=True, nbatch=H, nb1=H,
              sa=(0, B * T * P4), sb=(0, dh), sc=(0, dh))
     return dqkv, dpos, du, dvb
+
+
+# ---- conv-subsampling stem: training forward (keeps h1, h2) and backward -------------------------------------------
+def subsample_stem_train(x, w1, b1, w2p, b2):
+    """Like subsample_stem but also returns h1 (B,T1,F1,C), needed by the backward."""
+    x = _req(x, "x")
+    B, F, T = x.shape
+    C = w1.shape[0]
+    F1, T1 = (F - 1) // 2, (T - 1) // 2
+    F2, T2 = (F1 - 1) // 2, (T1 - 1) // 2
+    lib = _lib.load()
+    h1 = torch.empty(B, T1, F1, C, device=x.device, dtype=x.dtype)
+    _lib.check(lib.cfm_subsample_conv1_relu_f32(x.data_ptr(), w1.data_ptr(), b1.data_ptr(), h1.data_ptr(), B, F, T, C,
+                                                _stream()), "cfm_subsample_conv1_relu_f32")
+    h2 = torch.empty(B, T2, F2 * C, device=x.device, dtype=x.dtype)
+    _lib.check(lib.cfm_subsample_conv2_relu_f32(h1.data_ptr(), w2p.data_ptr(), b2.data_ptr(), h2.data_ptr(), B, F1, T1,
+                                                C, _stream()), "cfm_subsample_conv2_relu_f32")
+    return h2, h1
+
+
+def subsample_stem_bwd(x, w1, b1, w2, h1, h2, dh2):
+    """Returns (dw1, db1, dw2 [reference (Co,Ci,3,3) layout], db2)."""
+    lib = _lib.load()
+    B, F, T = x.shape
+    C = w1.shape[0]
+    F1, T1 = (F - 1) // 2, (T - 1) // 2
+    F2, T2 = (F1 - 1) // 2, (T1 - 1) // 2
+    dh2 = _req(dh2, "dh2")
+    dz2 = torch.empty_like(dh2)
+    _lib.check(lib.cfm_relu_bwd_f32(h2.data_ptr(), dh2.data_ptr(), dz2.data_ptr(), dz2.numel(), _stream()),
+               "cfm_relu_bwd_f32")
+    dw2p, db2, dw1, db1 = _zeros_split(x.device, x.dtype, (C, 9 * C), (C,), tuple(w1.shape), (C,))
+    colsum(dz2.view(-1, C), out=db2)
+    _lib.check(lib.cfm_subsample_conv2_bwd_weight_f32(dz2.data_ptr(), h1.data_ptr(), dw2p.data_ptr(), B, F1, T1, C,
+                                                      _stream()), "cfm_subsample_conv2_bwd_weight_f32")
+    w2c = torch.empty(9 * C * C, device=x.device, dtype=x.dtype)
+    _lib.check(lib.cfm_pack_conv2_weight_t_f32(w2.data_ptr(), w2c.data_ptr(), C, _stream()), "cfm_pack_conv2_weight_t_f32")
+    dh1 = torch.empty_like(h1)
+    _lib.check(lib.cfm_subsample_conv2_bwd_input_f32(dz2.data_ptr(), w2c.data_ptr(), dh1.data_ptr(), B, F1, T1, C,
+                                                     _stream()), "cfm_subsample_conv2_bwd_input_f32")
+    _lib.check(lib.cfm_subsample_conv1_bwd_f32(x.data_ptr(), w1.data_ptr(), b1.data_ptr(), dh1.data_ptr(), dw1.data_ptr(),
+                                               db1.data_ptr(), B, F, T, C, _stream()), "cfm_subsample_conv1_bwd_f32")
+    dw2 = dw2p.view(C, 3, 3, C).permute(0, 3, 1, 2).contiguous()        # packed (co,kf,kt,ci) -> (co,ci,kf,kt): tiny glue
+    return dw1, db1, dw2, db2

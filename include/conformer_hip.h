@@ -196,6 +196,23 @@ int cfm_debug_gemm_cfg_f32(int cfg, const float* A, const float* W, const float*
                            float alpha, float* C, int64_t M, int N, int K, void* trace_or_null,
                            cfm_stream_t stream);
 
+/* Backward of the conv-subsampling stem (convolution.py:42-52).  With dz2 = relu'(h2) * dh2 (cfm_relu_bwd_f32):
+ *   conv2_bwd_weight: dw2p (C, 9C) in the PACKED (co,kf,kt,ci) layout += dz2^T . im2col(h1)   (zero-filled by caller;
+ *                     un-pack with the inverse of cfm_pack_conv2_weight_f32)
+ *   pack_conv2_weight_t + conv2_bwd_input: dh1 (B,T1,F1,C) = conv-transpose(dz2, w2) as four parity-class implicit GEMMs
+ *   conv1_bwd: dw1 (C,1,3,3), db1 (C) accumulated from dh1 (ReLU mask recomputed from x)                       */
+int cfm_relu_bwd_f32(const float* y, const float* dy, float* dz, int64_t n, cfm_stream_t stream);
+int cfm_subsample_conv2_bwd_weight_f32(const float* dz2, const float* h1, float* dw2p, int B, int F1, int T1,
+                                       int C, cfm_stream_t stream);
+int cfm_pack_conv2_weight_t_f32(const float* w2, float* w2c, int C, cfm_stream_t stream);
+int cfm_subsample_conv2_bwd_input_f32(const float* dz2, const float* w2c, float* dh1, int B, int F1, int T1,
+                                      int C, cfm_stream_t stream);
+int cfm_subsample_conv1_bwd_f32(const float* x, const float* w1, const float* b1, const float* dh1, float* dw1,
+                                float* db1, int B, int F, int T, int C, cfm_stream_t stream);
+
+/* diagnostics only (process-global, not thread-safe): force the block tile of cfm_gemm_bwd* (-1 = heuristic) */
+int cfm_debug_set_bwd_tile(int tile);
+
 /* ---- integer helpers of the path (host-side, no device work) ---------------------------------
  *      frames after the stem: ((n-1)/2-1)/2, convolution.py:55 */
 int64_t cfm_subsampled_length(int64_t n);

@@ -151,14 +151,13 @@ def test_module_grads_vs_reference_golden(dev, case):
 
 
 def test_encoder_grads_vs_reference_golden(dev):
-    """Tiny 2-block encoder: parameter gradients of sum(enc*w) for everything behind the (frozen) stem."""
+    """Tiny 2-block encoder: every parameter gradient of sum(enc*w), stem included."""
     from model.modules.encoder import Encoder
     meta, g = load_golden("model_tiny")
     P = cfg_params(meta)
     enc = Encoder(80, meta["n_blocks"], meta["d"], meta["n_heads"], meta["ksize"], 0.0)
     enc.load_state_dict({k[len("encoder."):]: v for k, v in P.items() if k.startswith("encoder.")}, strict=True)
     enc = enc.to(dev).eval()
-    enc.downsampling_conv.requires_grad_(False)          # stem backward kernels are not built yet
     y, _ = enc(g["x"].to(dev), g["lengths"].to(dev))
     assert rel_l2(y, g["enc"]) < 1e-4
     (y * g["w"].to(dev)).sum().backward()

@@ -142,11 +142,11 @@ def test_encoder_cfg2_shapes_vs_oracle(dev):
 
 
 def test_unbuilt_training_features_are_refused_loudly(dev):
-    """No silent fallback: what has no kernels yet raises (dropout masks, stem backward)."""
+    """No silent fallback: what has no kernels yet raises (dropout masks; gradient w.r.t. the input spectrogram)."""
     from model.modules.encoder import Encoder
     from model.utils.ffn import FeedForwardModule
     with pytest.raises(NotImplementedError):
         FeedForwardModule(32, dropout_rate=0.1).to(dev).train()(torch.zeros(2, 4, 32, device=dev))
     enc = Encoder(80, 1, 32, 4, 7).to(dev).eval()
-    with pytest.raises(NotImplementedError):                       # stem parameters still require grad
-        enc(torch.zeros(1, 80, 40, device=dev), None)
+    with pytest.raises(NotImplementedError):
+        enc(torch.zeros(1, 80, 40, device=dev, requires_grad=True), None)

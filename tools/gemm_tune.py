@@ -104,7 +104,49 @@ def occ_sweep():
             print(line, flush=True)
 
 
+def bwd_sweep():
+    """Backward-GEMM products of the hot path at every block tile."""
+    from conformer_amd import ops
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    M = 7968
+    cases = []
+    for (N, K) in [(2048, 512), (512, 2048), (1536, 512), (512, 512), (1024, 512)]:
+        cases.append((f"dX  M x{K:5d} (Kc={N:5d})", False, True, M, K, N, False))      # dY (M,N) . W (N,K)
+        cases.append((f"dW {N:5d}x{K:5d} (Kc=M)   ", True, True, N, K, M, True))         # dY^T . X
+    cases.append(("dZ  M x 2048 (Kc=512) dswish", False, True, M, 2048, 512, False))
+    for name, a_col, b_col, I, J, Kc, split in cases:
+        A = torch.randn((Kc, I) if a_col else (I, Kc), device=dev)
+        Bm = torch.randn((Kc, J) if b_col else (J, Kc), device=dev)
+        Z = torch.randn(I, J, device=dev) if "dswish" in name else None
+        line = f"{name}: "
+        for tile in (0, 1, 3, -1):
+            lib.cfm_debug_set_bwd_tile(tile)
+            out = torch.zeros(I, J, device=dev)
+
+            def run():
+                ops.gemm_bwd(A, a_col, Bm, b_col, I, J, Kc, Z=Z, out=out, allow_split=split)
+            for _ in range(3):
+                run()
+            torch.cuda.synchronize()
+            best = 1e9
+            for _ in range(4):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(10):
+                    run()
+                e1.record()
+                torch.cuda.synchronize()
+                best = min(best, e0.elapsed_time(e1) / 10)
+            tname = {0: "128x128", 1: "128x64", 3: "64x64", -1: "auto"}[tile]
+            line += f"| {tname:>7s} {best * 1e3:6.1f}us {2.0 * I * J * Kc / best / 1e9:5.1f} "
+        lib.cfm_debug_set_bwd_tile(-1)
+        print(line, flush=True)
+
+
 def main():
+    if len(sys.argv) == 2 and sys.argv[1] == "bwd":
+        return bwd_sweep()
     if len(sys.argv) == 2 and sys.argv[1] == "occ":
         return occ_sweep()
     if len(sys.argv) == 6 and sys.argv[1] == "trace":

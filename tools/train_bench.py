@@ -3,8 +3,7 @@
 
     python tools/train_bench.py [--batch 32] [--steps 5] [--blocks 16]
 
-Stem parameters are frozen (their backward kernels are not built yet); loss = sum(enc * w) so the timing isolates
-the encoder's forward+backward.  Prints ms/step and mel-frames/s.
+loss = sum(enc * w), so the timing isolates the encoder's forward + backward (all parameters, stem included).  Prints ms/step and mel-frames/s.
 """
 import argparse
 import os
@@ -27,7 +26,6 @@ def main():
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
     enc = Encoder(80, args.blocks, 512, 8, 31, 0.0).to(dev).train()
-    enc.downsampling_conv.requires_grad_(False)
     x = torch.randn(args.batch, 80, args.frames, device=dev)
     L = torch.full((args.batch,), args.frames, dtype=torch.int64, device=dev)
     w = None
