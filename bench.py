@@ -154,18 +154,17 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    from conformer_amd import parallel
+    env = parallel.env_from_os()
+    world, rank, local = env.world, env.rank, env.local_rank
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the Conformer hot path has no CPU fallback")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
-    if world > 1:
+    if parallel.init_distributed(env, dev):                 # backend "nccl" = RCCL on ROCm
         import torch.distributed as dist_
         dist = dist_
-        dist.init_process_group("nccl", device_id=dev)     # "nccl" is RCCL on ROCm
     if args.gpus != world and rank == 0:
         log(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; reporting n_gpus={world}")
 
@@ -184,24 +183,14 @@ def main():
             return enc(x, lengths)
 
     log(f"[bench] rank {rank}/{world}: model on {dev}, warm-up {args.warmup} steps")
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        y, _ = step()
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if dist:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    last = {}
+
+    def step():
+        with torch.no_grad():
+            last["y"], _ = enc(x, lengths)
+
+    dt = parallel.timed_steps(step, args.steps, args.warmup, torch.cuda.synchronize, dev)
+    y = last["y"]
     if not torch.isfinite(y).all():
         raise SystemExit("non-finite encoder output")
 

@@ -38,7 +38,7 @@ class ConvolutionModule(nn.Module):
     def fused(self, x: torch.Tensor, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
         refuse_dropout(self, "ConvolutionModule")
         bn = self.batch_norm
-        train_bn = self.training or bn.running_mean is None
+        train_bn = bn.training or bn.running_mean is None      # nn.BatchNorm1d semantics: the BN sub-module's own flag
         if train_bn and (bn.momentum is None or not bn.track_running_stats):
             raise NotImplementedError("ConvolutionModule: only the default BatchNorm1d(momentum=0.1, "
                                       "track_running_stats=True) is built")

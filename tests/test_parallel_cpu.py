@@ -1,0 +1,83 @@
+"""world_size-2 gloo tests (CPU) of the data-parallel host logic: batch sharding, the bench.py timing contract
+(barrier + max over ranks), and DDP gradient averaging through conformer_amd.parallel.wrap_ddp."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from conformer_amd import parallel
+    env = parallel.env_from_os()
+    assert parallel.init_distributed(env, torch.device("cpu"))
+    try:
+        # 1. sharding: contiguous, disjoint, covering
+        lo, hi = parallel.shard_range(7, rank, world)
+        sizes = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+        dist.all_gather(sizes, torch.tensor([hi - lo]))
+        # 2. timing contract: rank 1 is slower; every rank must report the max
+        import time
+        calls = {"n": 0}
+
+        def step():
+            calls["n"] += 1
+            time.sleep(0.02 * (rank + 1))
+
+        dt = parallel.timed_steps(step, steps=3, warmup=2, sync=lambda: None)
+        # 3. DDP gradient averaging == full-batch gradient of the mean loss
+        torch.manual_seed(0)
+        model = torch.nn.Linear(8, 4)
+        ddp = parallel.wrap_ddp(model)
+        xs = torch.arange(6 * 8, dtype=torch.float32).reshape(6, 8) / 10
+        a, b = parallel.shard_range(6, rank, world)
+        ddp(xs[a:b]).pow(2).mean().backward()
+        ref = torch.nn.Linear(8, 4)
+        ref.load_state_dict(model.state_dict())
+        ref(xs).pow(2).mean().backward()
+        gerr = float((model.weight.grad - ref.weight.grad).abs().max())
+        q.put((rank, (lo, hi), [int(s) for s in sizes], calls["n"], dt, gerr))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gloo_harness():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (r0, s0, sizes0, n0, dt0, g0), (r1, s1, sizes1, n1, dt1, g1) = res
+    assert s0 == (0, 4) and s1 == (4, 7) and sizes0 == [4, 3] == sizes1
+    assert n0 == n1 == 5                                   # 2 warm-up + exactly 3 timed steps
+    assert abs(dt0 - dt1) < 1e-6 and dt0 >= 3 * 0.04 - 1e-3    # both report the slow rank's time
+    assert g0 < 1e-6 and g1 < 1e-6
+
+
+def test_shard_range_properties():
+    from conformer_amd.parallel import shard_range
+    for n in (0, 1, 7, 32, 512):
+        for w in (1, 2, 3, 8):
+            parts = [shard_range(n, r, w) for r in range(w)]
+            assert parts[0][0] == 0 and parts[-1][1] == n
+            assert all(parts[i][1] == parts[i + 1][0] for i in range(w - 1))
+            assert max(h - l for l, h in parts) - min(h - l for l, h in parts) <= 1
