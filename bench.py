@@ -88,7 +88,7 @@ def gemm_site_table(enc, x, iters):
     qkvw, qkvb = att._qkv_params()
     wl = enc.linear.weight
     sites = [
-        ("gemm<relu,conv>  stem conv2 implicit GEMM", (B * Tp * Fp, d, 9 * d), 1, conv2),
+        ("gemm<relu,conv>  stem conv2 implicit GEMM", (B * Tp * Fp, d, 9 * d), 1, conv2),   # pmc: gemm_f32_kernel<128, 128, 2, true>
         ("gemm<bias>       input linear", (N, d, Fp * d), 1, lambda: ops.linear(h2, wl, enc.linear.bias)),
         ("gemm<swish>      FFN hidden", (N, 4 * d, d), 2 * L,
          lambda: ops.linear(a_d, lay.ffn_1.hidden_linear.weight, lay.ffn_1.hidden_linear.bias, act="swish")),
@@ -106,8 +106,13 @@ def gemm_site_table(enc, x, iters):
         avg, med = time_events(fn, iters)
         log(f"[bench] {name}: {m}x{n}x{k} avg {avg:.3f} ms  {2.0 * m * n * k / avg / 1e9:.1f} TFLOP/s")
         fl = 2.0 * m * n * k
-        rows.append(dict(kernel=name, M=m, N=n, K=k, launches_per_step=per_step, avg_ms=avg, med_ms=med,
-                         tflops=fl / (avg * 1e-3) / 1e12, flops=fl))
+        row = dict(kernel=name, M=m, N=n, K=k, launches_per_step=per_step, avg_ms=avg, med_ms=med,
+                   tflops=fl / (avg * 1e-3) / 1e12, flops=fl)
+        if "conv2" in name:
+            row["pmc_name"] = "gemm_f32_kernel<128, 128, 2, true>"
+            # h1 read once + packed weight + h2 written (the stem's ideal traffic)
+            row["alg_bytes"] = 4.0 * (B * T1 * F1 * d + 9 * d * d + B * Tp * Fp * d)
+        rows.append(row)
     return rows
 
 
@@ -143,6 +148,21 @@ def cpu_baseline(enc, sample_b):
     return dict(value=sample_b * CFG["T"] / t, unit="audio-frames/sec", cores=cores, kind="port",
                 sample=f"oracle Encoder.forward fp32 on the same weights, B={sample_b} of 32, T=1000, 16 blocks, best of 2 after 1 warm-up "
                        f"({t:.2f} s/run, torch {torch.get_num_threads()} threads)")
+
+
+def pmc_traffic_bytes(kernel_substr: str):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE
+    collected in separate --pmc runs of this same command, corrected as MI355X_MICROARCH.md prescribes: KiB units,
+    FETCH_SIZE doubled on gfx950) -- tools/pmc_traffic.py writes the file; None when it is absent."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    try:
+        table = json.load(open(path))
+    except (OSError, ValueError):
+        return None
+    for name, v in table.items():
+        if kernel_substr in name:
+            return v["hbm_bytes_per_launch"]
+    return None
 
 
 def main():
@@ -217,10 +237,14 @@ def main():
         out["roofline"] = {
             "bound": "mfma", "kernel": dom["kernel"], "shape_MNK": [dom["M"], dom["N"], dom["K"]],
             "achieved": dom["tflops"], "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s",
-            "frac": dom["tflops"] / PEAK_MFMA_F32_TFLOPS, "traffic": None,
+            "frac": dom["tflops"] / PEAK_MFMA_F32_TFLOPS,
+            "traffic": pmc_traffic_bytes(dom["pmc_name"]) if dom.get("pmc_name") else None,
+            "traffic_unit": "HBM bytes per launch (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_pmc_traffic.json)",
+            "algorithmic_bytes": dom.get("alg_bytes"),
             "avg_launch_ms": dom["avg_ms"], "launches_per_step": dom["launches_per_step"],
             "gemm_ms_per_step": tot, "gemm_share_of_step": tot / ms,
-            "all_gemm_sites": [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in r.items() if k != "flops"}
+            "all_gemm_sites": [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in r.items()
+                                if k not in ("flops", "pmc_name", "alg_bytes")}
                                for r in rows],
         }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
