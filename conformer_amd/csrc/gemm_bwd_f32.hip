@@ -327,8 +327,7 @@ extern "C" int cfm_gemm_bwd_batched_f32(const float* A, int a_col, int64_t lda, 
     CFM_REQUIRE(I > 0 && J > 0 && Kc > 0 && nbatch > 0 && nb1 > 0 && nbatch % nb1 == 0 && nbatch <= 65535, CFM_ERR_BAD_SHAPE);
     CFM_REQUIRE((ldc & 3) == 0 && (lda & 3) == 0 && (ldb & 3) == 0, CFM_ERR_BAD_SHAPE);
     CFM_REQUIRE(((sa0 | sa1 | sb0 | sb1 | sc0 | sc1) & 3) == 0, CFM_ERR_BAD_SHAPE);
-    CFM_REQUIRE(a_col || lda >= Kc, CFM_ERR_BAD_SHAPE);
-    CFM_REQUIRE(b_col || ldb >= Kc, CFM_ERR_BAD_SHAPE);
+    // (lda < Kc is legal for an index-major operand: overlapping rows, e.g. STFT frames with lda = hop)
     CFM_REQUIRE(CFM_ALIGNED16(A) && CFM_ALIGNED16(B) && CFM_ALIGNED16(C), CFM_ERR_ALIGN);
     CFM_REQUIRE(!Z_or_null || (CFM_ALIGNED16(Z_or_null) && (ldz & 3) == 0), CFM_ERR_ALIGN);
     BwdArgs g{};

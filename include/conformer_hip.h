@@ -115,6 +115,17 @@ int cfm_subsample_conv2_relu_f32(const float* h1, const float* w2p, const float*
                                  int B, int F1, int T1, int C, cfm_stream_t stream);
 int cfm_pack_linear_weight_f32(const float* wl, float* wlp, int d_out, int C, int F2, cfm_stream_t stream);
 
+/* ---- audio front end (processing/processor.py:53-63,155-158,373-394; processing/augment.py:7-19).
+ *      log-mel = reflect_pad -> [frames * window * DFT] as cfm_gemm_bwd_batched_f32 over overlapping rows
+ *      (A = padded wave, lda = hop; B = windowed (2*n_bins, n_fft) cos/-sin basis) -> power_mel_log:
+ *      out (B, n_mels, T) = log(max(fb^T . (Re^2+Im^2), floor)); spec rows = frames (B*T, ld_spec), fb (n_bins, n_mels).
+ *      specaugment_apply: bands (n,3) int32 device rows {axis 1=freq | 2=time, start, end}, applied to every utterance. */
+int cfm_reflect_pad_f32(const float* x, float* xp, int B, int64_t L, int pad, int64_t ld_out, cfm_stream_t stream);
+int cfm_power_mel_log_f32(const float* spec, int64_t ld_spec, const float* fb, float* out, int B, int T,
+                          int n_bins, int n_mels, float floor_value, cfm_stream_t stream);
+int cfm_specaugment_apply_f32(float* spec, int B, int F, int T, const int* bands, int nbands, float value,
+                              cfm_stream_t stream);
+
 /* =============================== backward pass (fp32) =========================================
  * The reference relies on autograd (train.py:239); these are the explicit kernels behind the
  * torch.autograd.Function wrappers in conformer_amd/autograd.py.  Parameter-gradient outputs that
