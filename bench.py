@@ -172,6 +172,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="launch the ~260 kernels eagerly instead of one hipGraph replay")
     args = ap.parse_args()
 
     from conformer_amd import parallel
@@ -204,10 +205,17 @@ def main():
 
     log(f"[bench] rank {rank}/{world}: model on {dev}, warm-up {args.warmup} steps")
     last = {}
+    runner, graphed = enc, False
+    if not args.no_graph:
+        try:
+            from conformer_amd.graph import GraphedEncoder
+            runner, graphed = GraphedEncoder(enc, x, lengths), True
+        except Exception as e:                               # capture is an optimisation: fall back to eager launches
+            log(f"[bench] hipGraph capture unavailable ({type(e).__name__}: {e}); eager launches")
 
     def step():
         with torch.no_grad():
-            last["y"], _ = enc(x, lengths)
+            last["y"], _ = runner(x, lengths)
 
     dt = parallel.timed_steps(step, args.steps, args.warmup, torch.cuda.synchronize, dev)
     y = last["y"]
@@ -222,7 +230,7 @@ def main():
         "metric": "encoder audio-frames/sec (B=32,T=1000,d=512,L=16)",
         "value": frames / dt, "unit": "audio-frames/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        "dtype": "f32", "data": "synthetic", "launch": "hipGraph replay" if graphed else "eager",
         "config": {"workload": "cfg2 Conformer-L Encoder.forward: B=32/GPU, T=1000 mel frames (T'=249), d=512, 16 blocks, "
                                "8 heads, k=31, fp32, eval, random-init weights, batch-sharded replicas",
                    "per_gpu_batch": CFG["B"], "mel_frames": CFG["T"]},

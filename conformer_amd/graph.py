@@ -1,0 +1,44 @@
+"""hipGraph capture of the encoder forward (static shapes): the ~260 kernel launches of one Encoder.forward are recorded
+once and replayed with a single host call, so small configurations stop being launch-bound and large ones lose the
+host-side gaps.  Uses torch.cuda.CUDAGraph (= hipGraph on ROCm): every kernel of libconformer_hip.so is enqueued on
+torch's current stream and never allocates or synchronises, which is exactly what stream capture requires; outputs
+and intermediates live in the graph's private memory pool.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+
+
+class GraphedEncoder:
+    """Wraps an eval-mode Encoder for fixed (B, n_mel, T) inputs.  `lengths` is part of the static input (its VALUES may
+    change between replays: the attention kernel reads them from device memory)."""
+
+    def __init__(self, encoder: torch.nn.Module, example_x: torch.Tensor, example_lengths: Optional[torch.Tensor],
+                 warmup: int = 2) -> None:
+        if encoder.training:
+            raise ValueError("GraphedEncoder captures the inference path: call encoder.eval() first")
+        self.encoder = encoder
+        self.static_x = example_x.clone()
+        self.static_len = None if example_lengths is None else example_lengths.clone()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side), torch.no_grad():
+            for _ in range(warmup):                      # builds every cached pack / table outside the capture
+                encoder(self.static_x, self.static_len)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.no_grad(), torch.cuda.graph(self.graph):
+            self.static_y, self.static_out_len = encoder(self.static_x, self.static_len)
+
+    def __call__(self, x: torch.Tensor, lengths: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+        if x.shape != self.static_x.shape:
+            raise ValueError(f"graph captured for input {tuple(self.static_x.shape)}, got {tuple(x.shape)}")
+        if x.data_ptr() != self.static_x.data_ptr():
+            self.static_x.copy_(x)
+        if self.static_len is not None and lengths is not None and lengths.data_ptr() != self.static_len.data_ptr():
+            self.static_len.copy_(lengths)
+        self.graph.replay()
+        return self.static_y, self.static_out_len

@@ -150,3 +150,24 @@ def test_unbuilt_training_features_are_refused_loudly(dev):
     enc = Encoder(80, 1, 32, 4, 7).to(dev).eval()
     with pytest.raises(NotImplementedError):
         enc(torch.zeros(1, 80, 40, device=dev, requires_grad=True), None)
+
+
+def test_graphed_encoder_matches_eager(dev):
+    """hipGraph replay of the forward == eager launches, also after the input and the lengths change."""
+    from conformer_amd.graph import GraphedEncoder
+    from model.modules.encoder import Encoder
+    meta, g = load_golden("model_tiny")
+    P = cfg_params(meta)
+    enc = Encoder(80, meta["n_blocks"], meta["d"], meta["n_heads"], meta["ksize"], 0.0)
+    enc.load_state_dict({k[len("encoder."):]: v for k, v in P.items() if k.startswith("encoder.")}, strict=True)
+    enc = enc.to(dev).eval()
+    x, L = g["x"].to(dev), g["lengths"].to(dev)
+    ge = GraphedEncoder(enc, x, L)
+    y, L2 = ge(x, L)
+    assert rel_l2(y, g["enc"]) < 1e-4 and torch.equal(L2.cpu(), g["out_lengths"])
+    x2 = torch.flip(x, dims=[0]).contiguous()
+    L3 = torch.tensor([103, 103, 60], device=dev)
+    with torch.no_grad():
+        ref, _ = enc(x2, L3)
+    y2, _ = ge(x2, L3)
+    assert torch.equal(y2, ref)
