@@ -41,7 +41,11 @@ struct OperandTile {                                    // LDS image of one oper
 //   1: B operand = im2col(h1) read contraction-major: B(kidx, m) = h1[row(m) + tap(kidx)]   (dW2 = dz2^T . im2col(h1))
 //   2: A operand = rows of dz2 selected per (class row, tap), zero when the tap falls outside h2; C rows are scattered
 //      to the class's positions of dh1                                             (dh1 = conv-transpose(dz2, W2))
-template <int BM, int BN, bool AROW, bool BROW, int EPI, int GATHER = 0>
+// SPLITK: the contraction is split over gridDim.y and partial tiles are summed with fp32 atomics.  Atomics only run at
+// full rate when one wave instruction covers whole 128-byte row segments (MI355X_MICROARCH.md, global float atomics:
+// 64 lanes in 64 different rows are ~17x slower), so this variant keeps the accumulators in the NATURAL MFMA
+// orientation (lane = output column) instead of the transposed one used for 16-byte stores.
+template <int BM, int BN, bool AROW, bool BROW, int EPI, int GATHER = 0, bool SPLITK = false>
 __global__ __launch_bounds__(256, (BM == 128 && BN == 128) ? 3 : 4) void gemm_bwd_kernel(const BwdArgs g) {
     constexpr int TM = BM / 64, TN = BN / 64, BK = 16;
     constexpr int AF = OperandTile<BM, AROW>::FLOATS, BF = OperandTile<BN, BROW>::FLOATS;
@@ -190,7 +194,8 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 128) ? 3 : 4) void gemm_bw
     _Pragma("unroll") for (int e = 0; e < 4; ++e)                                                           \
     _Pragma("unroll") for (int mt = 0; mt < TM; ++mt)                                                       \
     _Pragma("unroll") for (int nt = 0; nt < TN; ++nt)                                                       \
-        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(FB[nt][e], FA[mt][e], acc[mt][nt], 0, 0, 0)
+        acc[mt][nt] = SPLITK ? __builtin_amdgcn_mfma_f32_32x32x2f32(FA[mt][e], FB[nt][e], acc[mt][nt], 0, 0, 0)    \
+                             : __builtin_amdgcn_mfma_f32_32x32x2f32(FB[nt][e], FA[mt][e], acc[mt][nt], 0, 0, 0)
 
     const int nkt = (int)((kend - kbeg + BK - 1) / BK);
     load_tile(ra0, rb0, 0);
@@ -224,8 +229,25 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 128) ? 3 : 4) void gemm_bw
     if (kt < nkt) k_step(kt, ra1, rb1);
 #undef BWD_MFMA_SLICE
 
+    if (SPLITK) {
+        // natural orientation: lane li = column, register r = row (r&3) + 8*(r>>2) + 4*hf: one atomic instruction adds two
+        // contiguous 128-byte row segments
+#pragma unroll
+        for (int mt = 0; mt < TM; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < TN; ++nt) {
+                const int col = j0 + wc * (BN / 2) + nt * 32 + li;
+                if (col >= g.J) continue;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = i0 + wr * (BM / 2) + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hf;
+                    if (row < g.I) atomicAdd(Cb + (int64_t)row * g.ldc + col, g.alpha * acc[mt][nt][r]);
+                }
+            }
+        return;
+    }
     // ---- epilogue: lane (li, hf) holds row i = tile_row + li and columns j = tile_col + 8q + 4hf + {0..3} in regs 4q..4q+3
-    const bool atomic = g.splits > 1;
+    const bool atomic = false;
 #pragma unroll
     for (int mt = 0; mt < TM; ++mt) {
         const int row = i0 + wr * (BM / 2) + mt * 32 + li;
@@ -279,18 +301,26 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 128) ? 3 : 4) void gemm_bw
 
 template <int BM, int BN, bool AROW, bool BROW, int EPI, int GATHER = 0>
 int launch_one(BwdArgs g, hipStream_t s) {
+    constexpr bool kCanSplit = EPI == BEPI_SCALE && GATHER != 2;
     g.tiles_i = (unsigned)((g.I + BM - 1) / BM);
     g.tiles_j = (unsigned)((g.J + BN - 1) / BN);
     // split the contraction when the output alone cannot fill the chip (weight gradients)
     const unsigned tiles = g.tiles_i * g.tiles_j;
     int splits = 1;
-    if (g.splits == 0) {                               // 0 = auto, 1 = forbid
+    if (g.splits == 0 && kCanSplit) {                  // 0 = auto, 1 = forbid
         while ((int64_t)tiles * g.nbatch * splits < 768 && g.Kc / (splits * 2) >= 512 && splits < 32) splits *= 2;
     }
     g.splits = splits;
     const int64_t per = (g.Kc + splits - 1) / splits;
     g.k_per_split = (per + 15) / 16 * 16;
-    hipLaunchKernelGGL((gemm_bwd_kernel<BM, BN, AROW, BROW, EPI, GATHER>), dim3(tiles, (unsigned)splits, (unsigned)g.nbatch), dim3(256), 0, s, g);
+    const dim3 grid(tiles, (unsigned)splits, (unsigned)g.nbatch);
+    if constexpr (kCanSplit) {
+        if (splits > 1) {
+            hipLaunchKernelGGL((gemm_bwd_kernel<BM, BN, AROW, BROW, EPI, GATHER, true>), grid, dim3(256), 0, s, g);
+            return cfm_launch_status();
+        }
+    }
+    hipLaunchKernelGGL((gemm_bwd_kernel<BM, BN, AROW, BROW, EPI, GATHER, false>), grid, dim3(256), 0, s, g);
     return cfm_launch_status();
 }
 
