@@ -389,7 +389,7 @@ extern "C" int cfm_subsample_conv2_bwd_weight_f32(const float* dz2, const float*
     g.cT1 = T1; g.cF1 = F1; g.cT2 = (T1 - 1) / 2; g.cF2 = (F1 - 1) / 2; g.cC = C;
     g.A = dz2; g.B = h1; g.C = dw2p; g.I = C; g.J = 9 * C; g.Kc = (int64_t)B * g.cT2 * g.cF2;
     g.lda = C; g.ldb = 0; g.ldc = 9 * C; g.alpha = 1.f; g.splits = 0; g.nbatch = 1; g.nb1 = 1;
-    return launch_one<64, 64, false, false, BEPI_SCALE, 1>(g, static_cast<hipStream_t>(stream));
+    return launch_one<128, 128, false, false, BEPI_SCALE, 1>(g, static_cast<hipStream_t>(stream));
 }
 
 // dh1 (B,T1,F1,C) = conv-transpose(dz2 (B,T2,F2,C), w2): four parity classes of (t1,f1), each a regular implicit GEMM
