@@ -7,12 +7,12 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p
+from ctypes import c_char_p, c_float, c_int, c_int64, c_uint64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libconformer_hip.so")
 
-_P, _I, _L, _F = c_void_p, c_int, c_int64, c_float
+_P, _I, _L, _F, _U = c_void_p, c_int, c_int64, c_float, c_uint64
 
 # name -> (restype, argtypes).  Mirrors include/conformer_hip.h one to one (checked by tests/test_abi.py).
 SIGNATURES = {
@@ -32,7 +32,10 @@ SIGNATURES = {
     "cfm_gemm_bias_swish_save_f32": (c_int, [_P, _P, _P, _P, _P, _L, _I, _I, _L, _L, _P]),
     "cfm_gemm_bwd_f32": (c_int, [_P, _I, _L, _P, _I, _L, _P, _L, _F, _P, _L, _I, _I, _L, _I, _P]),
     "cfm_gemm_bwd_batched_f32": (c_int, [_P, _I, _L, _P, _I, _L, _P, _L, _F, _P, _L, _I, _I, _L, _I, _I, _I, _I,
-                                         _L, _L, _L, _L, _L, _L, _P]),
+                                         _L, _L, _L, _L, _L, _L, _F, _U, _P]),
+    "cfm_gemm_train_f32": (c_int, [_I, _P, _P, _P, _P, _F, _P, _P, _L, _I, _I, _L, _L, _L, _F, _U, _P]),
+    "cfm_relpos_attention_train_f32": (c_int, [_P, _P, _P, _L, _P, _L, _P, _P, _P, _P, _L, _P, _I, _I, _I, _I, _F, _U, _P]),
+    "cfm_dropout_f32": (c_int, [_P, _P, _L, _F, _U, _P]),
     "cfm_layernorm_bwd_dx_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, _L, _I, _P]),
     "cfm_layernorm_bwd_params_f32": (c_int, [_P, _P, _P, _P, _P, _P, _L, _I, _P]),
     "cfm_colsum_f32": (c_int, [_P, _L, _L, _I, _F, _P, _P]),
@@ -43,7 +46,7 @@ SIGNATURES = {
     "cfm_dwconv_bn_stats_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _P]),
     "cfm_attn_qbias_f32": (c_int, [_P, _L, _P, _P, _P, _P, _L, _I, _P]),
     "cfm_attn_rowdot_f32": (c_int, [_P, _P, _P, _I, _I, _I, _I, _P]),
-    "cfm_attn_softmax_bwd_f32": (c_int, [_P, _P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _I, _P]),
+    "cfm_attn_softmax_bwd_f32": (c_int, [_P, _P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _I, _F, _U, _P]),
     "cfm_add_strided_f32": (c_int, [_P, _L, _P, _L, _L, _I, _P]),
     "cfm_relu_bwd_f32": (c_int, [_P, _P, _P, _L, _P]),
     "cfm_subsample_conv2_bwd_weight_f32": (c_int, [_P, _P, _P, _I, _I, _I, _I, _P]),

@@ -41,15 +41,22 @@ class LinearFn(Function):
     dx is produced only when x requires grad."""
 
     @staticmethod
-    def forward(ctx, x, w, b):
+    def forward(ctx, x, w, b, drop_p=0.0):
         ctx.save_for_backward(x, w)
+        ctx.drop_p = float(drop_p)
+        if ctx.drop_p > 0.0:
+            ctx.seed, = ops.new_seeds(1)
+            return ops.linear_train("bias", x, w, b, drop_p=ctx.drop_p, seed=ctx.seed)
         return ops.linear(x, w, b)
 
     @staticmethod
     def backward(ctx, dy):
         x, w = ctx.saved_tensors
-        dx, dw, db = ops.linear_bwd(_flat(x), w, _flat(dy.contiguous()), need_dx=ctx.needs_input_grad[0])
-        return (dx.view_as(x) if dx is not None else None), dw, db
+        dy = dy.contiguous()
+        if ctx.drop_p > 0.0:
+            dy = ops.dropout_apply(dy, ctx.drop_p, ctx.seed)
+        dx, dw, db = ops.linear_bwd(_flat(x), w, _flat(dy), need_dx=ctx.needs_input_grad[0])
+        return (dx.view_as(x) if dx is not None else None), dw, db, None
 
 
 class SubsampleStemFn(Function):
@@ -74,10 +81,13 @@ class FeedForwardFn(Function):
     """out = alpha * (W2 . swish(W1 . LN(x) + b1) + b2) + x        (ffn.py:15-23 + block.py:19,25)"""
 
     @staticmethod
-    def forward(ctx, x, ln_w, ln_b, w1, b1, w2, b2, alpha, eps):
+    def forward(ctx, x, ln_w, ln_b, w1, b1, w2, b2, alpha, eps, drop_p=0.0):
         h0, mean, rstd = ops.layernorm_train(x, ln_w, ln_b, eps)
-        h, z = ops.linear_swish_save(h0, w1, b1)
-        out = ops.linear_residual(h, w2, b2, x, alpha)
+        ctx.drop_p = float(drop_p)
+        ctx.seeds = ops.new_seeds(2) if ctx.drop_p > 0.0 else (0, 0)
+        # h = drop1(swish(z)); out = alpha * drop2(h.W2^T + b2) + x     (ffn.py:17-21)
+        h, z = ops.linear_train("swish", h0, w1, b1, drop_p=ctx.drop_p, seed=ctx.seeds[0], save_z=True)
+        out = ops.linear_train("residual", h, w2, b2, residual=x, alpha=alpha, drop_p=ctx.drop_p, seed=ctx.seeds[1])
         ctx.save_for_backward(x, ln_w, mean, rstd, h0, z, h, w1, w2)
         ctx.alpha = alpha
         return out
@@ -86,12 +96,13 @@ class FeedForwardFn(Function):
     def backward(ctx, dout):
         x, ln_w, mean, rstd, h0, z, h, w1, w2 = ctx.saved_tensors
         dout = dout.contiguous()
-        d2 = _flat(dout)
-        # out-projection: d(pre-activation) = alpha * (dout . W2) * swish'(z); dW2 = alpha * dout^T . h
-        dz, dw2, db2 = ops.linear_bwd(_flat(h), w2, d2, alpha=ctx.alpha, Z=_flat(z))
+        d2 = ops.dropout_apply(dout, ctx.drop_p, ctx.seeds[1])       # gradient w.r.t. the out-projection result
+        # d(pre-activation) = alpha * (d2 . W2) * mask1 * swish'(z); dW2 = alpha * d2^T . h (h already carries mask1)
+        dz, dw2, db2 = ops.linear_bwd(_flat(h), w2, _flat(d2), alpha=ctx.alpha, Z=_flat(z), drop_p=ctx.drop_p,
+                                      drop_seed=ctx.seeds[0])
         dh0, dw1, db1 = ops.linear_bwd(_flat(h0), w1, dz)
         dx, dlw, dlb = ops.layernorm_bwd(x, ln_w, dh0.view_as(x), mean, rstd, dres=dout)
-        return dx, dlw, dlb, dw1, db1, dw2, db2, None, None
+        return dx, dlw, dlb, dw1, db1, dw2, db2, None, None, None
 
 
 class SelfAttentionFn(Function):
@@ -99,13 +110,15 @@ class SelfAttentionFn(Function):
     `pos` is this layer's (2T-1, d) slice of the projected position table (it has its own graph through LinearFn)."""
 
     @staticmethod
-    def forward(ctx, x, ln_w, ln_b, wq, bq, wk, bk, wv, bv, pos, u, vb, wo, bo, lengths, n_heads, eps):
+    def forward(ctx, x, ln_w, ln_b, wq, bq, wk, bk, wv, bv, pos, u, vb, wo, bo, lengths, n_heads, eps, drop_p=0.0):
         h0, mean, rstd = ops.layernorm_train(x, ln_w, ln_b, eps)
         wqkv = torch.cat([wq, wk, wv], dim=0)
         bqkv = torch.cat([bq, bk, bv], dim=0)
         qkv = ops.linear(h0, wqkv, bqkv)
-        att, lse = ops.relpos_attention_train(qkv, pos, u, vb, lengths, n_heads)
-        out = ops.linear_residual(att, wo, bo, x, 1.0)
+        ctx.drop_p = float(drop_p)
+        ctx.seeds = ops.new_seeds(2) if ctx.drop_p > 0.0 else (0, 0)
+        att, lse = ops.relpos_attention_train(qkv, pos, u, vb, lengths, n_heads, ctx.drop_p, ctx.seeds[0])   # attention.py:67
+        out = ops.linear_train("residual", att, wo, bo, residual=x, alpha=1.0, drop_p=ctx.drop_p, seed=ctx.seeds[1])
         ctx.save_for_backward(x, ln_w, mean, rstd, h0, wqkv, qkv, pos, u, vb, att, lse, wo,
                               lengths if lengths is not None else torch.empty(0))
         ctx.has_len = lengths is not None
@@ -118,14 +131,15 @@ class SelfAttentionFn(Function):
         lengths = lengths if ctx.has_len else None
         dout = dout.contiguous()
         d = x.shape[-1]
-        datt, dwo, dbo = ops.linear_bwd(_flat(att), wo, _flat(dout))
+        d2 = ops.dropout_apply(dout, ctx.drop_p, ctx.seeds[1])
+        datt, dwo, dbo = ops.linear_bwd(_flat(att), wo, _flat(d2))
         dqkv, dpos, du, dvb = ops.relpos_attention_bwd(qkv, pos, u, vb, lengths, ctx.n_heads, att,
-                                                       lse, datt.view_as(att))
+                                                       lse, datt.view_as(att), ctx.drop_p, ctx.seeds[0])
         dh0, dwqkv, dbqkv = ops.linear_bwd(_flat(h0), wqkv, _flat(dqkv))
         dx, dlw, dlb = ops.layernorm_bwd(x, ln_w, dh0.view_as(x), mean, rstd, dres=dout)
         dwq, dwk, dwv = dwqkv[:d], dwqkv[d:2 * d], dwqkv[2 * d:]
         dbq, dbk, dbv = dbqkv[:d], dbqkv[d:2 * d], dbqkv[2 * d:]
-        return dx, dlw, dlb, dwq, dbq, dwk, dbk, dwv, dbv, dpos, du, dvb, dwo, dbo, None, None, None
+        return dx, dlw, dlb, dwq, dbq, dwk, dbk, dwv, dbv, dpos, du, dvb, dwo, dbo, None, None, None, None
 
 
 class ConvModuleFn(Function):
@@ -136,14 +150,16 @@ class ConvModuleFn(Function):
 
     @staticmethod
     def forward(ctx, x, ln_w, ln_b, w1, b1, wd, bd, bn_w, bn_b, bn_mean, bn_var, w2, b2, eps_ln, eps_bn, train_bn,
-                momentum):
+                momentum, drop_p=0.0):
         h0, mean, rstd = ops.layernorm_train(x, ln_w, ln_b, eps_ln)
         z = ops.linear(h0, w1, b1)                                  # (B,T,2C) pre-activation kept for GLU'
         g = ops.glu_fwd(z)
         if train_bn:
             bn_mean, bn_var = ops.dwconv_bn_batch_stats(g, wd, bd, bn_mean, bn_var, momentum)
         s = ops.dwconv_bn_swish(g, wd, bd, bn_w, bn_b, bn_mean, bn_var, eps_bn)
-        out = ops.linear_residual(s, w2, b2, x, 1.0)
+        ctx.drop_p = float(drop_p)
+        ctx.seed = ops.new_seeds(1)[0] if ctx.drop_p > 0.0 else 0
+        out = ops.linear_train("residual", s, w2, b2, residual=x, alpha=1.0, drop_p=ctx.drop_p, seed=ctx.seed)
         ctx.save_for_backward(x, ln_w, mean, rstd, h0, z, g, s, w1, wd, bd, bn_w, bn_b, bn_mean, bn_var, w2)
         ctx.eps_bn = eps_bn
         ctx.train_bn = bool(train_bn)
@@ -153,13 +169,14 @@ class ConvModuleFn(Function):
     def backward(ctx, dout):
         x, ln_w, mean, rstd, h0, z, g, s, w1, wd, bd, bn_w, bn_b, bn_mean, bn_var, w2 = ctx.saved_tensors
         dout = dout.contiguous()
-        ds, dw2, db2 = ops.linear_bwd(_flat(s), w2, _flat(dout))
+        d2 = ops.dropout_apply(dout, ctx.drop_p, ctx.seed)
+        ds, dw2, db2 = ops.linear_bwd(_flat(s), w2, _flat(d2))
         dg, dwd, dbd, dbnw, dbnb = ops.dwconv_bn_swish_bwd(g, ds.view_as(g), wd, bd, bn_w, bn_b, bn_mean, bn_var,
                                                            ctx.eps_bn, ctx.train_bn)
         dz = ops.glu_bwd(z, dg)
         dh0, dw1, db1 = ops.linear_bwd(_flat(h0), w1, _flat(dz))
         dx, dlw, dlb = ops.layernorm_bwd(x, ln_w, dh0.view_as(x), mean, rstd, dres=dout)
-        return dx, dlw, dlb, dw1, db1, dwd, dbd, dbnw, dbnb, None, None, dw2, db2, None, None, None, None
+        return dx, dlw, dlb, dw1, db1, dwd, dbd, dbnw, dbnb, None, None, dw2, db2, None, None, None, None, None
 
 
 def needs_grad(module: torch.nn.Module, *tensors: Optional[torch.Tensor]) -> bool:

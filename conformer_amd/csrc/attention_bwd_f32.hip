@@ -49,7 +49,8 @@ __global__ __launch_bounds__(256) void attn_softmax_bwd_kernel(float* __restrict
                                                                float* __restrict__ dP,        // (B,H,T,T4) -> dS
                                                                const float* __restrict__ lse, const float* __restrict__ D,
                                                                const int64_t* __restrict__ lengths, float scale, int B,
-                                                               int T, int H, int T4, int P4) {
+                                                               int T, int H, int T4, int P4, float drop_p,
+                                                               unsigned long long drop_seed) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);     // (b*H + h)*T + i
     if (row >= (int64_t)B * H * T) return;
@@ -71,13 +72,29 @@ __global__ __launch_bounds__(256) void attn_softmax_bwd_kernel(float* __restrict
             if (k < klen) {
                 const float s = (crow[k] + prow[k + jlo]) * scale;
                 p = exp_fast(s - l);
-                ds = p * (drow[k] - Di) * scale;
+                // forward dropped the weights: ctx = sum_k a*m*v, m in {0, 1/(1-p)}: d(a) = dP*m and the P that feeds dV is a*m
+                const float m = drop_p > 0.f ? dropout_keep(drop_seed, (unsigned long long)row * (unsigned long long)T + (unsigned)k,
+                                                           drop_p, 1.0f / (1.0f - drop_p)) : 1.0f;
+                ds = p * (drow[k] * m - Di) * scale;
+                p *= m;
             }
             prow[k + jlo] = ds;
         }
         crow[k] = p;
         drow[k] = ds;
     }
+}
+
+// y = x * keep(seed, flat index): the stand-alone form of the epilogue dropout (backward: mask the incoming gradient)
+__global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n4,
+                                                      float p, unsigned long long seed) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    const float inv_keep = 1.0f / (1.0f - p);
+    f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] *= dropout_keep(seed, (unsigned long long)(4 * i + e), p, inv_keep);
+    reinterpret_cast<f32x4*>(y)[i] = v;
 }
 
 __global__ __launch_bounds__(256) void add_strided_kernel(float* __restrict__ dst, int64_t ldd,
@@ -116,13 +133,23 @@ extern "C" int cfm_attn_rowdot_f32(const float* dO, const float* O, float* D, in
 
 extern "C" int cfm_attn_softmax_bwd_f32(float* content_to_p, float* posfull_to_dposfull, float* dp_to_ds,
                                         const float* lse, const float* D, const int64_t* lengths_or_null, float scale,
-                                        int B, int T, int H, int T4, int P4, cfm_stream_t stream) {
+                                        int B, int T, int H, int T4, int P4, float drop_p, uint64_t drop_seed,
+                                        cfm_stream_t stream) {
     CFM_REQUIRE(content_to_p && posfull_to_dposfull && dp_to_ds && lse && D, CFM_ERR_NULL);
     CFM_REQUIRE(B > 0 && T > 0 && H > 0 && T4 >= T && P4 >= 2 * T - 1, CFM_ERR_BAD_SHAPE);
     const int64_t rows = (int64_t)B * H * T;
     hipLaunchKernelGGL(attn_softmax_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0,
                        static_cast<hipStream_t>(stream), content_to_p, posfull_to_dposfull, dp_to_ds, lse, D,
-                       lengths_or_null, scale, B, T, H, T4, P4);
+                       lengths_or_null, scale, B, T, H, T4, P4, drop_p, drop_seed);
+    return cfm_launch_status();
+}
+
+extern "C" int cfm_dropout_f32(const float* x, float* y, int64_t n, float p, uint64_t seed, cfm_stream_t stream) {
+    CFM_REQUIRE(x && y, CFM_ERR_NULL);
+    CFM_REQUIRE(n > 0 && (n & 3) == 0 && p >= 0.f && p < 1.f, CFM_ERR_BAD_SHAPE);
+    CFM_REQUIRE(CFM_ALIGNED16(x) && CFM_ALIGNED16(y), CFM_ERR_ALIGN);
+    hipLaunchKernelGGL(dropout_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       x, y, n / 4, p, seed);
     return cfm_launch_status();
 }
 

@@ -32,6 +32,7 @@ struct AttnArgs {
     const float* pos; int64_t ldp; const float* u; const float* vb;
     const int64_t* lengths; float* ctx; int64_t ldo; float* lse;
     int B, T, H, dh; float inv_sqrt_dh;
+    float drop_p; unsigned long long drop_seed;     // training: dropout on the softmax weights (attention.py:67)
 };
 
 template <int NC, int ND>
@@ -203,6 +204,13 @@ __global__ __launch_bounds__(256, 2) void relpos_attn_fwd_kernel(const AttnArgs 
             psum += __shfl_xor(psum, 32, 64);
             lrow = lrow * alpha + psum;
             mrow = mnew;
+            if (a.drop_p > 0.f) {                                     // weights are dropped AFTER normalisation: l stays unmasked
+                const float inv_keep = 1.0f / (1.0f - a.drop_p);
+                const unsigned long long rowbase = ((unsigned long long)bh * T + (unsigned)(i0 + li)) * (unsigned long long)T;
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    p[r] *= dropout_keep(a.drop_seed, rowbase + (unsigned)(k0 + (r & 3) + 8 * (r >> 2) + 4 * hf), a.drop_p, inv_keep);
+            }
 #pragma unroll
             for (int n = 0; n < ND; ++n)
 #pragma unroll
@@ -245,10 +253,34 @@ __global__ __launch_bounds__(256, 2) void relpos_attn_fwd_kernel(const AttnArgs 
 
 }  // namespace
 
+static int attention_launch(const float* q, const float* k, const float* v, int64_t ld, const float* pos, int64_t ldp,
+                            const float* u, const float* vbias, const int64_t* lengths_or_null, float* ctx, int64_t ldo,
+                            float* lse_or_null, int B, int T, int H, int dh, float drop_p, uint64_t drop_seed,
+                            cfm_stream_t stream);
+
 extern "C" int cfm_relpos_attention_fwd_f32(const float* q, const float* k, const float* v, int64_t ld,
                                             const float* pos, int64_t ldp, const float* u, const float* vbias,
                                             const int64_t* lengths_or_null, float* ctx, int64_t ldo,
                                             float* lse_or_null, int B, int T, int H, int dh, cfm_stream_t stream) {
+    return attention_launch(q, k, v, ld, pos, ldp, u, vbias, lengths_or_null, ctx, ldo, lse_or_null, B, T, H, dh, 0.f, 0,
+                            stream);
+}
+
+// training variant: dropout with probability drop_p on the softmax weights (mask index ((b*H+h)*T + i)*T + k)
+extern "C" int cfm_relpos_attention_train_f32(const float* q, const float* k, const float* v, int64_t ld,
+                                              const float* pos, int64_t ldp, const float* u, const float* vbias,
+                                              const int64_t* lengths_or_null, float* ctx, int64_t ldo, float* lse,
+                                              int B, int T, int H, int dh, float drop_p, uint64_t drop_seed,
+                                              cfm_stream_t stream) {
+    CFM_REQUIRE(drop_p >= 0.f && drop_p < 1.f, CFM_ERR_BAD_SHAPE);
+    return attention_launch(q, k, v, ld, pos, ldp, u, vbias, lengths_or_null, ctx, ldo, lse, B, T, H, dh, drop_p, drop_seed,
+                            stream);
+}
+
+static int attention_launch(const float* q, const float* k, const float* v, int64_t ld, const float* pos, int64_t ldp,
+                            const float* u, const float* vbias, const int64_t* lengths_or_null, float* ctx, int64_t ldo,
+                            float* lse_or_null, int B, int T, int H, int dh, float drop_p, uint64_t drop_seed,
+                            cfm_stream_t stream) {
     CFM_REQUIRE(q && k && v && pos && u && vbias && ctx, CFM_ERR_NULL);
     CFM_REQUIRE(B > 0 && T > 0 && H > 0 && dh > 0 && (dh & 3) == 0, CFM_ERR_BAD_SHAPE);
     CFM_REQUIRE((ld & 3) == 0 && (ldp & 3) == 0 && (ldo & 3) == 0, CFM_ERR_BAD_SHAPE);
@@ -256,7 +288,8 @@ extern "C" int cfm_relpos_attention_fwd_f32(const float* q, const float* k, cons
     CFM_REQUIRE(CFM_ALIGNED16(q) && CFM_ALIGNED16(k) && CFM_ALIGNED16(v) && CFM_ALIGNED16(pos) && CFM_ALIGNED16(u) &&
                 CFM_ALIGNED16(vbias) && CFM_ALIGNED16(ctx), CFM_ERR_ALIGN);
     CFM_REQUIRE((int64_t)B * H <= 65535 && T < (1 << 28), CFM_ERR_UNSUPPORTED);
-    AttnArgs a{q, k, v, ld, pos, ldp, u, vbias, lengths_or_null, ctx, ldo, lse_or_null, B, T, H, dh, 1.0f / sqrtf((float)dh)};
+    AttnArgs a{q, k, v, ld, pos, ldp, u, vbias, lengths_or_null, ctx, ldo, lse_or_null, B, T, H, dh, 1.0f / sqrtf((float)dh),
+               drop_p, drop_seed};
     const dim3 grid((unsigned)((T + 127) / 128), (unsigned)(B * H)), block(256);
     hipStream_t s = static_cast<hipStream_t>(stream);
 #define ATT_LAUNCH(NC, ND) hipLaunchKernelGGL((relpos_attn_fwd_kernel<NC, ND>), grid, block, 0, s, a)

@@ -38,6 +38,19 @@ __device__ __forceinline__ float rcp_fast(float x) { return __builtin_amdgcn_rcp
 __device__ __forceinline__ float sigmoidf_acc(float x) { return rcp_fast(1.0f + exp_fast(-x)); }
 __device__ __forceinline__ float swishf_acc(float x) { return x * sigmoidf_acc(x); }
 
+// Dropout keep-factor for element `idx` of a tensor under (seed): a counter-based generator (splitmix64 finaliser of
+// seed + idx*golden), so the backward regenerates exactly the forward's mask from (seed, idx) with no stored mask.
+// Returns 0 (dropped, probability p) or 1/(1-p).  The stream differs from torch's Philox -- parity runs use p = 0,
+// as SURVEY.md Appendix B prescribes.
+__device__ __forceinline__ float dropout_keep(unsigned long long seed, unsigned long long idx, float p, float inv_keep) {
+    unsigned long long z = seed + idx * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    const float u = (float)(unsigned)(z >> 40) * (1.0f / 16777216.0f);      // 24 random bits -> [0,1)
+    return u < p ? 0.f : inv_keep;
+}
+
 // Bijective XCD-aware remap of a 1-D block id: blocks that share an XCD (id % 8 under the observed
 // round-robin placement) get a contiguous chunk of the logical grid so neighbouring tiles reuse that
 // XCD's L2.  Speed only -- never correctness.

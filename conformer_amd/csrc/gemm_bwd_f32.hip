@@ -22,6 +22,7 @@ struct BwdArgs {
     const float* A; const float* B; const float* Z; float* C;
     int I, J; int64_t Kc; int64_t lda, ldb, ldz, ldc; float alpha;
     unsigned tiles_i, tiles_j; int splits; int64_t k_per_split;
+    float drop_p; unsigned long long drop_seed;   // DSWISH: the forward dropped swish(Z): re-apply its mask to the incoming gradient
     int accumulate;                      // C += ... (non-atomic read-modify-write; not combined with splits)
     int nbatch, nb1;                     // batched: blockIdx.z = b0*nb1 + b1; operand offset = b0*s?0 + b1*s?1
     int64_t sa0, sa1, sb0, sb1, sc0, sc1;
@@ -270,6 +271,9 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 128) ? 3 : 4) void gemm_bw
                         const float z = zp[e];
                         const float sg = sigmoidf_acc(z);
                         v[e] *= sg * (1.0f + z * (1.0f - sg));
+                        if (g.drop_p > 0.f)
+                            v[e] *= dropout_keep(g.drop_seed, (unsigned long long)row * (unsigned long long)g.J + (unsigned)(col + e),
+                                                 g.drop_p, 1.0f / (1.0f - g.drop_p));
                     }
                 }
                 int64_t crow = row;
@@ -348,11 +352,12 @@ int launch_layout(const BwdArgs& g, hipStream_t s) {
 // split with fp32 atomics: C MUST then be zero-filled by the caller and the summation order is not deterministic.
 // `accumulate` != 0: C += (plain read-modify-write; splitting is disabled).  Batched form: nbatch = nb0*nb1 problems,
 // problem (b0,b1) uses A + b0*sa0 + b1*sa1 etc. (pass nbatch = nb1 = 1 and zero strides for a single GEMM).
+// drop_p/drop_seed (with Z): the forward applied dropout to swish(Z) -- the same mask is applied to the result.
 extern "C" int cfm_gemm_bwd_batched_f32(const float* A, int a_col, int64_t lda, const float* B, int b_col, int64_t ldb,
                                         const float* Z_or_null, int64_t ldz, float alpha, float* C, int64_t ldc,
                                         int I, int J, int64_t Kc, int allow_split, int accumulate, int nbatch, int nb1,
                                         int64_t sa0, int64_t sa1, int64_t sb0, int64_t sb1, int64_t sc0, int64_t sc1,
-                                        cfm_stream_t stream) {
+                                        float drop_p, uint64_t drop_seed, cfm_stream_t stream) {
     CFM_REQUIRE(A && B && C, CFM_ERR_NULL);
     CFM_REQUIRE(I > 0 && J > 0 && Kc > 0 && nbatch > 0 && nb1 > 0 && nbatch % nb1 == 0 && nbatch <= 65535, CFM_ERR_BAD_SHAPE);
     CFM_REQUIRE((ldc & 3) == 0 && (lda & 3) == 0 && (ldb & 3) == 0, CFM_ERR_BAD_SHAPE);
@@ -364,7 +369,7 @@ extern "C" int cfm_gemm_bwd_batched_f32(const float* A, int a_col, int64_t lda, 
     g.A = A; g.B = B; g.Z = Z_or_null; g.C = C; g.I = I; g.J = J; g.Kc = Kc;
     g.lda = lda; g.ldb = ldb; g.ldz = ldz; g.ldc = ldc; g.alpha = alpha;
     g.splits = (allow_split && !accumulate) ? 0 : 1;
-    g.accumulate = accumulate; g.nbatch = nbatch; g.nb1 = nb1;
+    g.accumulate = accumulate; g.nbatch = nbatch; g.nb1 = nb1; g.drop_p = drop_p; g.drop_seed = drop_seed;
     g.sa0 = sa0; g.sa1 = sa1; g.sb0 = sb0; g.sb1 = sb1; g.sc0 = sc0; g.sc1 = sc1;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (Z_or_null) {
@@ -429,5 +434,5 @@ extern "C" int cfm_gemm_bwd_f32(const float* A, int a_col, int64_t lda, const fl
                                 const float* Z_or_null, int64_t ldz, float alpha, float* C, int64_t ldc,
                                 int I, int J, int64_t Kc, int allow_split, cfm_stream_t stream) {
     return cfm_gemm_bwd_batched_f32(A, a_col, lda, B, b_col, ldb, Z_or_null, ldz, alpha, C, ldc, I, J, Kc, allow_split,
-                                    0, 1, 1, 0, 0, 0, 0, 0, 0, stream);
+                                    0, 1, 1, 0, 0, 0, 0, 0, 0, 0.f, 0, stream);
 }

@@ -22,6 +22,7 @@ enum Epi { EPI_BIAS = 0, EPI_SWISH = 1, EPI_RELU = 2, EPI_GLU = 3, EPI_RESID = 4
 struct GemmArgs {
     const float* A; const float* W; const float* bias; const float* R; float* C;
     float* Zsave;                   // swish epilogue, training: also store the pre-activation (same ldc), or NULL
+    float drop_p; unsigned long long drop_seed;   // training: dropout on the GEMM result (after Swish; before alpha*y+R)
     int64_t M; int N; int K; int64_t lda, ldr, ldc; float alpha;
     int n_out;                      // GLU: output columns (N = 2*n_out)
     int cT2, cF2, cT1, cF1, cC;     // conv mode geometry
@@ -97,6 +98,13 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const f32x16 (&
                     const f32x4 bb = *reinterpret_cast<const f32x4*>(g.bias + col);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = acc[mt][nt][4 * q + e] + bb[e];
+                    const bool drop = g.drop_p > 0.f && EPI != EPI_GLU && EPI != EPI_RELU;
+                    const float inv_keep = drop ? 1.0f / (1.0f - g.drop_p) : 1.0f;
+                    const unsigned long long e0 = (unsigned long long)row * (unsigned long long)g.N + (unsigned)col;
+                    if (drop && EPI != EPI_SWISH) {                        // dropout(y) then alpha*y + R  (or plain y)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] *= dropout_keep(g.drop_seed, e0 + e, g.drop_p, inv_keep);
+                    }
                     if (EPI == EPI_GLU) {
                         const f32x4 bg = *reinterpret_cast<const f32x4*>(g.bias + g.n_out + col);
 #pragma unroll
@@ -111,7 +119,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const f32x16 (&
                         *reinterpret_cast<f32x4*>(g.Zsave + row * g.ldc + col) = f32x4{v[0], v[1], v[2], v[3]};
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        if (EPI == EPI_SWISH) v[e] = swishf_acc(v[e]);
+                        if (EPI == EPI_SWISH) {
+                            v[e] = swishf_acc(v[e]);
+                            if (drop) v[e] *= dropout_keep(g.drop_seed, e0 + e, g.drop_p, inv_keep);
+                        }
                         if (EPI == EPI_RELU) v[e] = fmaxf(v[e], 0.f);
                     }
                     *reinterpret_cast<f32x4*>(g.C + row * g.ldc + col) = f32x4{v[0], v[1], v[2], v[3]};
@@ -120,10 +131,14 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const f32x16 (&
                     for (int e = 0; e < 4; ++e) {
                         if (col + e >= ncols) continue;
                         float x = acc[mt][nt][4 * q + e] + g.bias[col + e];
+                        const bool drop = g.drop_p > 0.f && EPI != EPI_GLU && EPI != EPI_RELU;
+                        const float keep = drop ? dropout_keep(g.drop_seed, (unsigned long long)row * (unsigned long long)g.N +
+                                                               (unsigned)(col + e), g.drop_p, 1.0f / (1.0f - g.drop_p)) : 1.0f;
+                        if (EPI != EPI_SWISH) x *= keep;
                         if (EPI == EPI_GLU) x *= sigmoidf_acc(acc[mt][TN - 1][4 * q + e] + g.bias[g.n_out + col + e]);
                         if (EPI == EPI_RESID) x = g.alpha * x + g.R[row * g.ldr + col + e];
                         if (EPI == EPI_SWISH && g.Zsave) g.Zsave[row * g.ldc + col + e] = x;
-                        if (EPI == EPI_SWISH) x = swishf_acc(x);
+                        if (EPI == EPI_SWISH) x = swishf_acc(x) * keep;
                         if (EPI == EPI_RELU) x = fmaxf(x, 0.f);
                         g.C[row * g.ldc + col + e] = x;
                     }
@@ -340,6 +355,28 @@ extern "C" int cfm_gemm_bias_swish_save_f32(const float* A, const float* W, cons
     CFM_REQUIRE(Z != nullptr, CFM_ERR_NULL);
     CFM_REQUIRE(ldc >= N, CFM_ERR_BAD_SHAPE);
     return launch<EPI_SWISH, false>(g, static_cast<hipStream_t>(stream));
+}
+
+// Training forward with dropout fused into the epilogue (element index = row*N + col, regenerated in the backward):
+//   epi 0: C = drop(A.W^T + b)                       (encoder.py:23-25)
+//   epi 1: C = drop(swish(Z)), Z = A.W^T + b saved   (ffn.py:17-19)
+//   epi 4: C = alpha * drop(A.W^T + b) + R           (ffn.py:20-21 / attention.py:17 / convolution.py:29-30 + block.py)
+extern "C" int cfm_gemm_train_f32(int epi, const float* A, const float* W, const float* bias, const float* R_or_null,
+                                  float alpha, float* C, float* Z_or_null, int64_t M, int N, int K, int64_t lda,
+                                  int64_t ldr, int64_t ldc, float drop_p, uint64_t drop_seed, cfm_stream_t stream) {
+    GEMM_ARGS_PLAIN(N);
+    g.R = R_or_null; g.ldr = ldr; g.alpha = alpha; g.Zsave = Z_or_null; g.drop_p = drop_p; g.drop_seed = drop_seed;
+    int st = check(g); if (st) return st;
+    CFM_REQUIRE(ldc >= N && drop_p >= 0.f && drop_p < 1.f, CFM_ERR_BAD_SHAPE);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (epi == EPI_BIAS) return launch<EPI_BIAS, false>(g, s);
+    if (epi == EPI_SWISH) return launch<EPI_SWISH, false>(g, s);
+    if (epi == EPI_RESID) {
+        CFM_REQUIRE(R_or_null != nullptr, CFM_ERR_NULL);
+        CFM_REQUIRE(ldr >= N, CFM_ERR_BAD_SHAPE);
+        return launch<EPI_RESID, false>(g, s);
+    }
+    return CFM_ERR_UNSUPPORTED;
 }
 
 extern "C" int cfm_gemm_bias_relu_f32(const float* A, const float* W, const float* bias, float* C, int64_t M,

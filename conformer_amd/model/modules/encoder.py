@@ -12,7 +12,7 @@ import torch.nn as nn
 
 from ... import autograd as ag
 from ... import ops
-from ..utils._guard import STRICT, PackCache, refuse_dropout
+from ..utils._guard import STRICT, PackCache, active_dropout, refuse_dropout
 from ..utils.block import ConformerBlock
 from ..utils.convolution import ConvolutionSubsampling
 from ..utils.position import RelativePositionalEncoding
@@ -40,7 +40,7 @@ class Encoder(nn.Module):
         if ag.needs_grad(self.linear):
             # differentiable re-layout of the weight (columns c*F'+f -> f*C+c) so .grad lands in the reference layout
             wlp = self.linear.weight.view(d, d, self.n_freq_out).transpose(1, 2).reshape(d, -1)
-            h = ag.LinearFn.apply(h, wlp, self.linear.bias)
+            h = ag.LinearFn.apply(h, wlp, self.linear.bias, active_dropout(self.dropout))     # encoder.py:23-25
         else:
             wlp = self._packs.get("wlp", (self.linear.weight,),
                                   lambda: ops.pack_linear_weight(self.linear.weight, d, self.n_freq_out))

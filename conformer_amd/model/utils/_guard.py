@@ -9,14 +9,19 @@ import torch
 STRICT = os.environ.get("CONFORMER_AMD_STRICT", "0") == "1"
 
 
+def active_dropout(drop: torch.nn.Dropout) -> float:
+    """The probability an nn.Dropout sub-module applies right now (0 in eval mode) -- nn.Dropout semantics."""
+    return float(drop.p) if drop.training else 0.0
+
+
 def refuse_dropout(module: torch.nn.Module, what: str) -> None:
-    """Dropout masks (Philox regeneration in the backward) are not built yet: refuse p > 0 in training mode
-    instead of silently skipping it."""
-    if module.training:
+    """Dropout is only wired through the autograd Functions (training with gradients).  `.train()` under no_grad with
+    p > 0 has no kernel path: refuse instead of silently skipping the masks."""
+    if module.training and not torch.is_grad_enabled():
         for m in module.modules():
             if isinstance(m, torch.nn.Dropout) and m.p > 0:
-                raise NotImplementedError(f"{what}: dropout p={m.p} in training mode is not built yet "
-                                          "(use dropout_rate=0.0 or .eval())")
+                raise NotImplementedError(f"{what}: dropout p={m.p} in training mode under no_grad is not built "
+                                          "(call .eval() for inference)")
 
 
 def refuse_grad(module: torch.nn.Module, what: str, *tensors: torch.Tensor) -> None:

@@ -16,7 +16,7 @@ import torch.nn as nn
 
 from ... import autograd as ag
 from ... import ops
-from ._guard import PackCache, refuse_dropout
+from ._guard import PackCache, active_dropout, refuse_dropout
 from .masking import lengths_from_key_padding_mask
 
 
@@ -103,7 +103,8 @@ class MultiHeadSelfAttentionModule(nn.Module):
             out = ag.SelfAttentionFn.apply(x, self.layer_norm.weight, self.layer_norm.bias, a.query_proj.weight,
                                            a.query_proj.bias, a.key_proj.weight, a.key_proj.bias, a.value_proj.weight,
                                            a.value_proj.bias, pos_projected, a.content_bias, a.position_bias,
-                                           a.out_proj.weight, a.out_proj.bias, lengths, a.n_heads, self.layer_norm.eps)
+                                           a.out_proj.weight, a.out_proj.bias, lengths, a.n_heads, self.layer_norm.eps,
+                                           active_dropout(self.dropout))
             return out if residual is not None else out - x
         xn = ops.layernorm(x, self.layer_norm.weight, self.layer_norm.bias, self.layer_norm.eps)
         return self.attention.fused(xn, pos_table, lengths, residual, pos_projected)

@@ -18,7 +18,7 @@ import torch.nn.functional as F
 
 from ... import autograd as ag
 from ... import ops
-from ._guard import PackCache, refuse_dropout
+from ._guard import PackCache, active_dropout, refuse_dropout
 from .activation import GLU, Swish
 
 
@@ -61,7 +61,8 @@ class ConvolutionModule(nn.Module):
                                         self.pointwise_conv_1.bias, self.deepwise_conv.weight, self.deepwise_conv.bias,
                                         bn.weight, bn.bias, bn.running_mean, bn.running_var,
                                         self.pointwise_conv_2.weight, self.pointwise_conv_2.bias,
-                                        self.layer_norm.eps, bn.eps, train_bn, bn.momentum if train_bn else 0.0)
+                                        self.layer_norm.eps, bn.eps, train_bn, bn.momentum if train_bn else 0.0,
+                                        active_dropout(self.dropout))
             if train_bn:
                 bn.num_batches_tracked += 1
             return out if residual is not None else out - x

@@ -11,7 +11,7 @@ import torch.nn as nn
 
 from ... import autograd as ag
 from ... import ops
-from ._guard import refuse_dropout
+from ._guard import active_dropout, refuse_dropout
 from .activation import Swish
 
 
@@ -33,7 +33,7 @@ class FeedForwardModule(nn.Module):
                                           "own input (block.py:19,25); pass residual=x")
             out = ag.FeedForwardFn.apply(x, self.layer_norm.weight, self.layer_norm.bias, self.hidden_linear.weight,
                                          self.hidden_linear.bias, self.out_linear.weight, self.out_linear.bias,
-                                         float(alpha), self.layer_norm.eps)
+                                         float(alpha), self.layer_norm.eps, active_dropout(self.dropout_1))
             # the Function always folds `+ x`; a stand-alone call (no residual) removes it again
             return out if residual is not None else out - x
         h = ops.layernorm(x, self.layer_norm.weight, self.layer_norm.bias, self.layer_norm.eps)

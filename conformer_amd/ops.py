@@ -226,6 +226,38 @@ def linear_swish_save(a, w, b):
     return c, z
 
 
+def new_seeds(n: int):
+    """n dropout seeds from torch's default CPU generator (so torch.manual_seed makes training runs reproducible)."""
+    return [int(v) for v in torch.randint(0, 2 ** 62, (n,), dtype=torch.int64)]
+
+
+def linear_train(epi: str, a, w, b, *, residual=None, alpha: float = 1.0, drop_p: float = 0.0, seed: int = 0,
+                 save_z: bool = False):
+    """Training forward GEMM with dropout fused in the epilogue.  epi: 'bias' | 'swish' | 'residual'.
+    Returns C (and Z, the pre-activation, when save_z)."""
+    a, w2, b, m, n, k = _gemm_common(a, w, b)
+    c = torch.empty(*a.shape[:-1], n, device=a.device, dtype=a.dtype)
+    z = torch.empty_like(c) if save_z else None
+    code = {"bias": 0, "swish": 1, "residual": 4}[epi]
+    if residual is not None:
+        residual = _req(residual, "residual")
+    st = _lib.load().cfm_gemm_train_f32(code, a.data_ptr(), w2.data_ptr(), b.data_ptr(), _p(residual), alpha, c.data_ptr(),
+                                        _p(z), m, n, k, k, n, n, float(drop_p), int(seed), _stream())
+    _lib.check(st, "cfm_gemm_train_f32")
+    return (c, z) if save_z else c
+
+
+def dropout_apply(x, drop_p: float, seed: int):
+    """x * mask(seed, flat index) -- the same mask cfm_gemm_train_f32 applied to a contiguous (M,N) result."""
+    x = _req(x, "x")
+    if drop_p <= 0.0:
+        return x
+    y = torch.empty_like(x)
+    _lib.check(_lib.load().cfm_dropout_f32(x.data_ptr(), y.data_ptr(), x.numel(), float(drop_p), int(seed), _stream()),
+               "cfm_dropout_f32")
+    return y
+
+
 def glu_fwd(z):
     z = _req(z, "z")
     n = z.shape[-1] // 2
@@ -259,7 +291,8 @@ def colsum(x2d, alpha: float = 1.0, rows=None, cols=None, ld=None, out=None):
 
 def gemm_bwd(A, a_col: bool, B, b_col: bool, I: int, J: int, Kc: int, *, alpha: float = 1.0, Z=None, out=None,
              lda=None, ldb=None, ldc=None, ldz=None, allow_split: bool = False, accumulate: bool = False,
-             nbatch: int = 1, nb1: int = 1, sa=(0, 0), sb=(0, 0), sc=(0, 0), a_ptr=None, b_ptr=None, c_ptr=None):
+             nbatch: int = 1, nb1: int = 1, sa=(0, 0), sb=(0, 0), sc=(0, 0), a_ptr=None, b_ptr=None, c_ptr=None,
+             drop_p: float = 0.0, drop_seed: int = 0):
     """C (I,J) (+)= alpha * sum_k A(i,k) B(j,k) [* swish'(Z)]; *_col selects the contraction-major layout.
     Pointers default to the tensors' data_ptr(); explicit *_ptr / ld* let callers address sub-blocks (head slices)."""
     lda = A.stride(-2) if lda is None else lda
@@ -271,12 +304,13 @@ def gemm_bwd(A, a_col: bool, B, b_col: bool, I: int, J: int, Kc: int, *, alpha: 
     st = _lib.load().cfm_gemm_bwd_batched_f32(
         A.data_ptr() if a_ptr is None else a_ptr, int(a_col), lda, B.data_ptr() if b_ptr is None else b_ptr, int(b_col),
         ldb, _p(Z), ldz, alpha, out.data_ptr() if c_ptr is None else c_ptr, ldc, I, J, Kc, int(allow_split),
-        int(accumulate), nbatch, nb1, sa[0], sa[1], sb[0], sb[1], sc[0], sc[1], _stream())
+        int(accumulate), nbatch, nb1, sa[0], sa[1], sb[0], sb[1], sc[0], sc[1], float(drop_p), int(drop_seed),
+        _stream())
     _lib.check(st, "cfm_gemm_bwd_batched_f32")
     return out
 
 
-def linear_bwd(x2d, w, dy2d, *, alpha: float = 1.0, Z=None, need_dx: bool = True):
+def linear_bwd(x2d, w, dy2d, *, alpha: float = 1.0, Z=None, need_dx: bool = True, drop_p: float = 0.0, drop_seed: int = 0):
     """Backward of y = x @ w.T + b for 2-D views: returns (dx or None, dw, db), all scaled by alpha;
     dx is additionally multiplied by swish'(Z) when Z is given (then it is d/d(pre-activation))."""
     m, k = x2d.shape
@@ -284,7 +318,7 @@ def linear_bwd(x2d, w, dy2d, *, alpha: float = 1.0, Z=None, need_dx: bool = True
     w2 = w.reshape(n, -1)
     dx = None
     if need_dx:
-        dx = gemm_bwd(dy2d, False, w2, True, m, k, n, alpha=alpha, Z=Z)
+        dx = gemm_bwd(dy2d, False, w2, True, m, k, n, alpha=alpha, Z=Z, drop_p=drop_p, drop_seed=drop_seed)
     dw, db = _zeros_split(x2d.device, x2d.dtype, (n, k), (n,))
     gemm_bwd(dy2d, True, x2d, True, n, k, m, alpha=alpha, allow_split=True, out=dw)
     colsum(dy2d, alpha, out=db)
@@ -321,8 +355,8 @@ def dwconv_bn_swish_bwd(g, dy, w, b, bn_w, bn_b, bn_mean, bn_var, eps: float = 1
     return dg, dw, db, dga, dbe
 
 
-def relpos_attention_train(qkv, pos, u, v, lengths, n_heads):
-    """Forward that also returns the per-row log-sum-exp (B,H,T) for the backward."""
+def relpos_attention_train(qkv, pos, u, v, lengths, n_heads, drop_p: float = 0.0, seed: int = 0):
+    """Forward that also returns the per-row log-sum-exp (B,H,T) for the backward; optional weight dropout."""
     qkv = _req(qkv, "qkv"); u = _req(u, "content_bias"); v = _req(v, "position_bias")
     B, T, d3 = qkv.shape
     d = d3 // 3
@@ -330,14 +364,14 @@ def relpos_attention_train(qkv, pos, u, v, lengths, n_heads):
     ctx = torch.empty(B, T, d, device=qkv.device, dtype=qkv.dtype)
     lse = torch.empty(B, n_heads, T, device=qkv.device, dtype=qkv.dtype)
     base = qkv.data_ptr()
-    st = _lib.load().cfm_relpos_attention_fwd_f32(base, base + 4 * d, base + 8 * d, d3, pos.data_ptr(), pos.stride(0),
-                                                  u.data_ptr(), v.data_ptr(), _p(lengths), ctx.data_ptr(), d,
-                                                  lse.data_ptr(), B, T, n_heads, dh, _stream())
-    _lib.check(st, "cfm_relpos_attention_fwd_f32")
+    st = _lib.load().cfm_relpos_attention_train_f32(base, base + 4 * d, base + 8 * d, d3, pos.data_ptr(), pos.stride(0),
+                                                    u.data_ptr(), v.data_ptr(), _p(lengths), ctx.data_ptr(), d,
+                                                    lse.data_ptr(), B, T, n_heads, dh, float(drop_p), int(seed), _stream())
+    _lib.check(st, "cfm_relpos_attention_train_f32")
     return ctx, lse
 
 
-def relpos_attention_bwd(qkv, pos, u, v, lengths, n_heads, ctx, lse, dctx):
+def relpos_attention_bwd(qkv, pos, u, v, lengths, n_heads, ctx, lse, dctx, drop_p: float = 0.0, seed: int = 0):
     """Backward of the attention core.  Returns (dqkv (B,T,3d), dpos (2T-1,d), du (H,dh), dv (H,dh)).
     Round-1 form: batched MFMA GEMMs over re-materialised (B,H,T,T) tensors (attention_bwd_f32.hip)."""
     lib = _lib.load()
@@ -379,7 +413,8 @@ def relpos_attention_bwd(qkv, pos, u, v, lengths, n_heads, ctx, lse, dctx):
     gemm_bwd(dctx, False, qkv, False, T, T4, dh, out=dP, lda=d, ldb=d3, ldc=T4, nbatch=nb, nb1=H,
              sa=sBH_rows, sb=sBH_qkv, sc=sBH_sq, b_ptr=vp)
     _lib.check(lib.cfm_attn_softmax_bwd_f32(content.data_ptr(), posfull.data_ptr(), dP.data_ptr(), lse.data_ptr(),
-                                            Dr.data_ptr(), _p(lengths), scale, B, T, H, T4, P4, _stream()),
+                                            Dr.data_ptr(), _p(lengths), scale, B, T, H, T4, P4, float(drop_p), int(seed),
+                                            _stream()),
                "cfm_attn_softmax_bwd_f32")
     Pm, dS, dpf = content, dP, posfull                      # in-place results
     dqkv = torch.empty(B, T, d3, device=dev, dtype=dt)

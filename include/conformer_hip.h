@@ -149,7 +149,23 @@ int cfm_gemm_bwd_batched_f32(const float* A, int a_col, int64_t lda, const float
                              const float* Z_or_null, int64_t ldz, float alpha, float* C, int64_t ldc,
                              int I, int J, int64_t Kc, int allow_split, int accumulate, int nbatch, int nb1,
                              int64_t sa0, int64_t sa1, int64_t sb0, int64_t sb1, int64_t sc0, int64_t sc1,
-                             cfm_stream_t stream);
+                             float drop_p, uint64_t drop_seed, cfm_stream_t stream);
+
+/* Dropout (nn.Dropout of ffn.py:19,21, attention.py:17,67, convolution.py:30, encoder.py:25) is a counter-based mask:
+ * element idx of a tensor is kept (scaled by 1/(1-p)) or zeroed as a pure function of (seed, idx), so the backward
+ * regenerates it.  The stream is NOT torch's Philox stream (parity runs use p = 0).
+ *   cfm_gemm_train_f32: the forward GEMMs with the mask fused in the epilogue (epi 0 bias, 1 swish [+Z saved], 4 residual)
+ *   cfm_relpos_attention_train_f32: mask on the softmax weights, index ((b*H+h)*T + i)*T + k
+ *   cfm_dropout_f32: y = x * mask (flat index), used on incoming gradients in the backward                      */
+int cfm_gemm_train_f32(int epi, const float* A, const float* W, const float* bias, const float* R_or_null,
+                       float alpha, float* C, float* Z_or_null, int64_t M, int N, int K, int64_t lda,
+                       int64_t ldr, int64_t ldc, float drop_p, uint64_t drop_seed, cfm_stream_t stream);
+int cfm_relpos_attention_train_f32(const float* q, const float* k, const float* v, int64_t ld,
+                                   const float* pos, int64_t ldp, const float* u, const float* vbias,
+                                   const int64_t* lengths_or_null, float* ctx, int64_t ldo, float* lse,
+                                   int B, int T, int H, int dh, float drop_p, uint64_t drop_seed,
+                                   cfm_stream_t stream);
+int cfm_dropout_f32(const float* x, float* y, int64_t n, float p, uint64_t seed, cfm_stream_t stream);
 
 /* LayerNorm backward (mean/rstd = the forward's saved row statistics).  dx = LN'(dy) [+ dres];
  * dgamma/dbeta accumulated. */
@@ -195,7 +211,8 @@ int cfm_attn_rowdot_f32(const float* dO, const float* O, float* D, int B, int T,
                         cfm_stream_t stream);
 int cfm_attn_softmax_bwd_f32(float* content_to_p, float* posfull_to_dposfull, float* dp_to_ds,
                              const float* lse, const float* D, const int64_t* lengths_or_null, float scale,
-                             int B, int T, int H, int T4, int P4, cfm_stream_t stream);
+                             int B, int T, int H, int T4, int P4, float drop_p, uint64_t drop_seed,
+                             cfm_stream_t stream);
 int cfm_add_strided_f32(float* dst, int64_t ld_dst, const float* src, int64_t ld_src, int64_t rows, int cols,
                         cfm_stream_t stream);
 

@@ -142,10 +142,10 @@ def test_encoder_cfg2_shapes_vs_oracle(dev):
 
 
 def test_unbuilt_training_features_are_refused_loudly(dev):
-    """No silent fallback: what has no kernels yet raises (dropout masks; gradient w.r.t. the input spectrogram)."""
+    """No silent fallback: what has no kernels yet raises (train-mode dropout under no_grad; gradient w.r.t. the input)."""
     from model.modules.encoder import Encoder
     from model.utils.ffn import FeedForwardModule
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(NotImplementedError), torch.no_grad():
         FeedForwardModule(32, dropout_rate=0.1).to(dev).train()(torch.zeros(2, 4, 32, device=dev))
     enc = Encoder(80, 1, 32, 4, 7).to(dev).eval()
     with pytest.raises(NotImplementedError):
