@@ -173,6 +173,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch the ~260 kernels eagerly instead of one hipGraph replay")
+    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
+                    help="f32 = the headline configuration (BASELINE cfg-2); bf16 = torch.autocast(bfloat16): dense GEMMs on "
+                         "the bf16 matrix pipe with fp32 accumulate and fp32 tensors (secondary result, never the default)")
     args = ap.parse_args()
 
     from conformer_amd import parallel
@@ -206,15 +209,18 @@ def main():
     log(f"[bench] rank {rank}/{world}: model on {dev}, warm-up {args.warmup} steps")
     last = {}
     runner, graphed = enc, False
-    if not args.no_graph:
+    if not args.no_graph and args.dtype == "f32":
         try:
             from conformer_amd.graph import GraphedEncoder
             runner, graphed = GraphedEncoder(enc, x, lengths), True
         except Exception as e:                               # capture is an optimisation: fall back to eager launches
             log(f"[bench] hipGraph capture unavailable ({type(e).__name__}: {e}); eager launches")
 
+    import contextlib
+    amp = (lambda: torch.autocast("cuda", dtype=torch.bfloat16)) if args.dtype == "bf16" else contextlib.nullcontext
+
     def step():
-        with torch.no_grad():
+        with torch.no_grad(), amp():
             last["y"], _ = runner(x, lengths)
 
     dt = parallel.timed_steps(step, args.steps, args.warmup, torch.cuda.synchronize, dev)
@@ -230,7 +236,7 @@ def main():
         "metric": "encoder audio-frames/sec (B=32,T=1000,d=512,L=16)",
         "value": frames / dt, "unit": "audio-frames/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic", "launch": "hipGraph replay" if graphed else "eager",
+        "dtype": "f32" if args.dtype == "f32" else "bf16 MFMA operands, f32 accumulate/storage (autocast)", "data": "synthetic", "launch": "hipGraph replay" if graphed else "eager",
         "config": {"workload": "cfg2 Conformer-L Encoder.forward: B=32/GPU, T=1000 mel frames (T'=249), d=512, 16 blocks, "
                                "8 heads, k=31, fp32, eval, random-init weights, batch-sharded replicas",
                    "per_gpu_batch": CFG["B"], "mel_frames": CFG["T"]},
@@ -238,7 +244,7 @@ def main():
         "path_frac_of_mfma_f32_peak": flops / (ms * 1e-3) / 1e12 / PEAK_MFMA_F32_TFLOPS,
     }
 
-    if rank == 0 and not args.no_roofline:
+    if rank == 0 and not args.no_roofline and args.dtype == "f32":
         rows = gemm_site_table(enc, x, iters=10)
         tot = sum(r["avg_ms"] * r["launches_per_step"] for r in rows)
         dom = max(rows, key=lambda r: r["avg_ms"] * r["launches_per_step"])

@@ -1,0 +1,179 @@
+// bf16-MFMA GEMM with fp32 storage: C = epilogue(bf16(A) . bf16(W)^T + bias), fp32 accumulate, fp32 in/out.
+//
+// This is the arithmetic torch.autocast(bfloat16) gives nn.Linear / Conv (inputs rounded to bf16, fp32 accumulation;
+// SURVEY.md Appendix D) and what the reference's train.py runs under AMP (train.py:232).  Operands stay fp32 in HBM --
+// LayerNorm, residual stream, softmax and every epilogue keep fp32 -- and are rounded to bf16 (v_cvt_pk_bf16_f32, RNE)
+// on their way into LDS, so no bf16 copies of activations or weights ever exist.
+// v_mfma_f32_32x32x16_bf16 runs at 16x the fp32 MFMA rate: the kernel is bound by the fp32 operand stream
+// (L2 -> LDS), not by the matrix pipe, so the staging is built for bytes: K-tile 64 (each row of a tile is 256
+// contiguous bytes = two full cache lines, 16 lanes x 16 B), registers -> bf16 -> LDS rows of 144 B (conflict-free
+// ds_read_b128: one read = the 8 k-values one lane feeds one MFMA), LDS double buffer, one barrier per K-tile.
+// Block tile 128x128 or 64x64, 4 waves (2x2); accumulators transposed (lanes = rows) for the shared 16-byte epilogue.
+#include "gemm_shared.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ bf16x4 to_bf16x4(const f32x4 v) {
+    bf16x4 r;
+    r[0] = (__bf16)v.x; r[1] = (__bf16)v.y; r[2] = (__bf16)v.z; r[3] = (__bf16)v.w;
+    return r;
+}
+
+template <int BM, int BN, int EPI, bool CONV>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmArgs g) {
+    constexpr int TM = BM / 64, TN = BN / 64, BK = 64;
+    constexpr int ROWB = 72;                                  // LDS row in bf16 elements: 64 + 8 pad = 144 B
+    constexpr int NA = BM / 16, NB = BN / 16;                 // float4 loads per thread per K-tile (rows / 16 passes)
+    static_assert(EPI != EPI_GLU || TN == 2, "GLU keeps value and gate tiles in one wave");
+    __shared__ __attribute__((aligned(16))) __bf16 lds[2 * (BM + BN) * ROWB];
+    __bf16* As = lds;                     // [2][BM][ROWB]
+    __bf16* Bs = lds + 2 * BM * ROWB;     // [2][BN][ROWB]
+
+    const unsigned nwg = g.tiles_m * g.tiles_n;
+    const unsigned tile = xcd_remap(blockIdx.x, nwg);
+    const unsigned tm = tile / g.tiles_n, tn = tile % g.tiles_n;
+    const int64_t m0 = (int64_t)tm * BM;
+    const int n0 = (int)tn * (EPI == EPI_GLU ? BN / 2 : BN);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int li = lane & 31, hf = lane >> 5;
+
+    // ---- staging: 16 lanes cover the 256 B of one tile row; pass p handles rows srow + 16 p
+    const int srow = tid >> 4, sch = tid & 15;
+    const float* a_ptr[NA];
+    const float* w_ptr[NB];
+#pragma unroll
+    for (int p = 0; p < NA; ++p) a_ptr[p] = a_row_ptr<CONV>(g, m0 + srow + 16 * p);
+#pragma unroll
+    for (int p = 0; p < NB; ++p) w_ptr[p] = w_row_ptr<EPI, BN>(g, n0, srow + 16 * p);
+    f32x4 ra[NA], rb[NB];
+    auto load_tile = [&](int kt) {
+        const int k = kt * BK + sch * 4;
+        const int64_t aoff = a_k_offset<CONV>(g, kt * BK) + sch * 4;
+        const bool ok = k < g.K;
+#pragma unroll
+        for (int p = 0; p < NA; ++p)
+            ra[p] = ok ? *reinterpret_cast<const f32x4*>(a_ptr[p] + aoff) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int p = 0; p < NB; ++p)
+            rb[p] = ok ? *reinterpret_cast<const f32x4*>(w_ptr[p] + k) : f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int p = 0; p < NA; ++p)
+            *reinterpret_cast<bf16x4*>(As + (buf * BM + srow + 16 * p) * ROWB + sch * 4) = to_bf16x4(ra[p]);
+#pragma unroll
+        for (int p = 0; p < NB; ++p)
+            *reinterpret_cast<bf16x4*>(Bs + (buf * BN + srow + 16 * p) * ROWB + sch * 4) = to_bf16x4(rb[p]);
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // lane (row li, half hf) feeds k = 16 s + 8 hf + {0..7} of MFMA step s: one 16-byte read
+    const int a_row = wr * (BM / 2) + li, b_row = wc * (BN / 2) + li;
+    const int nkt = (g.K + BK - 1) / BK;
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int cur = kt & 1;
+        const bool more = kt + 1 < nkt;
+        if (more) load_tile(kt + 1);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            bf16x8 fa[TM], fb[TN];
+#pragma unroll
+            for (int t = 0; t < TM; ++t)
+                fa[t] = *reinterpret_cast<const bf16x8*>(As + (cur * BM + a_row + 32 * t) * ROWB + 16 * s + 8 * hf);
+#pragma unroll
+            for (int t = 0; t < TN; ++t)
+                fb[t] = *reinterpret_cast<const bf16x8*>(Bs + (cur * BN + b_row + 32 * t) * ROWB + 16 * s + 8 * hf);
+#pragma unroll
+            for (int mt = 0; mt < TM; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < TN; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[nt], fa[mt], acc[mt][nt], 0, 0, 0);
+        }
+        if (more) store_tile(cur ^ 1);
+        __syncthreads();
+    }
+    gemm_epilogue<BM, BN, EPI, TM, TN>(g, acc, m0, n0, wr, wc, li, hf);
+}
+
+template <int BM, int BN, int EPI, bool CONV>
+int launch_cfg(GemmArgs g, hipStream_t s) {
+    const int ncols = EPI == EPI_GLU ? g.n_out : g.N;
+    const int bn = EPI == EPI_GLU ? BN / 2 : BN;
+    g.tiles_m = (unsigned)((g.M + BM - 1) / BM);
+    g.tiles_n = (unsigned)((ncols + bn - 1) / bn);
+    hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, EPI, CONV>), dim3(g.tiles_m * g.tiles_n), dim3(256), 0, s, g);
+    return cfm_launch_status();
+}
+
+template <int EPI, bool CONV>
+int launch(const GemmArgs& g, hipStream_t s) {
+    const int ncols = EPI == EPI_GLU ? g.n_out : g.N;
+    const int bn = EPI == EPI_GLU ? 64 : 128;
+    const int64_t t128 = ((g.M + 127) / 128) * ((ncols + bn - 1) / bn);
+    if constexpr (EPI == EPI_GLU) {
+        return t128 >= 512 ? launch_cfg<128, 128, EPI, CONV>(g, s) : launch_cfg<64, 128, EPI, CONV>(g, s);
+    } else {
+        return t128 >= 512 ? launch_cfg<128, 128, EPI, CONV>(g, s) : launch_cfg<64, 64, EPI, CONV>(g, s);
+    }
+}
+
+}  // namespace
+
+// epi: 0 bias | 1 bias+swish | 2 bias+relu | 3 bias+GLU (N = n_out columns of C, W has 2*n_out rows) | 4 alpha*y + R.
+// Same layouts and argument rules as the fp32 entry points of the forward section; results differ from them by the bf16
+// rounding of A and W only (<= 2^-9 relative per operand).
+extern "C" int cfm_gemm_bf16mfma_f32(int epi, const float* A, const float* W, const float* bias, const float* R_or_null,
+                                     float alpha, float* C, int64_t M, int N, int K, int64_t lda, int64_t ldr,
+                                     int64_t ldc, cfm_stream_t stream) {
+    CFM_REQUIRE(A && W && bias && C, CFM_ERR_NULL);
+    CFM_REQUIRE(M > 0 && N > 0 && K > 0 && (K & 3) == 0 && (lda & 3) == 0 && lda >= K && ldc >= N, CFM_ERR_BAD_SHAPE);
+    CFM_REQUIRE(CFM_ALIGNED16(A) && CFM_ALIGNED16(W), CFM_ERR_ALIGN);
+    GemmArgs g{};
+    g.A = A; g.W = W; g.bias = bias; g.R = R_or_null; g.C = C; g.M = M; g.K = K; g.lda = lda; g.ldr = ldr; g.ldc = ldc;
+    g.alpha = alpha;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (epi == EPI_GLU) {
+        g.n_out = N; g.N = 2 * N;
+        return launch<EPI_GLU, false>(g, s);
+    }
+    g.N = N;
+    switch (epi) {
+        case EPI_BIAS: return launch<EPI_BIAS, false>(g, s);
+        case EPI_SWISH: return launch<EPI_SWISH, false>(g, s);
+        case EPI_RELU: return launch<EPI_RELU, false>(g, s);
+        case EPI_RESID:
+            CFM_REQUIRE(R_or_null != nullptr, CFM_ERR_NULL);
+            CFM_REQUIRE(ldr >= N, CFM_ERR_BAD_SHAPE);
+            return launch<EPI_RESID, false>(g, s);
+        default: return CFM_ERR_UNSUPPORTED;
+    }
+}
+
+// bf16-MFMA form of cfm_subsample_conv2_relu_f32 (C % 64 == 0).
+extern "C" int cfm_subsample_conv2_relu_bf16mfma_f32(const float* h1, const float* w2p, const float* b2, float* h2, int B,
+                                                     int F1, int T1, int C, cfm_stream_t stream) {
+    CFM_REQUIRE(h1 && w2p && b2 && h2, CFM_ERR_NULL);
+    CFM_REQUIRE(B > 0 && F1 >= 3 && T1 >= 3 && C > 0, CFM_ERR_BAD_SHAPE);
+    CFM_REQUIRE(C % 64 == 0, CFM_ERR_UNSUPPORTED);
+    CFM_REQUIRE(CFM_ALIGNED16(h1) && CFM_ALIGNED16(w2p) && CFM_ALIGNED16(h2), CFM_ERR_ALIGN);
+    GemmArgs g{};
+    g.cT1 = T1; g.cF1 = F1; g.cC = C; g.cT2 = (T1 - 1) / 2; g.cF2 = (F1 - 1) / 2;
+    g.A = h1; g.W = w2p; g.bias = b2; g.C = h2;
+    g.M = (int64_t)B * g.cT2 * g.cF2; g.N = C; g.K = 9 * C; g.lda = 0; g.ldc = C; g.alpha = 1.f;
+    return launch<EPI_RELU, true>(g, static_cast<hipStream_t>(stream));
+}

@@ -30,6 +30,25 @@ def _p(t: Optional[torch.Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
 
 
+def bf16_mfma_active() -> bool:
+    """True inside `torch.autocast("cuda", dtype=torch.bfloat16)`: the dense GEMMs then round their operands to bf16 and
+    run on the bf16 matrix pipe (fp32 accumulate, fp32 tensors) -- the arithmetic autocast gives nn.Linear / Conv.
+    fp16 autocast (the reference's `--fp16 1`, train.py:217) has no kernel path and is refused."""
+    if not torch.is_autocast_enabled("cuda"):
+        return False
+    dt = torch.get_autocast_dtype("cuda")
+    if dt == torch.bfloat16:
+        return True
+    raise _lib.ConformerHipError(f"autocast dtype {dt} is not supported by the gfx950 path (use torch.bfloat16 or fp32)")
+
+
+def _bf16_gemm(epi: int, a, w2, b, c, m, n, k, res=None, alpha: float = 1.0):
+    st = _lib.load().cfm_gemm_bf16mfma_f32(epi, a.data_ptr(), w2.data_ptr(), b.data_ptr(), _p(res), alpha, c.data_ptr(),
+                                           m, n, k, k, n, n, _stream())
+    _lib.check(st, "cfm_gemm_bf16mfma_f32")
+    return c
+
+
 def subsampled_length(n: int) -> int:
     return int(_lib.load().cfm_subsampled_length(int(n)))
 
@@ -60,6 +79,8 @@ def linear(a, w, b, act: str = "none") -> torch.Tensor:
     """y = act(a @ w.T + b); act in {none, swish, relu}."""
     a, w2, b, m, n, k = _gemm_common(a, w, b)
     c = torch.empty(*a.shape[:-1], n, device=a.device, dtype=a.dtype)
+    if bf16_mfma_active():
+        return _bf16_gemm({"none": 0, "swish": 1, "relu": 2}[act], a, w2, b, c, m, n, k)
     fn = {"none": "cfm_gemm_bias_f32", "swish": "cfm_gemm_bias_swish_f32", "relu": "cfm_gemm_bias_relu_f32"}[act]
     st = getattr(_lib.load(), fn)(a.data_ptr(), w2.data_ptr(), b.data_ptr(), c.data_ptr(), m, n, k, k, n, _stream())
     _lib.check(st, fn)
@@ -71,6 +92,8 @@ def linear_glu(a, w, b) -> torch.Tensor:
     a, w2, b, m, n2, k = _gemm_common(a, w, b)
     n = n2 // 2
     c = torch.empty(*a.shape[:-1], n, device=a.device, dtype=a.dtype)
+    if bf16_mfma_active():
+        return _bf16_gemm(3, a, w2, b, c, m, n, k)
     st = _lib.load().cfm_gemm_bias_glu_f32(a.data_ptr(), w2.data_ptr(), b.data_ptr(), c.data_ptr(), m, n, k, k, n,
                                            _stream())
     _lib.check(st, "cfm_gemm_bias_glu_f32")
@@ -82,6 +105,8 @@ def linear_residual(a, w, b, res: torch.Tensor, alpha: float = 1.0) -> torch.Ten
     a, w2, b, m, n, k = _gemm_common(a, w, b)
     res = _req(res, "residual")
     c = torch.empty(*a.shape[:-1], n, device=a.device, dtype=a.dtype)
+    if bf16_mfma_active():
+        return _bf16_gemm(4, a, w2, b, c, m, n, k, res, alpha)
     st = _lib.load().cfm_gemm_bias_residual_f32(a.data_ptr(), w2.data_ptr(), b.data_ptr(), res.data_ptr(), alpha,
                                                 c.data_ptr(), m, n, k, k, n, n, _stream())
     _lib.check(st, "cfm_gemm_bias_residual_f32")
@@ -161,6 +186,10 @@ def subsample_stem(x: torch.Tensor, w1, b1, w2p, b2) -> torch.Tensor:
     _lib.check(lib.cfm_subsample_conv1_relu_f32(x.data_ptr(), w1.data_ptr(), b1.data_ptr(), h1.data_ptr(), B, F, T, C,
                                                 _stream()), "cfm_subsample_conv1_relu_f32")
     h2 = torch.empty(B, T2, F2 * C, device=x.device, dtype=x.dtype)
+    if bf16_mfma_active() and C % 64 == 0:
+        _lib.check(lib.cfm_subsample_conv2_relu_bf16mfma_f32(h1.data_ptr(), w2p.data_ptr(), b2.data_ptr(), h2.data_ptr(), B,
+                                                             F1, T1, C, _stream()), "cfm_subsample_conv2_relu_bf16mfma_f32")
+        return h2
     _lib.check(lib.cfm_subsample_conv2_relu_f32(h1.data_ptr(), w2p.data_ptr(), b2.data_ptr(), h2.data_ptr(), B, F1, T1,
                                                 C, _stream()), "cfm_subsample_conv2_relu_f32")
     return h2

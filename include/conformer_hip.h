@@ -115,6 +115,16 @@ int cfm_subsample_conv2_relu_f32(const float* h1, const float* w2p, const float*
                                  int B, int F1, int T1, int C, cfm_stream_t stream);
 int cfm_pack_linear_weight_f32(const float* wl, float* wlp, int d_out, int C, int F2, cfm_stream_t stream);
 
+/* ---- bf16-MFMA forward GEMMs with fp32 storage (torch.autocast(bfloat16) arithmetic for nn.Linear / Conv,
+ *      train.py:232 under AMP): operands are rounded to bf16 on their way into LDS, accumulation
+ *      and epilogues are fp32, tensors in HBM stay fp32.  epi: 0 bias | 1 +swish | 2 +relu | 3 +GLU | 4 alpha*y+R;
+ *      argument rules as the fp32 entry points (for GLU, N = n_out and W has 2*n_out rows). */
+int cfm_gemm_bf16mfma_f32(int epi, const float* A, const float* W, const float* bias, const float* R_or_null,
+                          float alpha, float* C, int64_t M, int N, int K, int64_t lda, int64_t ldr,
+                          int64_t ldc, cfm_stream_t stream);
+int cfm_subsample_conv2_relu_bf16mfma_f32(const float* h1, const float* w2p, const float* b2, float* h2, int B,
+                                          int F1, int T1, int C, cfm_stream_t stream);
+
 /* ---- audio front end (processing/processor.py:53-63,155-158,373-394; processing/augment.py:7-19).
  *      log-mel = reflect_pad -> [frames * window * DFT] as cfm_gemm_bwd_batched_f32 over overlapping rows
  *      (A = padded wave, lda = hop; B = windowed (2*n_bins, n_fft) cos/-sin basis) -> power_mel_log:
