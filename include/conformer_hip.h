@@ -248,6 +248,24 @@ int cfm_subsample_conv2_bwd_input_f32(const float* dz2, const float* w2c, float*
 int cfm_subsample_conv1_bwd_f32(const float* x, const float* w1, const float* b1, const float* dh1, float* dw1,
                                 float* db1, int B, int F, int T, int C, cfm_stream_t stream);
 
+/* ---- "next" rows.  N2: one fused Adam step (torch.optim.Adam defaults, train.py:188) over many tensors:
+ *      `tensors` is a HOST array of n_tensors descriptors holding DEVICE pointers; ceil(n/48) launches, the table rides
+ *      in the kernel arguments.  bias_c1 = 1-beta1^t, sqrt_bias_c2 = sqrt(1-beta2^t) (t = step count after increment).
+ *      N4: greedy CTC decode (processor.py:301-328): per-frame argmax (B,T) int64, decoded ids (B,T) padded with -1,
+ *      counts (B); pad/unk frames are skipped WITHOUT resetting the repeat filter (reference behaviour). */
+typedef struct cfm_adam_tensor {
+    float* param;
+    const float* grad;
+    float* exp_avg;
+    float* exp_avg_sq;
+    int64_t numel;
+} cfm_adam_tensor;
+int cfm_adam_step_f32(const cfm_adam_tensor* tensors, int n_tensors, float lr, float beta1, float beta2, float eps,
+                      float bias_c1, float sqrt_bias_c2, cfm_stream_t stream);
+int cfm_greedy_ctc_decode_f32(const float* logits, const int64_t* lengths_or_null, int64_t* frame_ids,
+                              int64_t* tokens, int64_t* counts, int B, int T, int V, int pad_id, int unk_id,
+                              cfm_stream_t stream);
+
 /* diagnostics only (process-global, not thread-safe): force the block tile of cfm_gemm_bwd* (-1 = heuristic) */
 int cfm_debug_set_bwd_tile(int tile);
 

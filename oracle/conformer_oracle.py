@@ -303,3 +303,29 @@ def make_params(vocab: int, n_mel: int, n_blocks: int, d: int, n_heads: int, ksi
         bn(dd + "norm", lstm_hidden)
         lin(dd + "linear", vocab, lstm_hidden)
     return P
+
+
+# --------------------------------------------------------------------------- "next" rows: N2 Adam, N4 greedy decode
+def greedy_decode_ids(logits: torch.Tensor, pad_id: int, unk_id: int):
+    """Token-id level restatement of ConformerProcessor.greedy_decode (processor.py:301-318) for one (T,V) utterance:
+    argmax per frame, skip pad/unk (WITHOUT resetting the repeat filter), drop consecutive repeats."""
+    ids = logits.argmax(-1).tolist()
+    out, prev = [], None
+    for t in ids:
+        if t == pad_id or t == unk_id:
+            continue
+        if prev is None or prev != t:
+            prev = t
+            out.append(t)
+    return ids, out
+
+
+def adam_reference(params, grads_per_step, lr=2e-5, betas=(0.9, 0.999), eps=1e-8):
+    """torch.optim.Adam (train.py:188) on CPU float64 tensors: returns the parameters after len(grads_per_step) steps."""
+    ps = [p.clone().double().requires_grad_(True) for p in params]
+    opt = torch.optim.Adam(ps, lr=lr, betas=betas, eps=eps)
+    for grads in grads_per_step:
+        for p, g in zip(ps, grads):
+            p.grad = g.double().clone()
+        opt.step()
+    return [p.detach() for p in ps]

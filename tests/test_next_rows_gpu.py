@@ -1,0 +1,69 @@
+"""N2 fused Adam and N4 greedy CTC decode on the device vs their oracle restatements."""
+import pytest
+import torch
+
+from oracle import conformer_oracle as O
+from tests.util import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda:0")
+
+
+def test_fused_adam_matches_torch_adam(dev):
+    from conformer_amd.optim import FusedAdam
+    g = torch.Generator().manual_seed(0)
+    shapes = [(512, 2048), (17,), (3, 5, 7), (4099,), (1,), (64, 1, 31)]
+    params = [torch.randn(*s, generator=g) for s in shapes]
+    grads = [[torch.randn(*s, generator=g) * (0.1 + k) for s in shapes] for k in range(4)]
+    ref = O.adam_reference(params, grads, lr=1e-2)
+    ps = [torch.nn.Parameter(p.to(dev)) for p in params]
+    opt = FusedAdam(ps, lr=1e-2)
+    for k in range(4):
+        for p, gr in zip(ps, grads[k]):
+            p.grad = gr.to(dev)
+        opt.step()
+    for p, r in zip(ps, ref):
+        assert rel_l2(p, r) < 2e-6
+    # state layout interchanges with torch.optim.Adam (manager.py:34-40 saves optimizer.state_dict())
+    sd = opt.state_dict()
+    t_opt = torch.optim.Adam(ps, lr=1e-2)
+    t_opt.load_state_dict(sd)
+    assert int(t_opt.state[ps[0]]["step"]) == 4
+    for p, gr in zip(ps, grads[0]):
+        p.grad = gr.to(dev)
+    before = [p.detach().clone() for p in ps]
+    t_opt.step()                                           # stock Adam continues from the fused optimizer's state
+    assert all(torch.isfinite(p).all() and not torch.equal(p, b) for p, b in zip(ps, before))
+
+
+@pytest.mark.parametrize("B,T,V", [(1, 1, 5), (3, 49, 370), (2, 249, 370), (4, 25, 17)])
+def test_greedy_decode_bit_exact(dev, B, T, V):
+    from conformer_amd.decode import greedy_ctc_decode, tokens_to_text
+    g = torch.Generator().manual_seed(B * 1000 + T)
+    logits = torch.randn(B, T, V, generator=g)
+    # long runs, pads between repeats, exact ties
+    logits[:, : T // 2, 3 % V] += 6.0
+    logits[:, ::5, 0] += 9.0
+    if T > 4:
+        logits[0, 4, :] = 0.0
+        logits[0, 4, [V - 1, 2 % V]] = 5.0                   # tie -> lowest index
+    pad_id, unk_id = 0, 1 % V
+    frame_ids, tokens, counts = greedy_ctc_decode(logits.to(dev), pad_id, unk_id)
+    for b in range(B):
+        ids, out = O.greedy_decode_ids(logits[b], pad_id, unk_id)
+        assert frame_ids[b].tolist() == ids
+        n = int(counts[b])
+        assert tokens[b, :n].tolist() == out and (tokens[b, n:] == -1).all()
+    L = torch.tensor([max(1, T - 3 * b) for b in range(B)])
+    _, tok2, cnt2 = greedy_ctc_decode(logits.to(dev), pad_id, unk_id, L.to(dev))
+    for b in range(B):
+        _, out = O.greedy_decode_ids(logits[b, : int(L[b])], pad_id, unk_id)
+        assert tok2[b, : int(cnt2[b])].tolist() == out
+    vocab = [f"<{i}>" for i in range(V)]
+    assert len(tokens_to_text(tokens, counts, vocab)) == B

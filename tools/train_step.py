@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--frames", type=int, default=1000)
+    ap.add_argument("--optim", choices=["torch", "fused"], default="fused")
     args = ap.parse_args()
     env = parallel.env_from_os()
     torch.cuda.set_device(env.local_rank)
@@ -36,7 +37,11 @@ def main():
     torch.manual_seed(0)
     model = Conformer(370, 80, 16, 512, 8, 31, 640, 1, 0.0).to(dev).train()
     ddp = parallel.wrap_ddp(model, dev)
-    opt = torch.optim.Adam(model.parameters(), lr=2e-5)
+    if args.optim == "fused":
+        from conformer_amd.optim import FusedAdam
+        opt = FusedAdam(model.parameters(), lr=2e-5)
+    else:
+        opt = torch.optim.Adam(model.parameters(), lr=2e-5)
     g = torch.Generator().manual_seed(100 + env.rank)
     x = torch.randn(args.batch, 80, args.frames, generator=g).to(dev)
     lengths = torch.full((args.batch,), args.frames, dtype=torch.int64, device=dev)
@@ -57,7 +62,7 @@ def main():
     if env.is_main:
         ms = dt / args.steps * 1e3
         print(json.dumps({"what": "Conformer-L training step fwd+CTC+bwd+Adam, fp32, dropout 0, BN train",
-                          "n_gpus": env.world, "per_gpu_batch": args.batch, "mel_frames": args.frames,
+                          "optimizer": args.optim, "n_gpus": env.world, "per_gpu_batch": args.batch, "mel_frames": args.frames,
                           "ms_per_step": ms, "frames_per_sec": env.world * args.batch * args.frames * args.steps / dt,
                           "loss": float(last["loss"]), "max_mem_gib": torch.cuda.max_memory_allocated() / 2 ** 30}),
               flush=True)
