@@ -10,6 +10,8 @@ from __future__ import annotations
 
 from typing import Optional
 
+import functools
+
 import torch
 from torch.autograd import Function
 
@@ -20,16 +22,36 @@ def _flat(t: torch.Tensor) -> torch.Tensor:
     return t.reshape(-1, t.shape[-1])
 
 
+def _fwd_prec(fn):
+    """Remember the matrix-pipe precision (autocast state) the forward ran under ..."""
+    @functools.wraps(fn)
+    def wrapped(ctx, *args):
+        ctx.prec = ops.mfma16_prec()
+        return fn(ctx, *args)
+    return wrapped
+
+
+def _bwd_prec(fn):
+    """... and run the backward GEMMs at the same precision (autocast is off inside autograd's backward)."""
+    @functools.wraps(fn)
+    def wrapped(ctx, *grads):
+        with ops.precision(ctx.prec):
+            return fn(ctx, *grads)
+    return wrapped
+
+
 class LayerNormFn(Function):
     """y = LayerNorm(x) -- the block's closing norm (block.py:27)."""
 
     @staticmethod
+    @_fwd_prec
     def forward(ctx, x, weight, bias, eps):
         y, mean, rstd = ops.layernorm_train(x, weight, bias, eps)
         ctx.save_for_backward(x, weight, mean, rstd)
         return y
 
     @staticmethod
+    @_bwd_prec
     def backward(ctx, dy):
         x, weight, mean, rstd = ctx.saved_tensors
         dx, dw, db = ops.layernorm_bwd(x, weight, dy.contiguous(), mean, rstd)
@@ -41,6 +63,7 @@ class LinearFn(Function):
     dx is produced only when x requires grad."""
 
     @staticmethod
+    @_fwd_prec
     def forward(ctx, x, w, b, drop_p=0.0):
         ctx.save_for_backward(x, w)
         ctx.drop_p = float(drop_p)
@@ -50,6 +73,7 @@ class LinearFn(Function):
         return ops.linear(x, w, b)
 
     @staticmethod
+    @_bwd_prec
     def backward(ctx, dy):
         x, w = ctx.saved_tensors
         dy = dy.contiguous()
@@ -64,6 +88,7 @@ class SubsampleStemFn(Function):
     The packed conv2 weight is rebuilt per call in training (weights change every step)."""
 
     @staticmethod
+    @_fwd_prec
     def forward(ctx, x, w1, b1, w2, b2):
         w2p = ops.pack_conv2_weight(w2)
         h2, h1 = ops.subsample_stem_train(x, w1, b1, w2p, b2)
@@ -71,6 +96,7 @@ class SubsampleStemFn(Function):
         return h2
 
     @staticmethod
+    @_bwd_prec
     def backward(ctx, dh2):
         x, w1, b1, w2, h1, h2 = ctx.saved_tensors
         dw1, db1, dw2, db2 = ops.subsample_stem_bwd(x, w1, b1, w2, h1, h2, dh2.contiguous())
@@ -81,6 +107,7 @@ class FeedForwardFn(Function):
     """out = alpha * (W2 . swish(W1 . LN(x) + b1) + b2) + x        (ffn.py:15-23 + block.py:19,25)"""
 
     @staticmethod
+    @_fwd_prec
     def forward(ctx, x, ln_w, ln_b, w1, b1, w2, b2, alpha, eps, drop_p=0.0):
         h0, mean, rstd = ops.layernorm_train(x, ln_w, ln_b, eps)
         ctx.drop_p = float(drop_p)
@@ -93,6 +120,7 @@ class FeedForwardFn(Function):
         return out
 
     @staticmethod
+    @_bwd_prec
     def backward(ctx, dout):
         x, ln_w, mean, rstd, h0, z, h, w1, w2 = ctx.saved_tensors
         dout = dout.contiguous()
@@ -110,6 +138,7 @@ class SelfAttentionFn(Function):
     `pos` is this layer's (2T-1, d) slice of the projected position table (it has its own graph through LinearFn)."""
 
     @staticmethod
+    @_fwd_prec
     def forward(ctx, x, ln_w, ln_b, wq, bq, wk, bk, wv, bv, pos, u, vb, wo, bo, lengths, n_heads, eps, drop_p=0.0):
         h0, mean, rstd = ops.layernorm_train(x, ln_w, ln_b, eps)
         wqkv = torch.cat([wq, wk, wv], dim=0)
@@ -126,6 +155,7 @@ class SelfAttentionFn(Function):
         return out
 
     @staticmethod
+    @_bwd_prec
     def backward(ctx, dout):
         x, ln_w, mean, rstd, h0, wqkv, qkv, pos, u, vb, att, lse, wo, lengths = ctx.saved_tensors
         lengths = lengths if ctx.has_len else None
@@ -149,6 +179,7 @@ class ConvModuleFn(Function):
                       updated in place (momentum) and the backward carries the mean/variance coupling."""
 
     @staticmethod
+    @_fwd_prec
     def forward(ctx, x, ln_w, ln_b, w1, b1, wd, bd, bn_w, bn_b, bn_mean, bn_var, w2, b2, eps_ln, eps_bn, train_bn,
                 momentum, drop_p=0.0):
         h0, mean, rstd = ops.layernorm_train(x, ln_w, ln_b, eps_ln)
@@ -166,6 +197,7 @@ class ConvModuleFn(Function):
         return out
 
     @staticmethod
+    @_bwd_prec
     def backward(ctx, dout):
         x, ln_w, mean, rstd, h0, z, g, s, w1, wd, bd, bn_w, bn_b, bn_mean, bn_var, w2 = ctx.saved_tensors
         dout = dout.contiguous()

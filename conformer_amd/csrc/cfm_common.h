@@ -59,3 +59,30 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nwg) {
     const unsigned base = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q;
     return base + i;
 }
+
+// 16-bit matrix-pipe element types (gemm_mfma16.hip, gemm_bwd_mfma16.hip): conversions are RNE, accumulation is fp32.
+template <typename T16> struct Lowp;
+template <> struct Lowp<__bf16> {
+    typedef __bf16 x8 __attribute__((ext_vector_type(8)));
+    typedef __bf16 x4 __attribute__((ext_vector_type(4)));
+    static __device__ __forceinline__ x4 cvt4(const f32x4 v) {
+        x4 r;
+        r[0] = (__bf16)v.x; r[1] = (__bf16)v.y; r[2] = (__bf16)v.z; r[3] = (__bf16)v.w;
+        return r;
+    }
+    static __device__ __forceinline__ f32x16 mfma(const x8 a, const x8 b, const f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    }
+};
+template <> struct Lowp<_Float16> {
+    typedef _Float16 x8 __attribute__((ext_vector_type(8)));
+    typedef _Float16 x4 __attribute__((ext_vector_type(4)));
+    static __device__ __forceinline__ x4 cvt4(const f32x4 v) {
+        x4 r;
+        r[0] = (_Float16)v.x; r[1] = (_Float16)v.y; r[2] = (_Float16)v.z; r[3] = (_Float16)v.w;
+        return r;
+    }
+    static __device__ __forceinline__ f32x16 mfma(const x8 a, const x8 b, const f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+    }
+};

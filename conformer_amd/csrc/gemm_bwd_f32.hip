@@ -12,26 +12,9 @@
 // conflict-free ds_read_b32 per 8-deep k-slice instead of one ds_read_b128.
 // Weight-gradient products have a short output (N x K) and a long contraction (M = B*T'): they are split along the
 // contraction over gridDim.y slices that accumulate with fp32 atomics into a zero-initialised C (caller zeroes it).
-#include "cfm_common.h"
+#include "gemm_bwd_args.h"
 
 namespace {
-
-enum BwdEpi { BEPI_SCALE = 0, BEPI_DSWISH = 1 };
-
-struct BwdArgs {
-    const float* A; const float* B; const float* Z; float* C;
-    int I, J; int64_t Kc; int64_t lda, ldb, ldz, ldc; float alpha;
-    unsigned tiles_i, tiles_j; int splits; int64_t k_per_split;
-    float drop_p; unsigned long long drop_seed;   // DSWISH: the forward dropped swish(Z): re-apply its mask to the incoming gradient
-    int accumulate;                      // C += ... (non-atomic read-modify-write; not combined with splits)
-    int nbatch, nb1;                     // batched: blockIdx.z = b0*nb1 + b1; operand offset = b0*s?0 + b1*s?1
-    int64_t sa0, sa1, sb0, sb1, sc0, sc1;
-    // stem-convolution gathers (GATHER != 0): geometry of the 3x3 / stride-2 conv over the channel-last h1
-    int cT1, cF1, cT2, cF2, cC;          // h1: (B,T1,F1,C); h2: (B,T2,F2,C)
-    int pA, pC;                          // GATHER 2: class grid (rows per utterance = pA*pC: a < pA, c < pC)
-    int pt, pf;                          // GATHER 2: parity class: t1 = 2a+pt, f1 = 2c+pf
-    int tap_dt[4], tap_df[4];            // GATHER 2: per class tap: t2 = a + dt, f2 = c + df
-};
 
 template <int BT, bool ROW>
 struct OperandTile {                                    // LDS image of one operand's BT x 16 tile, one stage
@@ -230,77 +213,8 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 128) ? 3 : 4) void gemm_bw
     if (kt < nkt) k_step(kt, ra1, rb1);
 #undef BWD_MFMA_SLICE
 
-    if (SPLITK) {
-        // natural orientation: lane li = column, register r = row (r&3) + 8*(r>>2) + 4*hf: one atomic instruction adds two
-        // contiguous 128-byte row segments
-#pragma unroll
-        for (int mt = 0; mt < TM; ++mt)
-#pragma unroll
-            for (int nt = 0; nt < TN; ++nt) {
-                const int col = j0 + wc * (BN / 2) + nt * 32 + li;
-                if (col >= g.J) continue;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = i0 + wr * (BM / 2) + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hf;
-                    if (row < g.I) atomicAdd(Cb + (int64_t)row * g.ldc + col, g.alpha * acc[mt][nt][r]);
-                }
-            }
-        return;
-    }
-    // ---- epilogue: lane (li, hf) holds row i = tile_row + li and columns j = tile_col + 8q + 4hf + {0..3} in regs 4q..4q+3
-    const bool atomic = false;
-#pragma unroll
-    for (int mt = 0; mt < TM; ++mt) {
-        const int row = i0 + wr * (BM / 2) + mt * 32 + li;
-        if (row >= g.I) continue;
-#pragma unroll
-        for (int nt = 0; nt < TN; ++nt)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int col = j0 + wc * (BN / 2) + nt * 32 + 8 * q + 4 * hf;
-                if (col >= g.J) continue;
-                const bool full = col + 3 < g.J;                           // ragged last columns: element-wise
-                float v[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = g.alpha * acc[mt][nt][4 * q + e];
-                if (EPI == BEPI_DSWISH) {
-                    const float* zp = g.Z + (int64_t)row * g.ldz + col;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        if (!full && col + e >= g.J) continue;
-                        const float z = zp[e];
-                        const float sg = sigmoidf_acc(z);
-                        v[e] *= sg * (1.0f + z * (1.0f - sg));
-                        if (g.drop_p > 0.f)
-                            v[e] *= dropout_keep(g.drop_seed, (unsigned long long)row * (unsigned long long)g.J + (unsigned)(col + e),
-                                                 g.drop_p, 1.0f / (1.0f - g.drop_p));
-                    }
-                }
-                int64_t crow = row;
-                if (GATHER == 2) {                                         // class row -> position (b, 2a+pt, 2c+pf) of dh1
-                    const int per = g.pA * g.pC;
-                    const int b = row / per, r = row - b * per;
-                    const int a = r / g.pC, c = r - a * g.pC;
-                    crow = ((int64_t)b * g.cT1 + 2 * a + g.pt) * g.cF1 + 2 * c + g.pf;
-                }
-                float* dst = Cb + crow * g.ldc + col;
-                if (full && !atomic) {
-                    if (g.accumulate) {
-                        const f32x4 o = *reinterpret_cast<const f32x4*>(dst);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] += o[e];
-                    }
-                    *reinterpret_cast<f32x4*>(dst) = f32x4{v[0], v[1], v[2], v[3]};
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        if (col + e >= g.J) continue;
-                        if (atomic) atomicAdd(dst + e, v[e]);
-                        else dst[e] = g.accumulate ? dst[e] + v[e] : v[e];
-                    }
-                }
-            }
-    }
+    if (SPLITK) bwd_epilogue_atomic<BM, BN, TM, TN>(g, Cb, acc, i0, j0, wr, wc, li, hf);
+    else bwd_epilogue_rows<BM, BN, EPI, GATHER, TM, TN>(g, Cb, acc, i0, j0, wr, wc, li, hf);
 }
 
 template <int BM, int BN, bool AROW, bool BROW, int EPI, int GATHER = 0>

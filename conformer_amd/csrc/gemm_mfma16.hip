@@ -1,9 +1,10 @@
-// bf16-MFMA GEMM with fp32 storage: C = epilogue(bf16(A) . bf16(W)^T + bias), fp32 accumulate, fp32 in/out.
+// 16-bit-MFMA GEMM with fp32 storage: C = epilogue(r16(A) . r16(W)^T + bias), fp32 accumulate, fp32 in/out, where r16
+// rounds to bfloat16 (CFM_PREC_BF16) or IEEE half (CFM_PREC_FP16: the reference's own AMP dtype, train.py:6,232).
 //
-// This is the arithmetic torch.autocast(bfloat16) gives nn.Linear / Conv (inputs rounded to bf16, fp32 accumulation;
-// SURVEY.md Appendix D) and what the reference's train.py runs under AMP (train.py:232).  Operands stay fp32 in HBM --
-// LayerNorm, residual stream, softmax and every epilogue keep fp32 -- and are rounded to bf16 (v_cvt_pk_bf16_f32, RNE)
-// on their way into LDS, so no bf16 copies of activations or weights ever exist.
+// This is the arithmetic torch.autocast gives nn.Linear / Conv (inputs rounded to the 16-bit type, fp32 accumulation;
+// SURVEY.md Appendix D).  Operands stay fp32 in HBM -- LayerNorm, residual stream, softmax and every epilogue keep fp32
+// (so results are never rounded to 16 bits, unlike autocast's) -- and are rounded (RNE) on their way into LDS, so no
+// 16-bit copies of activations or weights ever exist.
 // v_mfma_f32_32x32x16_bf16 runs at 16x the fp32 MFMA rate: the kernel is bound by the fp32 operand stream
 // (L2 -> LDS), not by the matrix pipe, so the staging is built for bytes: K-tile 64 (each row of a tile is 256
 // contiguous bytes = two full cache lines, 16 lanes x 16 B), registers -> bf16 -> LDS rows of 144 B (conflict-free
@@ -13,24 +14,17 @@
 
 namespace {
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ bf16x4 to_bf16x4(const f32x4 v) {
-    bf16x4 r;
-    r[0] = (__bf16)v.x; r[1] = (__bf16)v.y; r[2] = (__bf16)v.z; r[3] = (__bf16)v.w;
-    return r;
-}
-
-template <int BM, int BN, int EPI, bool CONV>
-__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmArgs g) {
+template <typename T16, int BM, int BN, int EPI, bool CONV>
+__global__ __launch_bounds__(256, 2) void gemm_mfma16_kernel(const GemmArgs g) {
+    using x8 = typename Lowp<T16>::x8;
+    using x4 = typename Lowp<T16>::x4;
     constexpr int TM = BM / 64, TN = BN / 64, BK = 64;
     constexpr int ROWB = 72;                                  // LDS row in bf16 elements: 64 + 8 pad = 144 B
     constexpr int NA = BM / 16, NB = BN / 16;                 // float4 loads per thread per K-tile (rows / 16 passes)
     static_assert(EPI != EPI_GLU || TN == 2, "GLU keeps value and gate tiles in one wave");
-    __shared__ __attribute__((aligned(16))) __bf16 lds[2 * (BM + BN) * ROWB];
-    __bf16* As = lds;                     // [2][BM][ROWB]
-    __bf16* Bs = lds + 2 * BM * ROWB;     // [2][BN][ROWB]
+    __shared__ __attribute__((aligned(16))) T16 lds[2 * (BM + BN) * ROWB];
+    T16* As = lds;                     // [2][BM][ROWB]
+    T16* Bs = lds + 2 * BM * ROWB;     // [2][BN][ROWB]
 
     const unsigned nwg = g.tiles_m * g.tiles_n;
     const unsigned tile = xcd_remap(blockIdx.x, nwg);
@@ -65,10 +59,10 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmArgs g) {
     auto store_tile = [&](int buf) {
 #pragma unroll
         for (int p = 0; p < NA; ++p)
-            *reinterpret_cast<bf16x4*>(As + (buf * BM + srow + 16 * p) * ROWB + sch * 4) = to_bf16x4(ra[p]);
+            *reinterpret_cast<x4*>(As + (buf * BM + srow + 16 * p) * ROWB + sch * 4) = Lowp<T16>::cvt4(ra[p]);
 #pragma unroll
         for (int p = 0; p < NB; ++p)
-            *reinterpret_cast<bf16x4*>(Bs + (buf * BN + srow + 16 * p) * ROWB + sch * 4) = to_bf16x4(rb[p]);
+            *reinterpret_cast<x4*>(Bs + (buf * BN + srow + 16 * p) * ROWB + sch * 4) = Lowp<T16>::cvt4(rb[p]);
     };
 
     f32x16 acc[TM][TN];
@@ -91,18 +85,18 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmArgs g) {
         if (more) load_tile(kt + 1);
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            bf16x8 fa[TM], fb[TN];
+            x8 fa[TM], fb[TN];
 #pragma unroll
             for (int t = 0; t < TM; ++t)
-                fa[t] = *reinterpret_cast<const bf16x8*>(As + (cur * BM + a_row + 32 * t) * ROWB + 16 * s + 8 * hf);
+                fa[t] = *reinterpret_cast<const x8*>(As + (cur * BM + a_row + 32 * t) * ROWB + 16 * s + 8 * hf);
 #pragma unroll
             for (int t = 0; t < TN; ++t)
-                fb[t] = *reinterpret_cast<const bf16x8*>(Bs + (cur * BN + b_row + 32 * t) * ROWB + 16 * s + 8 * hf);
+                fb[t] = *reinterpret_cast<const x8*>(Bs + (cur * BN + b_row + 32 * t) * ROWB + 16 * s + 8 * hf);
 #pragma unroll
             for (int mt = 0; mt < TM; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < TN; ++nt)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[nt], fa[mt], acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = Lowp<T16>::mfma(fb[nt], fa[mt], acc[mt][nt]);
         }
         if (more) store_tile(cur ^ 1);
         __syncthreads();
@@ -110,63 +104,72 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmArgs g) {
     gemm_epilogue<BM, BN, EPI, TM, TN>(g, acc, m0, n0, wr, wc, li, hf);
 }
 
-template <int BM, int BN, int EPI, bool CONV>
+template <typename T16, int BM, int BN, int EPI, bool CONV>
 int launch_cfg(GemmArgs g, hipStream_t s) {
     const int ncols = EPI == EPI_GLU ? g.n_out : g.N;
     const int bn = EPI == EPI_GLU ? BN / 2 : BN;
     g.tiles_m = (unsigned)((g.M + BM - 1) / BM);
     g.tiles_n = (unsigned)((ncols + bn - 1) / bn);
-    hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, EPI, CONV>), dim3(g.tiles_m * g.tiles_n), dim3(256), 0, s, g);
+    hipLaunchKernelGGL((gemm_mfma16_kernel<T16, BM, BN, EPI, CONV>), dim3(g.tiles_m * g.tiles_n), dim3(256), 0, s, g);
     return cfm_launch_status();
 }
 
-template <int EPI, bool CONV>
-int launch(const GemmArgs& g, hipStream_t s) {
+template <typename T16, int EPI, bool CONV>
+int launch_t(const GemmArgs& g, hipStream_t s) {
     const int ncols = EPI == EPI_GLU ? g.n_out : g.N;
     const int bn = EPI == EPI_GLU ? 64 : 128;
     const int64_t t128 = ((g.M + 127) / 128) * ((ncols + bn - 1) / bn);
     if constexpr (EPI == EPI_GLU) {
-        return t128 >= 512 ? launch_cfg<128, 128, EPI, CONV>(g, s) : launch_cfg<64, 128, EPI, CONV>(g, s);
+        return t128 >= 512 ? launch_cfg<T16, 128, 128, EPI, CONV>(g, s) : launch_cfg<T16, 64, 128, EPI, CONV>(g, s);
     } else {
-        return t128 >= 512 ? launch_cfg<128, 128, EPI, CONV>(g, s) : launch_cfg<64, 64, EPI, CONV>(g, s);
+        return t128 >= 512 ? launch_cfg<T16, 128, 128, EPI, CONV>(g, s) : launch_cfg<T16, 64, 64, EPI, CONV>(g, s);
     }
+}
+
+template <int EPI, bool CONV>
+int launch(int prec, const GemmArgs& g, hipStream_t s) {
+    if (prec == CFM_PREC_BF16) return launch_t<__bf16, EPI, CONV>(g, s);
+    if (prec == CFM_PREC_FP16) return launch_t<_Float16, EPI, CONV>(g, s);
+    return CFM_ERR_UNSUPPORTED;
 }
 
 }  // namespace
 
-// epi: 0 bias | 1 bias+swish | 2 bias+relu | 3 bias+GLU (N = n_out columns of C, W has 2*n_out rows) | 4 alpha*y + R.
-// Same layouts and argument rules as the fp32 entry points of the forward section; results differ from them by the bf16
-// rounding of A and W only (<= 2^-9 relative per operand).
-extern "C" int cfm_gemm_bf16mfma_f32(int epi, const float* A, const float* W, const float* bias, const float* R_or_null,
-                                     float alpha, float* C, int64_t M, int N, int K, int64_t lda, int64_t ldr,
-                                     int64_t ldc, cfm_stream_t stream) {
+// prec: CFM_PREC_BF16 | CFM_PREC_FP16.  epi: 0 bias | 1 bias+swish | 2 bias+relu | 3 bias+GLU (N = n_out columns of C,
+// W has 2*n_out rows) | 4 alpha*y + R.  Same layouts and argument rules as the fp32 entry points (cfm_gemm_train_f32 for
+// Z_or_null / drop_p / drop_seed); results differ from them by the 16-bit rounding of A and W only.
+extern "C" int cfm_gemm_mfma16_f32(int prec, int epi, const float* A, const float* W, const float* bias,
+                                   const float* R_or_null, float alpha, float* C, float* Z_or_null, int64_t M, int N, int K,
+                                   int64_t lda, int64_t ldr, int64_t ldc, float drop_p, uint64_t drop_seed,
+                                   cfm_stream_t stream) {
     CFM_REQUIRE(A && W && bias && C, CFM_ERR_NULL);
     CFM_REQUIRE(M > 0 && N > 0 && K > 0 && (K & 3) == 0 && (lda & 3) == 0 && lda >= K && ldc >= N, CFM_ERR_BAD_SHAPE);
+    CFM_REQUIRE(drop_p >= 0.f && drop_p < 1.f, CFM_ERR_BAD_SHAPE);
     CFM_REQUIRE(CFM_ALIGNED16(A) && CFM_ALIGNED16(W), CFM_ERR_ALIGN);
     GemmArgs g{};
     g.A = A; g.W = W; g.bias = bias; g.R = R_or_null; g.C = C; g.M = M; g.K = K; g.lda = lda; g.ldr = ldr; g.ldc = ldc;
-    g.alpha = alpha;
+    g.alpha = alpha; g.Zsave = Z_or_null; g.drop_p = drop_p; g.drop_seed = drop_seed;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (epi == EPI_GLU) {
         g.n_out = N; g.N = 2 * N;
-        return launch<EPI_GLU, false>(g, s);
+        return launch<EPI_GLU, false>(prec, g, s);
     }
     g.N = N;
     switch (epi) {
-        case EPI_BIAS: return launch<EPI_BIAS, false>(g, s);
-        case EPI_SWISH: return launch<EPI_SWISH, false>(g, s);
-        case EPI_RELU: return launch<EPI_RELU, false>(g, s);
+        case EPI_BIAS: return launch<EPI_BIAS, false>(prec, g, s);
+        case EPI_SWISH: return launch<EPI_SWISH, false>(prec, g, s);
+        case EPI_RELU: return launch<EPI_RELU, false>(prec, g, s);
         case EPI_RESID:
             CFM_REQUIRE(R_or_null != nullptr, CFM_ERR_NULL);
             CFM_REQUIRE(ldr >= N, CFM_ERR_BAD_SHAPE);
-            return launch<EPI_RESID, false>(g, s);
+            return launch<EPI_RESID, false>(prec, g, s);
         default: return CFM_ERR_UNSUPPORTED;
     }
 }
 
-// bf16-MFMA form of cfm_subsample_conv2_relu_f32 (C % 64 == 0).
-extern "C" int cfm_subsample_conv2_relu_bf16mfma_f32(const float* h1, const float* w2p, const float* b2, float* h2, int B,
-                                                     int F1, int T1, int C, cfm_stream_t stream) {
+// 16-bit-MFMA form of cfm_subsample_conv2_relu_f32 (C % 64 == 0).
+extern "C" int cfm_subsample_conv2_relu_mfma16_f32(int prec, const float* h1, const float* w2p, const float* b2, float* h2,
+                                                   int B, int F1, int T1, int C, cfm_stream_t stream) {
     CFM_REQUIRE(h1 && w2p && b2 && h2, CFM_ERR_NULL);
     CFM_REQUIRE(B > 0 && F1 >= 3 && T1 >= 3 && C > 0, CFM_ERR_BAD_SHAPE);
     CFM_REQUIRE(C % 64 == 0, CFM_ERR_UNSUPPORTED);
@@ -175,5 +178,5 @@ extern "C" int cfm_subsample_conv2_relu_bf16mfma_f32(const float* h1, const floa
     g.cT1 = T1; g.cF1 = F1; g.cC = C; g.cT2 = (T1 - 1) / 2; g.cF2 = (F1 - 1) / 2;
     g.A = h1; g.W = w2p; g.bias = b2; g.C = h2;
     g.M = (int64_t)B * g.cT2 * g.cF2; g.N = C; g.K = 9 * C; g.lda = 0; g.ldc = C; g.alpha = 1.f;
-    return launch<EPI_RELU, true>(g, static_cast<hipStream_t>(stream));
+    return launch<EPI_RELU, true>(prec, g, static_cast<hipStream_t>(stream));
 }

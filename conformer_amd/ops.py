@@ -30,22 +30,53 @@ def _p(t: Optional[torch.Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
 
 
-def bf16_mfma_active() -> bool:
-    """True inside `torch.autocast("cuda", dtype=torch.bfloat16)`: the dense GEMMs then round their operands to bf16 and
-    run on the bf16 matrix pipe (fp32 accumulate, fp32 tensors) -- the arithmetic autocast gives nn.Linear / Conv.
-    fp16 autocast (the reference's `--fp16 1`, train.py:217) has no kernel path and is refused."""
+PREC_F32, PREC_BF16, PREC_FP16 = 0, 1, 2          # CFM_PREC_* of include/conformer_hip.h (0 = the fp32 MFMA path)
+_forced_prec: Optional[int] = None
+
+
+def mfma16_prec() -> int:
+    """Matrix-pipe precision of the dense GEMMs: inside `torch.autocast("cuda")` they round their operands to the autocast
+    dtype (bf16, or fp16 as the reference's `--fp16 1` does, train.py:6,217,232) and run on the 16-bit matrix pipe with
+    fp32 accumulation and fp32 tensors -- the arithmetic autocast gives nn.Linear / Conv.  Backward passes run under
+    `precision(...)` with the value their forward saw (autocast is not active inside autograd's backward)."""
+    if _forced_prec is not None:
+        return _forced_prec
     if not torch.is_autocast_enabled("cuda"):
-        return False
+        return PREC_F32
     dt = torch.get_autocast_dtype("cuda")
     if dt == torch.bfloat16:
-        return True
-    raise _lib.ConformerHipError(f"autocast dtype {dt} is not supported by the gfx950 path (use torch.bfloat16 or fp32)")
+        return PREC_BF16
+    if dt == torch.float16:
+        return PREC_FP16
+    raise _lib.ConformerHipError(f"autocast dtype {dt} is not supported by the gfx950 path")
 
 
-def _bf16_gemm(epi: int, a, w2, b, c, m, n, k, res=None, alpha: float = 1.0):
-    st = _lib.load().cfm_gemm_bf16mfma_f32(epi, a.data_ptr(), w2.data_ptr(), b.data_ptr(), _p(res), alpha, c.data_ptr(),
-                                           m, n, k, k, n, n, _stream())
-    _lib.check(st, "cfm_gemm_bf16mfma_f32")
+class precision:
+    """Context manager pinning mfma16_prec() (used by the autograd Functions around their backward)."""
+
+    def __init__(self, prec: int) -> None:
+        self.prec, self.prev = prec, None
+
+    def __enter__(self):
+        global _forced_prec
+        self.prev, _forced_prec = _forced_prec, self.prec
+        return self
+
+    def __exit__(self, *exc):
+        global _forced_prec
+        _forced_prec = self.prev
+        return False
+
+
+def bf16_mfma_active() -> bool:
+    return mfma16_prec() == PREC_BF16
+
+
+def _mfma16_gemm(prec: int, epi: int, a, w2, b, c, m, n, k, res=None, alpha: float = 1.0, z=None, drop_p: float = 0.0,
+                 seed: int = 0):
+    st = _lib.load().cfm_gemm_mfma16_f32(prec, epi, a.data_ptr(), w2.data_ptr(), b.data_ptr(), _p(res), alpha, c.data_ptr(),
+                                         _p(z), m, n, k, k, n, n, float(drop_p), int(seed), _stream())
+    _lib.check(st, "cfm_gemm_mfma16_f32")
     return c
 
 
@@ -79,8 +110,9 @@ def linear(a, w, b, act: str = "none") -> torch.Tensor:
     """y = act(a @ w.T + b); act in {none, swish, relu}."""
     a, w2, b, m, n, k = _gemm_common(a, w, b)
     c = torch.empty(*a.shape[:-1], n, device=a.device, dtype=a.dtype)
-    if bf16_mfma_active():
-        return _bf16_gemm({"none": 0, "swish": 1, "relu": 2}[act], a, w2, b, c, m, n, k)
+    prec = mfma16_prec()
+    if prec:
+        return _mfma16_gemm(prec, {"none": 0, "swish": 1, "relu": 2}[act], a, w2, b, c, m, n, k)
     fn = {"none": "cfm_gemm_bias_f32", "swish": "cfm_gemm_bias_swish_f32", "relu": "cfm_gemm_bias_relu_f32"}[act]
     st = getattr(_lib.load(), fn)(a.data_ptr(), w2.data_ptr(), b.data_ptr(), c.data_ptr(), m, n, k, k, n, _stream())
     _lib.check(st, fn)
@@ -92,8 +124,9 @@ def linear_glu(a, w, b) -> torch.Tensor:
     a, w2, b, m, n2, k = _gemm_common(a, w, b)
     n = n2 // 2
     c = torch.empty(*a.shape[:-1], n, device=a.device, dtype=a.dtype)
-    if bf16_mfma_active():
-        return _bf16_gemm(3, a, w2, b, c, m, n, k)
+    prec = mfma16_prec()
+    if prec:
+        return _mfma16_gemm(prec, 3, a, w2, b, c, m, n, k)
     st = _lib.load().cfm_gemm_bias_glu_f32(a.data_ptr(), w2.data_ptr(), b.data_ptr(), c.data_ptr(), m, n, k, k, n,
                                            _stream())
     _lib.check(st, "cfm_gemm_bias_glu_f32")
@@ -105,8 +138,9 @@ def linear_residual(a, w, b, res: torch.Tensor, alpha: float = 1.0) -> torch.Ten
     a, w2, b, m, n, k = _gemm_common(a, w, b)
     res = _req(res, "residual")
     c = torch.empty(*a.shape[:-1], n, device=a.device, dtype=a.dtype)
-    if bf16_mfma_active():
-        return _bf16_gemm(4, a, w2, b, c, m, n, k, res, alpha)
+    prec = mfma16_prec()
+    if prec:
+        return _mfma16_gemm(prec, 4, a, w2, b, c, m, n, k, res, alpha)
     st = _lib.load().cfm_gemm_bias_residual_f32(a.data_ptr(), w2.data_ptr(), b.data_ptr(), res.data_ptr(), alpha,
                                                 c.data_ptr(), m, n, k, k, n, n, _stream())
     _lib.check(st, "cfm_gemm_bias_residual_f32")
@@ -186,13 +220,18 @@ def subsample_stem(x: torch.Tensor, w1, b1, w2p, b2) -> torch.Tensor:
     _lib.check(lib.cfm_subsample_conv1_relu_f32(x.data_ptr(), w1.data_ptr(), b1.data_ptr(), h1.data_ptr(), B, F, T, C,
                                                 _stream()), "cfm_subsample_conv1_relu_f32")
     h2 = torch.empty(B, T2, F2 * C, device=x.device, dtype=x.dtype)
-    if bf16_mfma_active() and C % 64 == 0:
-        _lib.check(lib.cfm_subsample_conv2_relu_bf16mfma_f32(h1.data_ptr(), w2p.data_ptr(), b2.data_ptr(), h2.data_ptr(), B,
-                                                             F1, T1, C, _stream()), "cfm_subsample_conv2_relu_bf16mfma_f32")
-        return h2
-    _lib.check(lib.cfm_subsample_conv2_relu_f32(h1.data_ptr(), w2p.data_ptr(), b2.data_ptr(), h2.data_ptr(), B, F1, T1,
-                                                C, _stream()), "cfm_subsample_conv2_relu_f32")
+    _conv2_relu(lib, h1, w2p, b2, h2, B, F1, T1, C)
     return h2
+
+
+def _conv2_relu(lib, h1, w2p, b2, h2, B, F1, T1, C):
+    prec = mfma16_prec()
+    if prec and C % 64 == 0:
+        _lib.check(lib.cfm_subsample_conv2_relu_mfma16_f32(prec, h1.data_ptr(), w2p.data_ptr(), b2.data_ptr(), h2.data_ptr(),
+                                                           B, F1, T1, C, _stream()), "cfm_subsample_conv2_relu_mfma16_f32")
+    else:
+        _lib.check(lib.cfm_subsample_conv2_relu_f32(h1.data_ptr(), w2p.data_ptr(), b2.data_ptr(), h2.data_ptr(), B, F1, T1,
+                                                    C, _stream()), "cfm_subsample_conv2_relu_f32")
 
 
 # ======================================================================================================
@@ -270,6 +309,10 @@ def linear_train(epi: str, a, w, b, *, residual=None, alpha: float = 1.0, drop_p
     code = {"bias": 0, "swish": 1, "residual": 4}[epi]
     if residual is not None:
         residual = _req(residual, "residual")
+    prec = mfma16_prec()
+    if prec:
+        _mfma16_gemm(prec, code, a, w2, b, c, m, n, k, residual, alpha, z, drop_p, seed)
+        return (c, z) if save_z else c
     st = _lib.load().cfm_gemm_train_f32(code, a.data_ptr(), w2.data_ptr(), b.data_ptr(), _p(residual), alpha, c.data_ptr(),
                                         _p(z), m, n, k, k, n, n, float(drop_p), int(seed), _stream())
     _lib.check(st, "cfm_gemm_train_f32")
@@ -321,21 +364,24 @@ def colsum(x2d, alpha: float = 1.0, rows=None, cols=None, ld=None, out=None):
 def gemm_bwd(A, a_col: bool, B, b_col: bool, I: int, J: int, Kc: int, *, alpha: float = 1.0, Z=None, out=None,
              lda=None, ldb=None, ldc=None, ldz=None, allow_split: bool = False, accumulate: bool = False,
              nbatch: int = 1, nb1: int = 1, sa=(0, 0), sb=(0, 0), sc=(0, 0), a_ptr=None, b_ptr=None, c_ptr=None,
-             drop_p: float = 0.0, drop_seed: int = 0):
+             drop_p: float = 0.0, drop_seed: int = 0, prec: int = 0):
     """C (I,J) (+)= alpha * sum_k A(i,k) B(j,k) [* swish'(Z)]; *_col selects the contraction-major layout.
-    Pointers default to the tensors' data_ptr(); explicit *_ptr / ld* let callers address sub-blocks (head slices)."""
+    Pointers default to the tensors' data_ptr(); explicit *_ptr / ld* let callers address sub-blocks (head slices).
+    prec: PREC_F32 (fp32 MFMA) | PREC_BF16 | PREC_FP16 (operands rounded while staged, fp32 accumulate)."""
     lda = A.stride(-2) if lda is None else lda
     ldb = B.stride(-2) if ldb is None else ldb
     if out is None:
         out = (torch.zeros if allow_split else torch.empty)(I, J, device=A.device, dtype=A.dtype)
     ldc = out.stride(-2) if ldc is None else ldc
     ldz = 0 if Z is None else (Z.stride(-2) if ldz is None else ldz)
-    st = _lib.load().cfm_gemm_bwd_batched_f32(
-        A.data_ptr() if a_ptr is None else a_ptr, int(a_col), lda, B.data_ptr() if b_ptr is None else b_ptr, int(b_col),
-        ldb, _p(Z), ldz, alpha, out.data_ptr() if c_ptr is None else c_ptr, ldc, I, J, Kc, int(allow_split),
-        int(accumulate), nbatch, nb1, sa[0], sa[1], sb[0], sb[1], sc[0], sc[1], float(drop_p), int(drop_seed),
-        _stream())
-    _lib.check(st, "cfm_gemm_bwd_batched_f32")
+    args = (A.data_ptr() if a_ptr is None else a_ptr, int(a_col), lda, B.data_ptr() if b_ptr is None else b_ptr, int(b_col),
+            ldb, _p(Z), ldz, alpha, out.data_ptr() if c_ptr is None else c_ptr, ldc, I, J, Kc, int(allow_split),
+            int(accumulate), nbatch, nb1, sa[0], sa[1], sb[0], sb[1], sc[0], sc[1], float(drop_p), int(drop_seed),
+            _stream())
+    if prec:
+        _lib.check(_lib.load().cfm_gemm_bwd_batched_mfma16_f32(prec, *args), "cfm_gemm_bwd_batched_mfma16_f32")
+    else:
+        _lib.check(_lib.load().cfm_gemm_bwd_batched_f32(*args), "cfm_gemm_bwd_batched_f32")
     return out
 
 
@@ -346,10 +392,11 @@ def linear_bwd(x2d, w, dy2d, *, alpha: float = 1.0, Z=None, need_dx: bool = True
     n = w.shape[0]
     w2 = w.reshape(n, -1)
     dx = None
+    prec = mfma16_prec()
     if need_dx:
-        dx = gemm_bwd(dy2d, False, w2, True, m, k, n, alpha=alpha, Z=Z, drop_p=drop_p, drop_seed=drop_seed)
+        dx = gemm_bwd(dy2d, False, w2, True, m, k, n, alpha=alpha, Z=Z, drop_p=drop_p, drop_seed=drop_seed, prec=prec)
     dw, db = _zeros_split(x2d.device, x2d.dtype, (n, k), (n,))
-    gemm_bwd(dy2d, True, x2d, True, n, k, m, alpha=alpha, allow_split=True, out=dw)
+    gemm_bwd(dy2d, True, x2d, True, n, k, m, alpha=alpha, allow_split=True, out=dw, prec=prec)
     colsum(dy2d, alpha, out=db)
     return dx, dw.view_as(w), db
 
@@ -484,8 +531,7 @@ def subsample_stem_train(x, w1, b1, w2p, b2):
     _lib.check(lib.cfm_subsample_conv1_relu_f32(x.data_ptr(), w1.data_ptr(), b1.data_ptr(), h1.data_ptr(), B, F, T, C,
                                                 _stream()), "cfm_subsample_conv1_relu_f32")
     h2 = torch.empty(B, T2, F2 * C, device=x.device, dtype=x.dtype)
-    _lib.check(lib.cfm_subsample_conv2_relu_f32(h1.data_ptr(), w2p.data_ptr(), b2.data_ptr(), h2.data_ptr(), B, F1, T1,
-                                                C, _stream()), "cfm_subsample_conv2_relu_f32")
+    _conv2_relu(lib, h1, w2p, b2, h2, B, F1, T1, C)
     return h2, h1
 
 
@@ -502,13 +548,22 @@ def subsample_stem_bwd(x, w1, b1, w2, h1, h2, dh2):
                "cfm_relu_bwd_f32")
     dw2p, db2, dw1, db1 = _zeros_split(x.device, x.dtype, (C, 9 * C), (C,), tuple(w1.shape), (C,))
     colsum(dz2.view(-1, C), out=db2)
-    _lib.check(lib.cfm_subsample_conv2_bwd_weight_f32(dz2.data_ptr(), h1.data_ptr(), dw2p.data_ptr(), B, F1, T1, C,
-                                                      _stream()), "cfm_subsample_conv2_bwd_weight_f32")
+    prec = mfma16_prec() if C % 64 == 0 else 0
+    if prec:
+        _lib.check(lib.cfm_subsample_conv2_bwd_weight_mfma16_f32(prec, dz2.data_ptr(), h1.data_ptr(), dw2p.data_ptr(), B, F1,
+                                                                 T1, C, _stream()), "cfm_subsample_conv2_bwd_weight_mfma16_f32")
+    else:
+        _lib.check(lib.cfm_subsample_conv2_bwd_weight_f32(dz2.data_ptr(), h1.data_ptr(), dw2p.data_ptr(), B, F1, T1, C,
+                                                          _stream()), "cfm_subsample_conv2_bwd_weight_f32")
     w2c = torch.empty(9 * C * C, device=x.device, dtype=x.dtype)
     _lib.check(lib.cfm_pack_conv2_weight_t_f32(w2.data_ptr(), w2c.data_ptr(), C, _stream()), "cfm_pack_conv2_weight_t_f32")
     dh1 = torch.empty_like(h1)
-    _lib.check(lib.cfm_subsample_conv2_bwd_input_f32(dz2.data_ptr(), w2c.data_ptr(), dh1.data_ptr(), B, F1, T1, C,
-                                                     _stream()), "cfm_subsample_conv2_bwd_input_f32")
+    if prec:
+        _lib.check(lib.cfm_subsample_conv2_bwd_input_mfma16_f32(prec, dz2.data_ptr(), w2c.data_ptr(), dh1.data_ptr(), B, F1,
+                                                                T1, C, _stream()), "cfm_subsample_conv2_bwd_input_mfma16_f32")
+    else:
+        _lib.check(lib.cfm_subsample_conv2_bwd_input_f32(dz2.data_ptr(), w2c.data_ptr(), dh1.data_ptr(), B, F1, T1, C,
+                                                         _stream()), "cfm_subsample_conv2_bwd_input_f32")
     _lib.check(lib.cfm_subsample_conv1_bwd_f32(x.data_ptr(), w1.data_ptr(), b1.data_ptr(), dh1.data_ptr(), dw1.data_ptr(),
                                                db1.data_ptr(), B, F, T, C, _stream()), "cfm_subsample_conv1_bwd_f32")
     dw2 = dw2p.view(C, 3, 3, C).permute(0, 3, 1, 2).contiguous()        # packed (co,kf,kt,ci) -> (co,ci,kf,kt): tiny glue

@@ -115,15 +115,29 @@ int cfm_subsample_conv2_relu_f32(const float* h1, const float* w2p, const float*
                                  int B, int F1, int T1, int C, cfm_stream_t stream);
 int cfm_pack_linear_weight_f32(const float* wl, float* wlp, int d_out, int C, int F2, cfm_stream_t stream);
 
-/* ---- bf16-MFMA forward GEMMs with fp32 storage (torch.autocast(bfloat16) arithmetic for nn.Linear / Conv,
- *      train.py:232 under AMP): operands are rounded to bf16 on their way into LDS, accumulation
- *      and epilogues are fp32, tensors in HBM stay fp32.  epi: 0 bias | 1 +swish | 2 +relu | 3 +GLU | 4 alpha*y+R;
- *      argument rules as the fp32 entry points (for GLU, N = n_out and W has 2*n_out rows). */
-int cfm_gemm_bf16mfma_f32(int epi, const float* A, const float* W, const float* bias, const float* R_or_null,
-                          float alpha, float* C, int64_t M, int N, int K, int64_t lda, int64_t ldr,
-                          int64_t ldc, cfm_stream_t stream);
-int cfm_subsample_conv2_relu_bf16mfma_f32(const float* h1, const float* w2p, const float* b2, float* h2, int B,
-                                          int F1, int T1, int C, cfm_stream_t stream);
+/* ---- 16-bit-MFMA GEMMs with fp32 storage: the arithmetic torch.autocast gives nn.Linear / Conv (train.py:6,232 runs the
+ *      model under torch.cuda.amp.autocast = fp16; bf16 is the MI355X-preferred variant).  Operands
+ *      are rounded to `prec` on their way into LDS, accumulation and epilogues are fp32, tensors in HBM stay fp32.
+ *      epi: 0 bias | 1 +swish | 2 +relu | 3 +GLU | 4 alpha*y+R; argument rules as the fp32 entry points
+ *      (cfm_gemm_train_f32 for Z_or_null / drop_p / drop_seed; for GLU, N = n_out and W has 2*n_out rows).
+ *      The *_bwd_* entries mirror cfm_gemm_bwd_batched_f32 / cfm_subsample_conv2_bwd_{weight,input}_f32 (the stem
+ *      forms need C % 64 == 0). */
+#define CFM_PREC_BF16 1
+#define CFM_PREC_FP16 2
+int cfm_gemm_mfma16_f32(int prec, int epi, const float* A, const float* W, const float* bias, const float* R_or_null,
+                        float alpha, float* C, float* Z_or_null, int64_t M, int N, int K, int64_t lda, int64_t ldr,
+                        int64_t ldc, float drop_p, uint64_t drop_seed, cfm_stream_t stream);
+int cfm_subsample_conv2_relu_mfma16_f32(int prec, const float* h1, const float* w2p, const float* b2, float* h2, int B,
+                                        int F1, int T1, int C, cfm_stream_t stream);
+int cfm_gemm_bwd_batched_mfma16_f32(int prec, const float* A, int a_col, int64_t lda, const float* B, int b_col,
+                                    int64_t ldb, const float* Z_or_null, int64_t ldz, float alpha, float* C,
+                                    int64_t ldc, int I, int J, int64_t Kc, int allow_split, int accumulate,
+                                    int nbatch, int nb1, int64_t sa0, int64_t sa1, int64_t sb0, int64_t sb1,
+                                    int64_t sc0, int64_t sc1, float drop_p, uint64_t drop_seed, cfm_stream_t stream);
+int cfm_subsample_conv2_bwd_weight_mfma16_f32(int prec, const float* dz2, const float* h1, float* dw2p, int B, int F1,
+                                              int T1, int C, cfm_stream_t stream);
+int cfm_subsample_conv2_bwd_input_mfma16_f32(int prec, const float* dz2, const float* w2c, float* dh1, int B, int F1,
+                                             int T1, int C, cfm_stream_t stream);
 
 /* ---- audio front end (processing/processor.py:53-63,155-158,373-394; processing/augment.py:7-19).
  *      log-mel = reflect_pad -> [frames * window * DFT] as cfm_gemm_bwd_batched_f32 over overlapping rows

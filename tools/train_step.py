@@ -29,6 +29,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--frames", type=int, default=1000)
     ap.add_argument("--optim", choices=["torch", "fused"], default="fused")
+    ap.add_argument("--dtype", choices=["f32", "bf16", "f16"], default="f32",
+                    help="bf16/f16: model under torch.autocast (f16 with GradScaler), as train.py:217,232-243")
     args = ap.parse_args()
     env = parallel.env_from_os()
     torch.cuda.set_device(env.local_rank)
@@ -50,18 +52,24 @@ def main():
     crit = torch.nn.CTCLoss(blank=0, zero_infinity=True)
     last = {}
 
+    amp_dtype = {"f32": None, "bf16": torch.bfloat16, "f16": torch.float16}[args.dtype]
+    scaler = torch.amp.GradScaler("cuda", enabled=args.dtype == "f16")
+
     def step():
-        logits, out_len = ddp(x, lengths)
+        with torch.autocast("cuda", dtype=amp_dtype, enabled=amp_dtype is not None):
+            logits, out_len = ddp(x, lengths)
         loss = crit(logits.float().log_softmax(-1).transpose(0, 1), targets, out_len, tlen)
         opt.zero_grad(set_to_none=True)
-        loss.backward()
-        opt.step()
+        scaler.scale(loss).backward()
+        scaler.unscale_(opt)
+        scaler.step(opt)
+        scaler.update()
         last["loss"] = loss
 
     dt = parallel.timed_steps(step, args.steps, args.warmup, torch.cuda.synchronize, dev)
     if env.is_main:
         ms = dt / args.steps * 1e3
-        print(json.dumps({"what": "Conformer-L training step fwd+CTC+bwd+Adam, fp32, dropout 0, BN train",
+        print(json.dumps({"what": "Conformer-L training step fwd+CTC+bwd+Adam, dropout 0, BN train", "dtype": args.dtype,
                           "optimizer": args.optim, "n_gpus": env.world, "per_gpu_batch": args.batch, "mel_frames": args.frames,
                           "ms_per_step": ms, "frames_per_sec": env.world * args.batch * args.frames * args.steps / dt,
                           "loss": float(last["loss"]), "max_mem_gib": torch.cuda.max_memory_allocated() / 2 ** 30}),
