@@ -51,37 +51,76 @@ __global__ __launch_bounds__(256) void layernorm_bwd_dx_kernel(
 // ---- LayerNorm backward, parameter gradients; also the generic column-sum (MODE 0) --------------------------------
 //   MODE 0: out0[c] += alpha * sum_r X[r][c]
 //   MODE 1: out0[c] (dgamma) += sum_r dy*xhat ; out1[c] (dbeta) += sum_r dy       (X = x, Y = dy)
-// block = 64 columns x 4 row-lanes; each block walks `rows_per_block` rows; LDS combine; one atomic per column per block.
-template <int MODE>
+// block = 64 columns (16 lanes x float4) x 16 row-lanes; each block walks `rows_per_block` rows with 16-byte loads; LDS
+// combine; one atomic per column per block.  VEC = false: scalar loads for unaligned / ragged column counts.
+template <int MODE, bool VEC>
 __global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict__ X, const float* __restrict__ Y,
                                                         const float* __restrict__ mean, const float* __restrict__ rstd,
                                                         int64_t ld, int64_t rows, int cols, int rows_per_block,
                                                         float alpha, float* __restrict__ out0, float* __restrict__ out1) {
-    __shared__ float red[2][4][64];
-    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + cx;
+    constexpr int RL = VEC ? 16 : 4;                       // row lanes
+    __shared__ float red[2][RL][64];
     const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
     const int64_t r1 = min(rows, r0 + rows_per_block);
-    float a0 = 0.f, a1 = 0.f;
-    if (c < cols) {
-        for (int64_t r = r0 + ry; r < r1; r += 4) {
-            if (MODE == 0) {
-                a0 += X[r * ld + c];
-            } else {
-                const float dyv = Y[r * ld + c];
-                a0 += dyv * (X[r * ld + c] - mean[r]) * rstd[r];
-                a1 += dyv;
+    if (VEC) {
+        const int cq = threadIdx.x & 15, ry = threadIdx.x >> 4;
+        const int c = blockIdx.x * 64 + cq * 4;
+        f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+        if (c < cols) {
+#pragma unroll 4
+            for (int64_t r = r0 + ry; r < r1; r += RL) {
+                if (MODE == 0) {
+                    a0 = a0 + *reinterpret_cast<const f32x4*>(X + r * ld + c);
+                } else {
+                    const f32x4 dyv = *reinterpret_cast<const f32x4*>(Y + r * ld + c);
+                    const f32x4 xv = *reinterpret_cast<const f32x4*>(X + r * ld + c);
+                    const float mu = mean[r], rs = rstd[r];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) a0[e] += dyv[e] * (xv[e] - mu) * rs;
+                    a1 = a1 + dyv;
+                }
             }
         }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { red[0][ry][cq * 4 + e] = a0[e]; red[1][ry][cq * 4 + e] = a1[e]; }
+    } else {
+        const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+        const int c = blockIdx.x * 64 + cx;
+        float a0 = 0.f, a1 = 0.f;
+        if (c < cols) {
+            for (int64_t r = r0 + ry; r < r1; r += RL) {
+                if (MODE == 0) {
+                    a0 += X[r * ld + c];
+                } else {
+                    const float dyv = Y[r * ld + c];
+                    a0 += dyv * (X[r * ld + c] - mean[r]) * rstd[r];
+                    a1 += dyv;
+                }
+            }
+        }
+        red[0][ry][cx] = a0;
+        red[1][ry][cx] = a1;
     }
-    red[0][ry][cx] = a0;
-    red[1][ry][cx] = a1;
     __syncthreads();
-    if (ry == 0 && c < cols) {
-        const float s0 = (red[0][0][cx] + red[0][1][cx]) + (red[0][2][cx] + red[0][3][cx]);
-        atomicAdd(out0 + c, (MODE == 0 ? alpha : 1.0f) * s0);
-        if (MODE == 1) atomicAdd(out1 + c, (red[1][0][cx] + red[1][1][cx]) + (red[1][2][cx] + red[1][3][cx]));
+    const int cx = threadIdx.x & 63, which = threadIdx.x >> 6;          // wave 0 -> out0, wave 1 -> out1
+    const int c = blockIdx.x * 64 + cx;
+    if (which < (MODE == 1 ? 2 : 1) && c < cols) {
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < RL; ++j) s += red[which][j][cx];
+        if (which == 0) atomicAdd(out0 + c, (MODE == 0 ? alpha : 1.0f) * s);
+        else atomicAdd(out1 + c, s);
     }
+}
+
+template <int MODE>
+void colreduce_launch(const float* X, const float* Y, const float* mean, const float* rstd, int64_t ld, int64_t rows, int cols,
+                      float alpha, float* out0, float* out1, hipStream_t s) {
+    const bool vec = (cols & 3) == 0 && (ld & 3) == 0 && CFM_ALIGNED16(X) && (!Y || CFM_ALIGNED16(Y));
+    const int rpb = vec ? 64 : 128;
+    const dim3 grid((unsigned)((cols + 63) / 64), (unsigned)((rows + rpb - 1) / rpb));
+    if (vec) hipLaunchKernelGGL((colreduce_kernel<MODE, true>), grid, dim3(256), 0, s, X, Y, mean, rstd, ld, rows, cols, rpb, alpha, out0, out1);
+    else hipLaunchKernelGGL((colreduce_kernel<MODE, false>), grid, dim3(256), 0, s, X, Y, mean, rstd, ld, rows, cols, rpb, alpha, out0, out1);
 }
 
 // ---- GLU forward on a stored pre-activation (training path: z is kept for the backward) --------------------------------
@@ -142,7 +181,8 @@ __global__ __launch_bounds__(256) void dwconv_bn_swish_bwd_kernel(
     int T, int C, int seg_len, float inv_n /* 0 = fixed statistics */) {
     constexpr int HALF = (K - 1) / 2;
     constexpr int NRED = PASS == 0 ? 2 : K + 1;
-    __shared__ float red[4][NRED][64];
+    __shared__ float red[4][NRED][65];                 // 65: the tap-major read-out below walks q at fixed channel
+    __shared__ float taps[64 * K];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + lane;
     const int b = blockIdx.z;
@@ -150,8 +190,9 @@ __global__ __launch_bounds__(256) void dwconv_bn_swish_bwd_kernel(
     const bool cok = c < C;
     const int cc = cok ? c : C - 1;
     float wr[K], dwacc[K];
+    load_taps<K>(w, blockIdx.x * 64, C, taps, wr);
 #pragma unroll
-    for (int j = 0; j < K; ++j) { wr[j] = w[(int64_t)cc * K + j]; dwacc[j] = 0.f; }
+    for (int j = 0; j < K; ++j) dwacc[j] = 0.f;
     const float inv = 1.0f / sqrtf(bn_var[cc] + eps);
     const float mu = bn_mean[cc], ga = bn_w[cc], be = bn_b[cc], bi = bias[cc];
     const float k1 = PASS == 1 ? ga * inv * inv_n * dbeta[cc] : 0.f;      // sums are complete: pass A has finished
@@ -161,12 +202,9 @@ __global__ __launch_bounds__(256) void dwconv_bn_swish_bwd_kernel(
     float* dcb = dc + (int64_t)b * T * C + cc;
     float s_du = 0.f, s_dux = 0.f, s_dc = 0.f;
     for (int t0 = seg0 + wave * TT; t0 < seg1; t0 += 4 * TT) {
-        float gwin[TT + K - 1];
-#pragma unroll
-        for (int tau = 0; tau < TT + K - 1; ++tau) {
-            const int t = t0 + tau - HALF;
-            gwin[tau] = (t >= 0 && t < T) ? gb[(int64_t)t * C] : 0.f;
-        }
+        float gwin[TT + K - 1], dwin[TT];                 // dwin: dy (pass A) or dc (pass B) of the chunk's TT frames
+        load_window<TT + K - 1>(gb, t0 - HALF, T, C, gwin);
+        load_window<TT>(PASS == 0 ? dyb : dcb, t0, seg1, C, dwin);
 #pragma unroll
         for (int o = 0; o < TT; ++o) {
             const int t = t0 + o;
@@ -178,12 +216,12 @@ __global__ __launch_bounds__(256) void dwconv_bn_swish_bwd_kernel(
             if (PASS == 0) {
                 const float u = xh * ga + be;
                 const float sg = sigmoidf_acc(u);
-                const float dyv = tok ? dyb[(int64_t)t * C] : 0.f;
+                const float dyv = dwin[o];
                 const float du = dyv * sg * (1.0f + u * (1.0f - sg));
                 if (tok && cok) dcb[(int64_t)t * C] = du * inv * ga;
                 s_du += du; s_dux += du * xh;
             } else {
-                float dcv = tok ? dcb[(int64_t)t * C] : 0.f;
+                float dcv = dwin[o];
                 if (tok) dcv -= k1 + xh * k2;
                 if (tok && cok && inv_n != 0.f) dcb[(int64_t)t * C] = dcv;
                 s_dc += dcv;
@@ -199,13 +237,21 @@ __global__ __launch_bounds__(256) void dwconv_bn_swish_bwd_kernel(
         for (int j = 0; j < K; ++j) red[wave][j][lane] = dwacc[j];
     }
     __syncthreads();
-    // NRED x 64 sums, 256 threads: thread -> (quantity q = tid/64 + 4*i, channel lane)
-    for (int q = wave; q < NRED; q += 4) {
-        const float v = (red[0][q][lane] + red[1][q][lane]) + (red[2][q][lane] + red[3][q][lane]);
-        if (!cok) continue;
-        if (PASS == 0) atomicAdd((q == 0 ? dbeta : dgamma) + c, v);
-        else if (q == K) atomicAdd(dbias + c, v);
-        else atomicAdd(dw + (int64_t)c * K + q, v);
+    if (PASS == 0) {
+        if (wave < 2 && cok)
+            atomicAdd((wave == 0 ? dbeta : dgamma) + c,
+                      (red[0][wave][lane] + red[1][wave][lane]) + (red[2][wave][lane] + red[3][wave][lane]));
+    } else {
+        // dw is (C,K): the 64 x K gradients of this workgroup are one contiguous run -- walk it in memory order so every
+        // atomic instruction covers whole 256-byte segments (scattered lanes run ~17x slower, MI355X_MICROARCH.md)
+        const int64_t base = (int64_t)blockIdx.x * 64 * K, lim = (int64_t)C * K;
+        for (int f = threadIdx.x; f < 64 * K; f += 256) {
+            const int cl = f / K, q = f - cl * K;
+            if (base + f < lim)
+                atomicAdd(dw + base + f, (red[0][q][cl] + red[1][q][cl]) + (red[2][q][cl] + red[3][q][cl]));
+        }
+        if (wave == 0 && cok)
+            atomicAdd(dbias + c, (red[0][K][lane] + red[1][K][lane]) + (red[2][K][lane] + red[3][K][lane]));
     }
 }
 
@@ -214,39 +260,39 @@ __global__ __launch_bounds__(256) void dwconv_bn_swish_bwd_kernel(
 template <int K, int TT, int PASS>
 __global__ __launch_bounds__(256) void dwconv_stats_kernel(const float* __restrict__ g, const float* __restrict__ w,
                                                            const float* __restrict__ bias, const float* __restrict__ mean,
-                                                           float* __restrict__ sum0, int T, int C) {
+                                                           float* __restrict__ sum0, int T, int C, int seg_len) {
     constexpr int HALF = (K - 1) / 2;
+    __shared__ float taps[64 * K];
+    __shared__ float red[4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + lane;
-    const int t0 = (blockIdx.y * 4 + wave) * TT;
     const int b = blockIdx.z;
-    if (t0 >= T) return;
+    const int seg0 = blockIdx.y * seg_len, seg1 = min(T, seg0 + seg_len);
     const bool cok = c < C;
     const int cc = cok ? c : C - 1;
     float wr[K];
-#pragma unroll
-    for (int j = 0; j < K; ++j) wr[j] = w[(int64_t)cc * K + j];
+    load_taps<K>(w, blockIdx.x * 64, C, taps, wr);
     const float bi = bias[cc];
     const float mu = PASS == 1 ? mean[cc] : 0.f;
     const float* gb = g + (int64_t)b * T * C + cc;
-    float acc[TT];
-#pragma unroll
-    for (int o = 0; o < TT; ++o) acc[o] = bi;
-#pragma unroll
-    for (int tau = 0; tau < TT + K - 1; ++tau) {
-        const int t = t0 + tau - HALF;
-        const float v = (t >= 0 && t < T) ? gb[(int64_t)t * C] : 0.f;
-#pragma unroll
-        for (int o = 0; o < TT; ++o) {
-            const int j = tau - o;
-            if (j >= 0 && j < K) acc[o] = fmaf(wr[j], v, acc[o]);
-        }
-    }
     float s = 0.f;
+    for (int t0 = seg0 + wave * TT; t0 < seg1; t0 += 4 * TT) {          // one atomic per channel per WORKGROUP below:
+        float acc[TT];                                                   // same-address atomics serialise in L2
 #pragma unroll
-    for (int o = 0; o < TT; ++o)
-        if (t0 + o < T) s += PASS == 0 ? acc[o] : (acc[o] - mu) * (acc[o] - mu);
-    if (cok) atomicAdd(sum0 + c, s);
+        for (int o = 0; o < TT; ++o) acc[o] = bi;
+        float win[TT + K - 1];
+        load_window<TT + K - 1>(gb, t0 - HALF, T, C, win);
+#pragma unroll
+        for (int o = 0; o < TT; ++o)
+#pragma unroll
+            for (int j = 0; j < K; ++j) acc[o] = fmaf(wr[j], win[o + j], acc[o]);
+#pragma unroll
+        for (int o = 0; o < TT; ++o)
+            if (t0 + o < seg1) s += PASS == 0 ? acc[o] : (acc[o] - mu) * (acc[o] - mu);
+    }
+    red[wave][lane] = s;
+    __syncthreads();
+    if (wave == 0 && cok) atomicAdd(sum0 + c, (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]));
 }
 
 // mean = sum/n; var = m2/n (biased); running <- (1-mom)*running + mom*{mean, var*n/(n-1)}   (convolution.py:16 defaults)
@@ -270,30 +316,26 @@ template <int K, int TT, bool FLIP>
 __global__ __launch_bounds__(256) void dwconv_plain_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                            float* __restrict__ y, int T, int C) {
     constexpr int HALF = (K - 1) / 2;
+    __shared__ float taps[64 * K];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + lane;
     const int t0 = (blockIdx.y * 4 + wave) * TT;
     const int b = blockIdx.z;
+    float wr[K];
+    load_taps<K, FLIP>(w, blockIdx.x * 64, C, taps, wr);
     if (t0 >= T) return;
     const bool cok = c < C;
     const int cc = cok ? c : C - 1;
-    float wr[K];
-#pragma unroll
-    for (int j = 0; j < K; ++j) wr[j] = w[(int64_t)cc * K + (FLIP ? K - 1 - j : j)];
     float acc[TT];
 #pragma unroll
     for (int o = 0; o < TT; ++o) acc[o] = 0.f;
     const float* xb = x + (int64_t)b * T * C + cc;
+    float win[TT + K - 1];
+    load_window<TT + K - 1>(xb, t0 - HALF, T, C, win);
 #pragma unroll
-    for (int tau = 0; tau < TT + K - 1; ++tau) {
-        const int t = t0 + tau - HALF;
-        const float v = (t >= 0 && t < T) ? xb[(int64_t)t * C] : 0.f;
+    for (int o = 0; o < TT; ++o)
 #pragma unroll
-        for (int o = 0; o < TT; ++o) {
-            const int j = tau - o;
-            if (j >= 0 && j < K) acc[o] = fmaf(wr[j], v, acc[o]);
-        }
-    }
+        for (int j = 0; j < K; ++j) acc[o] = fmaf(wr[j], win[o + j], acc[o]);
     float* yb = y + (int64_t)b * T * C + cc;
 #pragma unroll
     for (int o = 0; o < TT; ++o) {
@@ -329,10 +371,7 @@ extern "C" int cfm_layernorm_bwd_params_f32(const float* x, const float* dy, con
                                             float* dgamma, float* dbeta, int64_t rows, int d, cfm_stream_t stream) {
     CFM_REQUIRE(x && dy && mean && rstd && dgamma && dbeta, CFM_ERR_NULL);
     CFM_REQUIRE(rows > 0 && d > 0, CFM_ERR_BAD_SHAPE);
-    const int rpb = 128;
-    const dim3 grid((unsigned)((d + 63) / 64), (unsigned)((rows + rpb - 1) / rpb));
-    hipLaunchKernelGGL(colreduce_kernel<1>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), x, dy, mean, rstd,
-                       (int64_t)d, rows, d, rpb, 1.0f, dgamma, dbeta);
+    colreduce_launch<1>(x, dy, mean, rstd, (int64_t)d, rows, d, 1.0f, dgamma, dbeta, static_cast<hipStream_t>(stream));
     return cfm_launch_status();
 }
 
@@ -341,10 +380,7 @@ extern "C" int cfm_colsum_f32(const float* X, int64_t ld, int64_t rows, int cols
                               cfm_stream_t stream) {
     CFM_REQUIRE(X && out, CFM_ERR_NULL);
     CFM_REQUIRE(rows > 0 && cols > 0 && ld >= cols, CFM_ERR_BAD_SHAPE);
-    const int rpb = 128;
-    const dim3 grid((unsigned)((cols + 63) / 64), (unsigned)((rows + rpb - 1) / rpb));
-    hipLaunchKernelGGL(colreduce_kernel<0>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), X, nullptr, nullptr,
-                       nullptr, ld, rows, cols, rpb, alpha, out, nullptr);
+    colreduce_launch<0>(X, nullptr, nullptr, nullptr, ld, rows, cols, alpha, out, nullptr, static_cast<hipStream_t>(stream));
     return cfm_launch_status();
 }
 
@@ -420,14 +456,20 @@ extern "C" int cfm_dwconv_bn_stats_f32(const float* g, const float* w, const flo
     hipStream_t s = static_cast<hipStream_t>(stream);
     constexpr int TT = 16;
     const int64_t n = (int64_t)B * T;
-    const dim3 grid((unsigned)((C + 63) / 64), (unsigned)((T + 4 * TT - 1) / (4 * TT)), (unsigned)B), block(256);
+    const int cblocks = (C + 63) / 64;
+    int nseg = (1024 + cblocks * B - 1) / (cblocks * B);                 // >= ~4 workgroups per CU, as few atomics as possible
+    nseg = nseg < 1 ? 1 : nseg;
+    int seg_len = (T + nseg - 1) / nseg;
+    seg_len = (seg_len + 4 * TT - 1) / (4 * TT) * (4 * TT);
+    nseg = (T + seg_len - 1) / seg_len;
+    const dim3 grid((unsigned)cblocks, (unsigned)nseg, (unsigned)B), block(256);
     const unsigned cb = (unsigned)((C + 255) / 256);
     if (hipMemsetAsync(batch_mean, 0, sizeof(float) * C, s) != hipSuccess) return CFM_ERR_LAUNCH;
     if (hipMemsetAsync(batch_var, 0, sizeof(float) * C, s) != hipSuccess) return CFM_ERR_LAUNCH;
 #define DWS(KK)                                                                                                        \
-    hipLaunchKernelGGL((dwconv_stats_kernel<KK, TT, 0>), grid, block, 0, s, g, w, bias, nullptr, batch_mean, T, C);     \
+    hipLaunchKernelGGL((dwconv_stats_kernel<KK, TT, 0>), grid, block, 0, s, g, w, bias, nullptr, batch_mean, T, C, seg_len); \
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(cb), dim3(256), 0, s, batch_mean, 1.0f / (float)n, C);                  \
-    hipLaunchKernelGGL((dwconv_stats_kernel<KK, TT, 1>), grid, block, 0, s, g, w, bias, batch_mean, batch_var, T, C)
+    hipLaunchKernelGGL((dwconv_stats_kernel<KK, TT, 1>), grid, block, 0, s, g, w, bias, batch_mean, batch_var, T, C, seg_len)
     switch (K) {
         case 31: DWS(31); break;
         case 15: DWS(15); break;

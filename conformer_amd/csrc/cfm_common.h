@@ -60,6 +60,35 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nwg) {
     return base + i;
 }
 
+// Depthwise-conv taps of the 64 channels a workgroup owns: the (C,K) weight block [c0*K, (c0+64)*K) is contiguous, so
+// it is read with coalesced loads into LDS and each lane then picks its K taps (stride K words: conflict-free for odd K)
+// -- the direct per-lane read w[c*K + j] touches 64 cache lines per instruction.  All 256 threads must call it.
+template <int K, bool FLIP = false>
+__device__ __forceinline__ void load_taps(const float* __restrict__ w, int c0, int C, float* taps_lds /* [64*K] */,
+                                          float (&wr)[K]) {
+    const int64_t base = (int64_t)c0 * K, lim = (int64_t)C * K;
+    for (int f = threadIdx.x; f < 64 * K; f += blockDim.x) taps_lds[f] = base + f < lim ? w[base + f] : 0.f;
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int j = 0; j < K; ++j) wr[j] = taps_lds[lane * K + (FLIP ? K - 1 - j : j)];
+}
+
+// Sliding window of N frames of one channel column (frame stride C) starting at frame t_first: out-of-range frames
+// read a clamped address and are zeroed by a select, so all N loads are unconditional and issue back to back (a
+// conditional load compiles to a branch + s_waitcnt per frame and serialises the memory latency).
+template <int N>
+__device__ __forceinline__ void load_window(const float* __restrict__ col, int t_first, int T, int C, float (&win)[N]) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) win[i] = col[(int64_t)min(max(t_first + i, 0), T - 1) * C];
+    __builtin_amdgcn_sched_barrier(0);          // keep the scheduler from sinking each load next to its first use
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const int t = t_first + i;
+        win[i] = (t >= 0 && t < T) ? win[i] : 0.f;
+    }
+}
+
 // 16-bit matrix-pipe element types (gemm_mfma16.hip, gemm_bwd_mfma16.hip): conversions are RNE, accumulation is fp32.
 template <typename T16> struct Lowp;
 template <> struct Lowp<__bf16> {

@@ -12,31 +12,27 @@ __global__ __launch_bounds__(256) void dwconv_bn_swish_kernel(
     const float* __restrict__ bn_w, const float* __restrict__ bn_b, const float* __restrict__ bn_mean,
     const float* __restrict__ bn_var, float eps, float* __restrict__ y, int T, int C) {
     constexpr int HALF = (K - 1) / 2;
+    __shared__ float taps[64 * K];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + lane;
     const int t0 = (blockIdx.y * 4 + wave) * TT;
     const int b = blockIdx.z;
-    if (t0 >= T) return;                               // wave-uniform
+    float wr[K];
+    load_taps<K>(w, blockIdx.x * 64, C, taps, wr);
+    if (t0 >= T) return;                               // wave-uniform (after the block-wide tap staging)
     const bool cok = c < C;
     const int cc = cok ? c : C - 1;
-    float wr[K];
-#pragma unroll
-    for (int j = 0; j < K; ++j) wr[j] = w[(int64_t)cc * K + j];
     float acc[TT];
     const float bi = bias[cc];
 #pragma unroll
     for (int o = 0; o < TT; ++o) acc[o] = bi;
     const float* gb = g + (int64_t)b * T * C + cc;
+    float win[TT + K - 1];
+    load_window<TT + K - 1>(gb, t0 - HALF, T, C, win);
 #pragma unroll
-    for (int tau = 0; tau < TT + K - 1; ++tau) {
-        const int t = t0 + tau - HALF;
-        const float v = (t >= 0 && t < T) ? gb[(int64_t)t * C] : 0.f;
+    for (int o = 0; o < TT; ++o)
 #pragma unroll
-        for (int o = 0; o < TT; ++o) {
-            const int j = tau - o;
-            if (j >= 0 && j < K) acc[o] = fmaf(wr[j], v, acc[o]);
-        }
-    }
+        for (int j = 0; j < K; ++j) acc[o] = fmaf(wr[j], win[o + j], acc[o]);
     const float inv = 1.0f / sqrtf(bn_var[cc] + eps);
     const float mu = bn_mean[cc], ga = bn_w[cc], be = bn_b[cc];
     float* yb = y + (int64_t)b * T * C + cc;

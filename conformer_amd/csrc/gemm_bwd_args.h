@@ -4,6 +4,8 @@
 
 enum BwdEpi { BEPI_SCALE = 0, BEPI_DSWISH = 1 };
 
+int cfm_bwd_debug_tile();   // diagnostics (cfm_debug_set_bwd_tile): -1 = heuristic, 0 = 128x128, 1 = 128x64, 3 = 64x64
+
 struct BwdArgs {
     const float* A; const float* B; const float* Z; float* C;
     int I, J; int64_t Kc; int64_t lda, ldb, ldz, ldc; float alpha;

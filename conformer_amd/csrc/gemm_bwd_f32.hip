@@ -260,6 +260,8 @@ int launch_layout(const BwdArgs& g, hipStream_t s) {
 
 }  // namespace
 
+int cfm_bwd_debug_tile() { return g_debug_tile; }
+
 // C (I x J, leading dim ldc) (+)= alpha * op(A) . op(B)^T, optionally times swish'(Z).  a_col / b_col select the
 // contraction-major layout of each operand (see the header of this file).  Requirements: lda, ldb, ldc multiples of
 // 4; A, B, C, Z 16-byte aligned (also per batch: strides multiples of 4).  `allow_split` != 0 lets the contraction be

@@ -213,7 +213,10 @@ int launch_one(BwdArgs g, hipStream_t s) {
 template <typename T16, bool AROW, bool BROW, int EPI>
 int launch_layout(const BwdArgs& g, hipStream_t s) {
     const int64_t t128 = (int64_t)((g.I + 127) / 128) * ((g.J + 127) / 128) * g.nbatch;
-    if (t128 >= 512 && g.I >= 96 && g.J >= 96) return launch_one<T16, 128, 128, AROW, BROW, EPI>(g, s);
+    int tile = cfm_bwd_debug_tile();
+    if (tile < 0) tile = (t128 >= 512 && g.I >= 96 && g.J >= 96) ? 0 : 3;
+    if (tile == 0) return launch_one<T16, 128, 128, AROW, BROW, EPI>(g, s);
+    if (tile == 1) return launch_one<T16, 128, 64, AROW, BROW, EPI>(g, s);
     return launch_one<T16, 64, 64, AROW, BROW, EPI>(g, s);
 }
 

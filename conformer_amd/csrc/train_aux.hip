@@ -54,45 +54,56 @@ __global__ __launch_bounds__(256) void adam_kernel(const AdamBatch batch, float 
 
 // ---- N4: greedy CTC decode (processor.py:301-328): per-frame argmax, drop pad/unk, collapse repeats ---------------------------
 // NOTE the reference's collapse does NOT reset on a skipped pad/unk frame ("a <pad> a" -> "a"): reproduced as is.
-// One workgroup per utterance: waves sweep the frames (lanes over the vocabulary), then one lane compacts.
-__global__ __launch_bounds__(256) void greedy_decode_kernel(const float* __restrict__ logits, const int64_t* __restrict__ lengths,
-                                                            int64_t* __restrict__ frame_ids, int64_t* __restrict__ tokens,
-                                                            int64_t* __restrict__ counts, int T, int V, int pad_id,
-                                                            int unk_id) {
-    const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int64_t* ids = frame_ids + (int64_t)b * T;
-    for (int t = wave; t < T; t += 4) {
-        const float* row = logits + ((int64_t)b * T + t) * V;
-        float best = -INFINITY;
-        int bi = 0x7fffffff;
-        for (int c = lane; c < V; c += 64) {
-            const float x = row[c];
-            if (x > best || (x == best && c < bi)) { best = x; bi = c; }   // NaN-free logits assumed; ties -> lowest index
-        }
+// Two launches: (1) one wave per frame, lanes over the vocabulary, shuffle arg-max (ties -> lowest index);
+// (2) one wave per utterance compacts 64 frames at a time with ballots -- "previous kept-or-skipped id" is the id of
+// the nearest earlier non-pad/unk frame, found from the ballot mask, so the collapse needs no serial loop over frames.
+__global__ __launch_bounds__(256) void frame_argmax_kernel(const float* __restrict__ logits, int64_t* __restrict__ frame_ids,
+                                                           int64_t rows, int V) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* r = logits + row * V;
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int c = lane; c < V; c += 64) {
+        const float x = r[c];
+        if (x > best || (x == best && c < bi)) { best = x; bi = c; }       // NaN-free logits assumed
+    }
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const float ob = __shfl_xor(best, o, 64);
-            const int oi = __shfl_xor(bi, o, 64);
-            if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
-        }
-        if (lane == 0) ids[t] = bi;
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ob = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
     }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const int n = lengths ? (int)min((int64_t)T, max((int64_t)0, lengths[b])) : T;
-        int64_t* out = tokens + (int64_t)b * T;
-        int cnt = 0;
-        int64_t prev = -1;
-        for (int t = 0; t < n; ++t) {
-            const int64_t id = ids[t];
-            if (id == pad_id || id == unk_id) continue;
-            if (id == prev) continue;
-            prev = id;
-            out[cnt++] = id;
-        }
-        for (int t = cnt; t < T; ++t) out[t] = -1;
-        counts[b] = cnt;
+    if (lane == 0) frame_ids[row] = bi;
+}
+
+__global__ __launch_bounds__(64) void ctc_collapse_kernel(const int64_t* __restrict__ frame_ids,
+                                                          const int64_t* __restrict__ lengths, int64_t* __restrict__ tokens,
+                                                          int64_t* __restrict__ counts, int T, int pad_id, int unk_id) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int64_t* ids = frame_ids + (int64_t)b * T;
+    int64_t* out = tokens + (int64_t)b * T;
+    const int n = lengths ? (int)min((int64_t)T, max((int64_t)0, lengths[b])) : T;
+    int cnt = 0;
+    int64_t carry = -1;                                   // id of the last non-skipped frame so far (-1: none yet)
+    for (int t0 = 0; t0 < n; t0 += 64) {
+        const int t = t0 + lane;
+        const int64_t id = t < n ? ids[t] : -1;
+        const bool valid = t < n && id != pad_id && id != unk_id;
+        const unsigned long long vm = __ballot(valid);
+        const unsigned long long below = vm & ((1ull << lane) - 1ull);
+        const int src = below ? 63 - __clzll(below) : 0;
+        const int64_t prev_in = __shfl(id, src, 64);
+        const int64_t prev = below ? prev_in : carry;
+        const bool keep = valid && id != prev;
+        const unsigned long long km = __ballot(keep);
+        if (keep) out[cnt + __popcll(km & ((1ull << lane) - 1ull))] = id;
+        cnt += __popcll(km);
+        if (vm) carry = __shfl(id, 63 - __clzll(vm), 64);
     }
+    for (int t = cnt + lane; t < T; t += 64) out[t] = -1;
+    if (lane == 0) counts[b] = cnt;
 }
 
 }  // namespace
@@ -135,7 +146,10 @@ extern "C" int cfm_greedy_ctc_decode_f32(const float* logits, const int64_t* len
                                          cfm_stream_t stream) {
     CFM_REQUIRE(logits && frame_ids && tokens && counts, CFM_ERR_NULL);
     CFM_REQUIRE(B > 0 && T > 0 && V > 0, CFM_ERR_BAD_SHAPE);
-    hipLaunchKernelGGL(greedy_decode_kernel, dim3((unsigned)B), dim3(256), 0, static_cast<hipStream_t>(stream), logits,
-                       lengths_or_null, frame_ids, tokens, counts, T, V, pad_id, unk_id);
+    const int64_t rows = (int64_t)B * T;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(frame_argmax_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, logits, frame_ids, rows, V);
+    hipLaunchKernelGGL(ctc_collapse_kernel, dim3((unsigned)B), dim3(64), 0, s, frame_ids, lengths_or_null, tokens, counts, T,
+                       pad_id, unk_id);
     return cfm_launch_status();
 }

@@ -141,6 +141,58 @@ def test_encoder_cfg2_shapes_vs_oracle(dev):
     assert rel_l2(y, ref) < 1e-4
 
 
+def test_encoder_cfg2_full_depth_vs_oracle(dev):
+    """BASELINE cfg-2 model (16 blocks, d=512, H=8, T=1000) at B=2 vs the float64 oracle: the full-depth error budget."""
+    meta = dict(vocab=8, n_mel=80, n_blocks=16, d=512, n_heads=8, ksize=31, lstm_hidden=8, seed=21)
+    P = O.make_params(**meta, with_decoder=False)
+    from model.modules.encoder import Encoder
+    enc = Encoder(80, 16, 512, 8, 31, 0.0)
+    enc.load_state_dict({k[len("encoder."):]: v for k, v in P.items()}, strict=True)
+    enc = enc.to(dev).eval()
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(2, 80, 1000, generator=g)
+    L = torch.tensor([1000, 613])
+    Pd = {k: (v.double() if v.is_floating_point() else v) for k, v in P.items()}
+    with torch.no_grad():
+        y, L2 = enc(x.to(dev), L.to(dev))
+        ref, R2 = O.encoder_forward(x.double(), L, Pd, 16, 8)
+    assert torch.equal(L2.cpu(), R2)
+    assert rel_l2(y, ref) < 1e-4          # north_star: 1e-3 rel fp32
+
+
+def test_encoder_cfg2_full_size_properties(dev):
+    """The bench workload itself (B=32, T=1000, 16 blocks), too large for the CPU oracle: size-independent properties.
+    Eval mode has no cross-utterance term (BatchNorm uses running statistics), so the encoder must be (a) deterministic,
+    (b) equivariant under a permutation of the utterances and (c) consistent with running any sub-batch on its own;
+    together with the B=2 full-depth oracle check above this pins the full-size result."""
+    from model.modules.encoder import Encoder
+    torch.manual_seed(0)
+    enc = Encoder(80, 16, 512, 8, 31, 0.0).to(dev).eval()
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(32, 80, 1000, generator=g).to(dev)
+    L = torch.full((32,), 1000, dtype=torch.int64)
+    L[5], L[17], L[31] = 911, 640, 37
+    L = L.to(dev)
+    with torch.no_grad():
+        y, L2 = enc(x, L)
+        y_again, _ = enc(x, L)
+        assert torch.equal(y, y_again)
+        perm = torch.randperm(32, generator=g).to(dev)
+        yp, Lp = enc(x[perm].contiguous(), L[perm].contiguous())
+        assert torch.equal(Lp, L2[perm])
+        assert rel_l2(yp, y[perm]) < 1e-6
+        sub = torch.tensor([0, 5, 17], device=dev)          # keeps one full-length utterance: lengths.max() == T'
+        ys, _ = enc(x[sub].contiguous(), L[sub].contiguous())
+        assert rel_l2(ys, y[sub]) < 1e-6
+    assert torch.isfinite(y).all() and y.shape == (32, 249, 512)
+    # (d) utterances are independent: changing one leaves every other output bit-identical
+    x2 = x.clone()
+    x2[31, :, 200:] = 0.0
+    with torch.no_grad():
+        y2, _ = enc(x2, L)
+    assert torch.equal(y2[:31], y[:31])
+
+
 def test_unbuilt_training_features_are_refused_loudly(dev):
     """No silent fallback: what has no kernels yet raises (train-mode dropout under no_grad; gradient w.r.t. the input)."""
     from model.modules.encoder import Encoder

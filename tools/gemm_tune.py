@@ -104,8 +104,8 @@ def occ_sweep():
             print(line, flush=True)
 
 
-def bwd_sweep():
-    """Backward-GEMM products of the hot path at every block tile."""
+def bwd_sweep(prec=0):
+    """Backward-GEMM products of the hot path at every block tile (prec 0 = fp32 MFMA, 1 = bf16, 2 = fp16)."""
     from conformer_amd import ops
     lib = _lib.load()
     dev = torch.device("cuda:0")
@@ -125,7 +125,7 @@ def bwd_sweep():
             out = torch.zeros(I, J, device=dev)
 
             def run():
-                ops.gemm_bwd(A, a_col, Bm, b_col, I, J, Kc, Z=Z, out=out, allow_split=split)
+                ops.gemm_bwd(A, a_col, Bm, b_col, I, J, Kc, Z=Z, out=out, allow_split=split, prec=prec)
             for _ in range(3):
                 run()
             torch.cuda.synchronize()
@@ -145,8 +145,8 @@ def bwd_sweep():
 
 
 def main():
-    if len(sys.argv) == 2 and sys.argv[1] == "bwd":
-        return bwd_sweep()
+    if len(sys.argv) == 2 and sys.argv[1] in ("bwd", "bwd16"):
+        return bwd_sweep(1 if sys.argv[1] == "bwd16" else 0)
     if len(sys.argv) == 2 and sys.argv[1] == "occ":
         return occ_sweep()
     if len(sys.argv) == 6 and sys.argv[1] == "trace":

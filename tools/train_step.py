@@ -67,11 +67,18 @@ def main():
         last["loss"] = loss
 
     dt = parallel.timed_steps(step, args.steps, args.warmup, torch.cuda.synchronize, dev)
+    # host-side issue time of one step (no sync inside): tells whether the step is launch-bound
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        step()
+    host_ms = (time.perf_counter() - t0) / 3 * 1e3
+    torch.cuda.synchronize()
     if env.is_main:
         ms = dt / args.steps * 1e3
         print(json.dumps({"what": "Conformer-L training step fwd+CTC+bwd+Adam, dropout 0, BN train", "dtype": args.dtype,
                           "optimizer": args.optim, "n_gpus": env.world, "per_gpu_batch": args.batch, "mel_frames": args.frames,
-                          "ms_per_step": ms, "frames_per_sec": env.world * args.batch * args.frames * args.steps / dt,
+                          "ms_per_step": ms, "host_issue_ms_per_step": host_ms, "frames_per_sec": env.world * args.batch * args.frames * args.steps / dt,
                           "loss": float(last["loss"]), "max_mem_gib": torch.cuda.max_memory_allocated() / 2 ** 30}),
               flush=True)
     if torch.distributed.is_initialized():
