@@ -33,6 +33,7 @@ struct AttnArgs {
     const int64_t* lengths; float* ctx; int64_t ldo; float* lse;
     int B, T, H, dh; float inv_sqrt_dh;
     float drop_p; unsigned long long drop_seed;     // training: dropout on the softmax weights (attention.py:67)
+    unsigned long long* trace;                      // diagnostics (cfm_debug_attention_trace_f32): phase stamps of one wave
 };
 
 template <int NC, int ND>
@@ -141,23 +142,20 @@ __global__ __launch_bounds__(256, 2) void relpos_attn_fwd_kernel(const AttnArgs 
         for (int r = 0; r < 16; ++r) o[n][r] = 0.f;
     float mrow = -INFINITY, lrow = 0.f;
 
+    const bool tracer = a.trace && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0;
+#define ATT_STAMP(i) do { if (tracer) a.trace[16 * kt + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
     for (int kt = 0; kt < ntiles; ++kt) {
         const int k0 = kt * 32;
+        ATT_STAMP(0);
         if (active) {
-            // ---- content scores S^T[key][query]
-            f32x16 sc;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) sc[r] = 0.f;
-#pragma unroll
-            for (int c = 0; c < NC; ++c) {
-                const f32x4 kf = *reinterpret_cast<const f32x4*>(Ks + li * KROW + 8 * c + 4 * hf);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) sc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[e], qu[4 * c + e], sc, 0, 0, 0);
-            }
-            // ---- positional band G^T[jj][query], jj = 32*mt + row <-> table row j = jbase - jj; skew through LDS
+            // ---- positional band G^T[jj][query], jj = 32*mt + row <-> table row j = jbase - jj, then the "relative shift":
+            // lane (query li) needs G^T[li - kk + 31][li] for its 16 keys kk -- a per-lane column skew through the per-wave
+            // LDS tile (each lane only touches its own bank).  Order: band 0 -> tile; band 1 MFMAs are issued while the skewed
+            // reads of band 0 return; band 1 -> tile; the content MFMAs are issued while the reads of band 1 return.  All 16
+            // skew reads of a band are unconditional and issued back to back (a per-key `if` compiles to 16 serialized
+            // branch + ds_read + wait sequences: measured 3 us per band), the band that owns key kk is picked by a select.
             const int jbase = T - 1 - i0 + k0 + 31;
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt) {
+            auto band = [&](int mt) {
                 const int slot = (jbase - (32 * mt + li) + ring_bias) % RING;
                 const float* prow = Pr + slot * KROW + 4 * hf;
                 f32x16 ga;
@@ -169,20 +167,54 @@ __global__ __launch_bounds__(256, 2) void relpos_attn_fwd_kernel(const AttnArgs 
 #pragma unroll
                     for (int e = 0; e < 4; ++e) ga = __builtin_amdgcn_mfma_f32_32x32x2f32(pf[e], qv[4 * c + e], ga, 0, 0, 0);
                 }
+                return ga;
+            };
+            auto spill_band = [&](const f32x16& ga) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) gs[((r & 3) + 8 * (r >> 2) + 4 * hf) * 32 + li] = ga[r];
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int kk = (r & 3) + 8 * (r >> 2) + 4 * hf;
-                    const int jj = li - kk + 31;                    // 0..62
-                    if ((jj >> 5) == mt) sc[r] += gs[(jj & 31) * 32 + li];
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();                    // tile is rewritten by the next mt / key tile
+            };
+            float sk[16];                                            // skewed positional scores of this lane's 16 keys
+            {
+                const f32x16 g0 = band(0);
+                ATT_STAMP(1);
+                spill_band(g0);
             }
+            const f32x16 g1 = band(1);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int jj = li - ((r & 3) + 8 * (r >> 2) + 4 * hf) + 31;     // 0..62
+                sk[r] = gs[(jj & 31) * 32 + li];
+            }
+            ATT_STAMP(2);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // band-0 reads have landed before the tile is rewritten
+            __builtin_amdgcn_wave_barrier();
+            spill_band(g1);
+            ATT_STAMP(3);
+            // ---- content scores S^T[key][query]
+            f32x16 sc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sc[r] = 0.f;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const f32x4 kf = *reinterpret_cast<const f32x4*>(Ks + li * KROW + 8 * c + 4 * hf);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) sc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[e], qu[4 * c + e], sc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int jj = li - ((r & 3) + 8 * (r >> 2) + 4 * hf) + 31;
+                const float g1v = gs[(jj & 31) * 32 + li];
+                sk[r] = (jj >> 5) ? g1v : sk[r];
+            }
+            ATT_STAMP(4);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();                        // the tile is rewritten by the next key tile
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sc[r] += sk[r];
+            ATT_STAMP(5);
             // ---- scale + mask, online softmax (query = lane column; keys = registers x 2 halves)
             float p[16];
             float tmax = -INFINITY;
@@ -204,6 +236,7 @@ __global__ __launch_bounds__(256, 2) void relpos_attn_fwd_kernel(const AttnArgs 
             psum += __shfl_xor(psum, 32, 64);
             lrow = lrow * alpha + psum;
             mrow = mnew;
+            ATT_STAMP(6);
             if (a.drop_p > 0.f) {                                     // weights are dropped AFTER normalisation: l stays unmasked
                 const float inv_keep = 1.0f / (1.0f - a.drop_p);
                 const unsigned long long rowbase = ((unsigned long long)bh * T + (unsigned)(i0 + li)) * (unsigned long long)T;
@@ -223,6 +256,7 @@ __global__ __launch_bounds__(256, 2) void relpos_attn_fwd_kernel(const AttnArgs 
                     const float vv = Vs[((s & 3) + 8 * (s >> 2) + 4 * hf) * 64 + ((32 * n + li) & 63)];
                     o[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv, p[s], o[n], 0, 0, 0);
                 }
+            ATT_STAMP(7);
         }
         // ---- rotate the staged tiles: everyone is done reading tile kt -> write tile kt+1 -> fetch tile kt+2
         if (kt + 1 < ntiles) {
@@ -231,7 +265,9 @@ __global__ __launch_bounds__(256, 2) void relpos_attn_fwd_kernel(const AttnArgs 
             __syncthreads();
             if (kt + 2 < ntiles) prefetch(kt + 2);
         }
+        ATT_STAMP(8);
     }
+#undef ATT_STAMP
 
     // ---- normalise and store: lane = query row, registers = head dims (4 consecutive dims per r>>2 group)
     if (active && i0 + li < T) {
@@ -256,7 +292,17 @@ __global__ __launch_bounds__(256, 2) void relpos_attn_fwd_kernel(const AttnArgs 
 static int attention_launch(const float* q, const float* k, const float* v, int64_t ld, const float* pos, int64_t ldp,
                             const float* u, const float* vbias, const int64_t* lengths_or_null, float* ctx, int64_t ldo,
                             float* lse_or_null, int B, int T, int H, int dh, float drop_p, uint64_t drop_seed,
-                            cfm_stream_t stream);
+                            cfm_stream_t stream, void* trace = nullptr);
+
+// diagnostics only (tools/attn_probe.py trace): as cfm_relpos_attention_fwd_f32, plus s_memrealtime (100 MHz) stamps of
+// wave 0 of workgroup (0,0) at 9 phase boundaries of every key tile: trace[16*tile + phase], 16*ceil(T/32) uint64.
+extern "C" int cfm_debug_attention_trace_f32(const float* q, const float* k, const float* v, int64_t ld, const float* pos,
+                                             int64_t ldp, const float* u, const float* vbias,
+                                             const int64_t* lengths_or_null, float* ctx, int64_t ldo, int B, int T, int H,
+                                             int dh, void* trace, cfm_stream_t stream) {
+    return attention_launch(q, k, v, ld, pos, ldp, u, vbias, lengths_or_null, ctx, ldo, nullptr, B, T, H, dh, 0.f, 0, stream,
+                            trace);
+}
 
 extern "C" int cfm_relpos_attention_fwd_f32(const float* q, const float* k, const float* v, int64_t ld,
                                             const float* pos, int64_t ldp, const float* u, const float* vbias,
@@ -280,7 +326,7 @@ extern "C" int cfm_relpos_attention_train_f32(const float* q, const float* k, co
 static int attention_launch(const float* q, const float* k, const float* v, int64_t ld, const float* pos, int64_t ldp,
                             const float* u, const float* vbias, const int64_t* lengths_or_null, float* ctx, int64_t ldo,
                             float* lse_or_null, int B, int T, int H, int dh, float drop_p, uint64_t drop_seed,
-                            cfm_stream_t stream) {
+                            cfm_stream_t stream, void* trace) {
     CFM_REQUIRE(q && k && v && pos && u && vbias && ctx, CFM_ERR_NULL);
     CFM_REQUIRE(B > 0 && T > 0 && H > 0 && dh > 0 && (dh & 3) == 0, CFM_ERR_BAD_SHAPE);
     CFM_REQUIRE((ld & 3) == 0 && (ldp & 3) == 0 && (ldo & 3) == 0, CFM_ERR_BAD_SHAPE);
@@ -289,7 +335,7 @@ static int attention_launch(const float* q, const float* k, const float* v, int6
                 CFM_ALIGNED16(vbias) && CFM_ALIGNED16(ctx), CFM_ERR_ALIGN);
     CFM_REQUIRE((int64_t)B * H <= 65535 && T < (1 << 28), CFM_ERR_UNSUPPORTED);
     AttnArgs a{q, k, v, ld, pos, ldp, u, vbias, lengths_or_null, ctx, ldo, lse_or_null, B, T, H, dh, 1.0f / sqrtf((float)dh),
-               drop_p, drop_seed};
+               drop_p, drop_seed, static_cast<unsigned long long*>(trace)};
     const dim3 grid((unsigned)((T + 127) / 128), (unsigned)(B * H)), block(256);
     hipStream_t s = static_cast<hipStream_t>(stream);
 #define ATT_LAUNCH(NC, ND) hipLaunchKernelGGL((relpos_attn_fwd_kernel<NC, ND>), grid, block, 0, s, a)

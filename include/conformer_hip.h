@@ -280,6 +280,10 @@ int cfm_greedy_ctc_decode_f32(const float* logits, const int64_t* lengths_or_nul
                               int64_t* tokens, int64_t* counts, int B, int T, int V, int pad_id, int unk_id,
                               cfm_stream_t stream);
 
+/* diagnostics only: cfm_relpos_attention_fwd_f32 + s_memrealtime stamps of one wave (trace: 16*ceil(T/32) uint64) */
+int cfm_debug_attention_trace_f32(const float* q, const float* k, const float* v, int64_t ld, const float* pos,
+                                  int64_t ldp, const float* u, const float* vbias, const int64_t* lengths_or_null,
+                                  float* ctx, int64_t ldo, int B, int T, int H, int dh, void* trace, cfm_stream_t stream);
 /* diagnostics only (process-global, not thread-safe): force the block tile of cfm_gemm_bwd* (-1 = heuristic) */
 int cfm_debug_set_bwd_tile(int tile);
 
