@@ -75,3 +75,30 @@ def test_frontend_call_and_specaugment_gpu():
     out = aug(mels)
     bands = FO.specaugment_bands(101, 80, 10, 35, 10, 35, 0.05, torch.Generator().manual_seed(7))
     assert torch.equal(out.cpu(), FO.specaugment_apply(before.cpu(), bands, 0.0))
+
+
+@pytest.mark.gpu
+def test_frontend_pipeline_matches_serial_path():
+    """N3: batches prepared on the side stream equal the serial front end + the collate's length sort, also while the
+    consumer stream is busy."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from conformer_amd.frontend import ConformerAudioFrontend
+    from conformer_amd.pipeline import FrontendPipeline
+    dev = torch.device("cuda:0")
+    fe = ConformerAudioFrontend(device=dev)
+    g = torch.Generator().manual_seed(0)
+    batches = [[torch.randn(n, generator=g) for n in lens] for lens in ([16000, 4000, 12345], [800, 8000], [3200], [401, 16000, 7000, 160])]
+    busy = torch.randn(2048, 2048, device=dev)
+    seen = 0
+    for (mels, frames, order), src in zip(FrontendPipeline(batches, fe), batches):
+        for _ in range(3):
+            busy = busy @ busy * 1e-3                                   # keep the consumer stream occupied
+        ref_m, ref_l = fe(src)
+        ref_l, ref_o = torch.sort(ref_l, descending=True)
+        assert torch.equal(frames, ref_l)
+        assert torch.equal(mels, ref_m[order])
+        assert sorted(order.tolist()) == list(range(len(src)))
+        assert [len(src[i]) // 160 + 1 for i in order.tolist()] == frames.tolist()
+        seen += 1
+    assert seen == len(batches)
