@@ -568,3 +568,34 @@ def subsample_stem_bwd(x, w1, b1, w2, h1, h2, dh2):
                                                db1.data_ptr(), B, F, T, C, _stream()), "cfm_subsample_conv1_bwd_f32")
     dw2 = dw2p.view(C, 3, 3, C).permute(0, 3, 1, 2).contiguous()        # packed (co,kf,kt,ci) -> (co,ci,kf,kt): tiny glue
     return dw1, db1, dw2, db2
+
+
+# ---- N1 decoder: LSTM over a packed batch, Swish + BatchNorm(eval), vocabulary projection -------------------------------
+def lstm_forward(x, w_ih, w_hh, bias, lengths=None, save: bool = False):
+    """nn.LSTM(batch_first) forward of one layer: x (B,T,D) -> y (B,T,H); bias = b_ih + b_hh (4H).  `lengths` (B) int64 on
+    the device gives pack_padded_sequence semantics (outputs beyond an utterance's length are 0).  The input projection is
+    one GEMM (16-bit MFMA under autocast), the recurrence runs in fp32.  save=True also returns (gates, cells)."""
+    x = _req(x, "x"); w_hh = _req(w_hh, "weight_hh")
+    B, T, _ = x.shape
+    H = w_hh.shape[1]
+    gx = linear(x, w_ih, bias)                                        # (B,T,4H)
+    y = torch.empty(B, T, H, device=x.device, dtype=x.dtype)
+    c = torch.empty(B, H, device=x.device, dtype=x.dtype)
+    gates = torch.empty(B, T, 4 * H, device=x.device, dtype=x.dtype) if save else None
+    cells = torch.empty(B, T, H, device=x.device, dtype=x.dtype) if save else None
+    if lengths is not None:
+        lengths = _req(lengths, "lengths", torch.int64)
+    _lib.check(_lib.load().cfm_lstm_fwd_f32(gx.data_ptr(), w_hh.data_ptr(), _p(lengths), y.data_ptr(), c.data_ptr(), _p(gates),
+                                            _p(cells), B, T, H, _stream()), "cfm_lstm_fwd_f32")
+    return (y, gates, cells) if save else y
+
+
+def swish_bn_eval(h, bn_mean, bn_var, bn_weight, bn_bias, eps: float = 1e-5):
+    h = _req(h, "h")
+    C = h.shape[-1]
+    out = torch.empty_like(h)
+    _lib.check(_lib.load().cfm_swish_bn_eval_f32(h.data_ptr(), _req(bn_mean, "bn_mean").data_ptr(),
+                                                 _req(bn_var, "bn_var").data_ptr(), _req(bn_weight, "bn_weight").data_ptr(),
+                                                 _req(bn_bias, "bn_bias").data_ptr(), eps, out.data_ptr(), h.numel() // C, C,
+                                                 _stream()), "cfm_swish_bn_eval_f32")
+    return out

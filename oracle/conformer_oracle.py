@@ -201,20 +201,36 @@ def encoder_forward(x: torch.Tensor, lengths: Optional[torch.Tensor], p: Params,
     return h, out_len
 
 
+def lstm_layer(x: torch.Tensor, lengths: Optional[torch.Tensor], w_ih, w_hh, b_ih, b_hh) -> torch.Tensor:
+    """One nn.LSTM(batch_first=True) layer over a packed batch (decoder.py:10,17-22), written out: gate order i|f|g|o,
+    c_t = f*c + i*g, h_t = o*tanh(c_t); utterance b is advanced for lengths[b] frames only and later outputs are 0
+    (pack_padded_sequence / pad_packed_sequence).  Checked against torch.nn.LSTM in tests/test_oracle_golden.py."""
+    B, T, _ = x.shape
+    H = w_hh.shape[1]
+    gx = x @ w_ih.t() + b_ih + b_hh
+    h = x.new_zeros(B, H)
+    c = x.new_zeros(B, H)
+    out = x.new_zeros(B, T, H)
+    for t in range(T):
+        g = gx[:, t] + h @ w_hh.t()
+        i, f, gg, o = torch.sigmoid(g[:, :H]), torch.sigmoid(g[:, H:2 * H]), torch.tanh(g[:, 2 * H:3 * H]), torch.sigmoid(g[:, 3 * H:])
+        cn = f * c + i * gg
+        hn = o * torch.tanh(cn)
+        live = torch.ones(B, 1, dtype=torch.bool) if lengths is None else (t < lengths)[:, None]
+        c = torch.where(live, cn, c)
+        h = torch.where(live, hn, h)
+        out[:, t] = torch.where(live, hn, torch.zeros_like(hn))
+    return out
+
+
 def decoder_forward(x: torch.Tensor, lengths: Optional[torch.Tensor], p: Params, pre: str = "decoder.") -> torch.Tensor:
-    """Decoder.forward in eval mode, decoder.py:15-27 (stock torch LSTM; not a HIP target)."""
-    hid = p[pre + "lstm.weight_hh_l0"].shape[1]
-    lstm = torch.nn.LSTM(x.shape[-1], hid, 1, batch_first=True).to(x.dtype)
-    with torch.no_grad():
-        for n in ("weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0"):
-            getattr(lstm, n).copy_(p[pre + "lstm." + n])
-    with torch.no_grad():
-        if lengths is not None:
-            pk = torch.nn.utils.rnn.pack_padded_sequence(x, lengths.cpu(), batch_first=True, enforce_sorted=False)
-            y, _ = lstm(pk)
-            y, _ = torch.nn.utils.rnn.pad_packed_sequence(y, batch_first=True)
-        else:
-            y, _ = lstm(x)
+    """Decoder.forward in eval mode, decoder.py:15-27: packed LSTM -> Swish -> BatchNorm1d(running stats) -> Linear."""
+    y = x
+    k = 0
+    while pre + f"lstm.weight_ih_l{k}" in p:
+        y = lstm_layer(y, None if lengths is None else lengths.cpu(), p[pre + f"lstm.weight_ih_l{k}"], p[pre + f"lstm.weight_hh_l{k}"],
+                       p[pre + f"lstm.bias_ih_l{k}"], p[pre + f"lstm.bias_hh_l{k}"])
+        k += 1
     y = swish(y)
     y = (y - p[pre + "norm.running_mean"]) / torch.sqrt(p[pre + "norm.running_var"] + BN_EPS) \
         * p[pre + "norm.weight"] + p[pre + "norm.bias"]

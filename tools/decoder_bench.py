@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Decoder forward (LSTM 512->640, Swish, BatchNorm eval, Linear 640->370) at cfg-2 shapes: gfx950 kernels vs the stock
+PyTorch-ROCm modules (MIOpen LSTM) the reference would run.  Wall time per call incl. host issue, and device time."""
+import json
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from model.modules.decoder import Decoder  # noqa: E402
+
+
+def main():
+    B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    dec = Decoder(370, 512, 640, 1).to(dev).eval()
+    x = torch.randn(B, 249, 512, device=dev)
+    L = torch.full((B,), 249, dtype=torch.int64, device=dev)
+    L[B // 2:] = 200
+    res = {}
+    with torch.no_grad():
+        for name, fn in (("hip", lambda: dec.fused(x, L)), ("stock_miopen", lambda: torch.nn.Module.__call__(dec, x, L))):
+            if name == "stock_miopen":
+                dec._hip_eligible = lambda _x: False
+            for _ in range(3):
+                fn()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                y = fn()
+            e1.record()
+            torch.cuda.synchronize()
+            res[name] = {"wall_ms": (time.perf_counter() - t0) / 10 * 1e3, "device_ms": e0.elapsed_time(e1) / 10}
+            res[name + "_out"] = y
+    err = float((res.pop("hip_out") - res.pop("stock_miopen_out")).abs().max())
+    print(json.dumps({"what": f"decoder forward B={B} T'=249 512->640->370, eval", **res, "max_abs_diff": err}))
+
+
+if __name__ == "__main__":
+    main()
