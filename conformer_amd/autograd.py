@@ -217,3 +217,47 @@ def needs_grad(module: torch.nn.Module, *tensors: Optional[torch.Tensor]) -> boo
         return False
     return any(isinstance(t, torch.Tensor) and t.requires_grad for t in tensors) or \
         any(p.requires_grad for p in module.parameters())
+
+
+class LstmFn(Function):
+    """One nn.LSTM(batch_first) layer over a packed batch (decoder.py:10,17-22): GEMM + per-frame recurrence kernels
+    forward, back-propagation through time + three GEMMs backward (csrc/lstm.hip)."""
+
+    @staticmethod
+    @_fwd_prec
+    def forward(ctx, x, w_ih, w_hh, b_ih, b_hh, lengths):
+        bias = b_ih + b_hh
+        y, gates, cells = ops.lstm_forward(x, w_ih, w_hh, bias, lengths, save=True)
+        ctx.save_for_backward(x, w_ih, w_hh, y, gates, cells)
+        ctx.lengths = lengths
+        return y
+
+    @staticmethod
+    @_bwd_prec
+    def backward(ctx, dy):
+        x, w_ih, w_hh, y, gates, cells = ctx.saved_tensors
+        dx, dw_ih, dw_hh, db = ops.lstm_backward(x, w_ih, w_hh, y, gates, cells, dy.contiguous(), ctx.lengths,
+                                                 need_dx=ctx.needs_input_grad[0])
+        return dx, dw_ih, dw_hh, db, db, None
+
+
+class SwishBatchNormFn(Function):
+    """BatchNorm1d(swish(h)) over the channel-last (B,T,C) tensor (decoder.py:23-26): eval = running statistics,
+    train = batch statistics over all B*T rows + running update + coupled backward."""
+
+    @staticmethod
+    def forward(ctx, h, weight, bias, running_mean, running_var, train_bn, momentum, eps):
+        if train_bn:
+            mean, var = ops.swish_bn_batch_stats(h, running_mean, running_var, momentum)
+        else:
+            mean, var = running_mean, running_var
+        z = ops.swish_bn_eval(h, mean, var, weight, bias, eps)
+        ctx.save_for_backward(h, weight, mean, var)
+        ctx.train_bn, ctx.eps = bool(train_bn), eps
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        h, weight, mean, var = ctx.saved_tensors
+        dh, dga, dbe = ops.swish_bn_bwd(h, dz.contiguous(), mean, var, weight, ctx.eps, ctx.train_bn)
+        return dh, dga, dbe, None, None, None, None, None

@@ -107,6 +107,94 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(const LstmArgs a, const 
     }
 }
 
+// ---- backward through time ---------------------------------------------------------------------------------------------
+// Step t (T-1 .. 0), one launch:  dh_rec[b,u] = sum_r dG_{t+1}[b,r] * W_hh[r,u]   (dG = gradients of the gate
+// pre-activations; contraction over the 4H gate rows, W_hh^T rows are contiguous in `whh_t`), then for the workgroup's
+// 16 hidden units:  dh = dy_t + dh_rec;  do = dh*tanh(c_t)*o(1-o);  dc = dh*o*(1-tanh^2 c_t) + dc_next;
+// di = dc*g*i(1-i);  df = dc*c_{t-1}*f(1-f);  dg = dc*i*(1-g^2);  dc_next = dc*f.   Frames beyond an utterance's length
+// carry no gradient (dG = 0, dc = 0).  8 waves split the contraction; partial 16x16 tiles are summed through LDS.
+struct LstmBwdArgs {
+    const float* dy;              // (B, T, H)
+    const float* gates;           // (B, T, 4H) saved i|f|g|o
+    const float* cells;           // (B, T, H)  saved c_t
+    const float* whh_t;           // (H, 4H) = W_hh^T
+    const int64_t* lengths;
+    float* dgates;                // (B, T, 4H) out
+    float* dc;                    // (B, H) running dc_next, in place
+    int B, T, H;
+};
+
+template <int RB>
+__global__ __launch_bounds__(512) void lstm_bwd_step_kernel(const LstmBwdArgs a, const int t) {
+    __shared__ float part[8][RB * 16][17];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l16 = lane & 15, kq = lane >> 4;
+    const int u0 = blockIdx.x * 16;
+    const int b0 = blockIdx.y * (RB * 16);
+    const int H = a.H, H4 = 4 * a.H;
+
+    f32x4 acc[RB];
+#pragma unroll
+    for (int r = 0; r < RB; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (t + 1 < a.T) {
+        const int unit = u0 + l16;
+        const float* wrow = a.whh_t + (int64_t)min(unit, H - 1) * H4;
+        const float* grow[RB];
+        bool gok[RB];
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+            const int b = b0 + 16 * r + l16;
+            gok[r] = b < a.B;
+            grow[r] = a.dgates + ((int64_t)min(b, a.B - 1) * a.T + (t + 1)) * H4;
+        }
+        const int nchunk = H4 / 16;                              // H % 4 == 0 -> 4H % 16 == 0
+        for (int ch = wave; ch < nchunk; ch += 8) {
+            const int k = 16 * ch + 4 * kq;
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            const f32x4 wv = unit < H ? *reinterpret_cast<const f32x4*>(wrow + k) : z;
+            f32x4 gv[RB];
+#pragma unroll
+            for (int r = 0; r < RB; ++r) gv[r] = gok[r] ? *reinterpret_cast<const f32x4*>(grow[r] + k) : z;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int r = 0; r < RB; ++r) acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(gv[r][e], wv[e], acc[r], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < RB; ++r)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) part[wave][16 * r + 4 * kq + i][l16] = acc[r][i];
+    __syncthreads();
+    for (int e = tid; e < RB * 16 * 16; e += 512) {              // one (utterance, unit) per thread
+        const int bl = e >> 4, u = e & 15;
+        const int b = b0 + bl, unit = u0 + u;
+        if (b >= a.B || unit >= H) continue;
+        float* dg = a.dgates + ((int64_t)b * a.T + t) * H4 + unit;
+        const bool live = !a.lengths || t < a.lengths[b];
+        if (!live) {
+            dg[0] = 0.f; dg[H] = 0.f; dg[2 * H] = 0.f; dg[3 * H] = 0.f;
+            a.dc[(int64_t)b * H + unit] = 0.f;
+            continue;
+        }
+        float dh = a.dy[((int64_t)b * a.T + t) * H + unit];
+#pragma unroll
+        for (int w = 0; w < 8; ++w) dh += part[w][bl][u];
+        const float* sg = a.gates + ((int64_t)b * a.T + t) * H4 + unit;
+        const float ig = sg[0], fg = sg[H], gg = sg[2 * H], og = sg[3 * H];
+        const float ct = a.cells[((int64_t)b * a.T + t) * H + unit];
+        const float cprev = t > 0 ? a.cells[((int64_t)b * a.T + t - 1) * H + unit] : 0.f;
+        const float th = tanh_precise(ct);
+        const float dcn = t + 1 < a.T ? a.dc[(int64_t)b * H + unit] : 0.f;
+        const float dct = dh * og * (1.0f - th * th) + dcn;
+        dg[0] = dct * gg * ig * (1.0f - ig);
+        dg[H] = dct * cprev * fg * (1.0f - fg);
+        dg[2 * H] = dct * ig * (1.0f - gg * gg);
+        dg[3 * H] = dh * th * og * (1.0f - og);
+        a.dc[(int64_t)b * H + unit] = dct * fg;
+    }
+}
+
 // y = BatchNorm1d(eval)(swish(h)) per channel (decoder.py:23-26 with running statistics)
 __global__ __launch_bounds__(256) void swish_bn_eval_kernel(const float* __restrict__ h, const float* __restrict__ mean,
                                                             const float* __restrict__ var, const float* __restrict__ w,
@@ -121,6 +209,93 @@ __global__ __launch_bounds__(256) void swish_bn_eval_kernel(const float* __restr
     for (int e = 0; e < 4; ++e)
         o[e] = (swishf_acc(x[e]) - mean[c + e]) * (1.0f / sqrtf(var[c + e] + eps)) * w[c + e] + b[c + e];
     reinterpret_cast<f32x4*>(out)[i] = o;
+}
+
+// ---- Swish + BatchNorm1d in train mode (decoder.py:23-26 under .train()): batch statistics over all B*T rows (padded
+// frames included, as the reference does), running-statistics update, and the coupled backward.
+//   RMODE 0: out0[c] += sum swish(h)            RMODE 1: out0[c] += sum (swish(h) - mean[c])^2
+//   RMODE 2: out0[c] (dgamma) += sum dz*xhat ;  out1[c] (dbeta) += sum dz          xhat = (swish(h) - mean[c]) * inv[c]
+// block = 64 channels (16 lanes x float4) x 16 row lanes x 64 rows; LDS combine; one atomic per channel per workgroup.
+template <int RMODE>
+__global__ __launch_bounds__(256) void swish_bn_reduce_kernel(const float* __restrict__ h, const float* __restrict__ dz,
+                                                              const float* __restrict__ mean, const float* __restrict__ var,
+                                                              float eps, int64_t rows, int C, float* __restrict__ out0,
+                                                              float* __restrict__ out1) {
+    __shared__ float red[2][16][64];
+    const int cq = threadIdx.x & 15, ry = threadIdx.x >> 4;
+    const int c = blockIdx.x * 64 + cq * 4;
+    const int64_t r0 = (int64_t)blockIdx.y * 64, r1 = min(rows, r0 + 64);
+    f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+    if (c < C) {
+        f32x4 mu = {0.f, 0.f, 0.f, 0.f}, inv = {1.f, 1.f, 1.f, 1.f};
+        if (RMODE >= 1) mu = *reinterpret_cast<const f32x4*>(mean + c);
+        if (RMODE == 2) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(var + c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) inv[e] = 1.0f / sqrtf(v[e] + eps);
+        }
+        for (int64_t r = r0 + ry; r < r1; r += 16) {
+            const f32x4 x = *reinterpret_cast<const f32x4*>(h + r * C + c);
+            f32x4 d = {0.f, 0.f, 0.f, 0.f};
+            if (RMODE == 2) d = *reinterpret_cast<const f32x4*>(dz + r * C + c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float s = swishf_acc(x[e]);
+                if (RMODE == 0) a0[e] += s;
+                if (RMODE == 1) a0[e] += (s - mu[e]) * (s - mu[e]);
+                if (RMODE == 2) { a0[e] += d[e] * (s - mu[e]) * inv[e]; a1[e] += d[e]; }
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { red[0][ry][cq * 4 + e] = a0[e]; red[1][ry][cq * 4 + e] = a1[e]; }
+    __syncthreads();
+    const int cx = threadIdx.x & 63, which = threadIdx.x >> 6;
+    const int cc = blockIdx.x * 64 + cx;
+    if (which < (RMODE == 2 ? 2 : 1) && cc < C) {
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) s += red[which][j][cx];
+        atomicAdd((which == 0 ? out0 : out1) + cc, s);
+    }
+}
+
+__global__ void dec_bn_mean_kernel(float* __restrict__ sum_to_mean, float inv_n, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < C) sum_to_mean[c] *= inv_n;
+}
+__global__ void dec_bn_var_kernel(float* __restrict__ m2_to_var, const float* __restrict__ mean, float* __restrict__ run_mean,
+                                  float* __restrict__ run_var, float inv_n, float unbias, float momentum, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float var = m2_to_var[c] * inv_n;
+    m2_to_var[c] = var;
+    if (run_mean) run_mean[c] = (1.0f - momentum) * run_mean[c] + momentum * mean[c];
+    if (run_var) run_var[c] = (1.0f - momentum) * run_var[c] + momentum * var * unbias;
+}
+
+// dh = swish'(h) * gamma*inv * (dz - inv_n*(dbeta + xhat*dgamma))      (inv_n = 0: fixed statistics)
+__global__ __launch_bounds__(256) void swish_bn_bwd_kernel(const float* __restrict__ h, const float* __restrict__ dz,
+                                                           const float* __restrict__ mean, const float* __restrict__ var,
+                                                           const float* __restrict__ w, const float* __restrict__ dgamma,
+                                                           const float* __restrict__ dbeta, float eps, float inv_n,
+                                                           float* __restrict__ dh, int64_t n4, int C) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    const int c = (int)((4 * i) % C);
+    const f32x4 x = reinterpret_cast<const f32x4*>(h)[i];
+    const f32x4 d = reinterpret_cast<const f32x4*>(dz)[i];
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float sg = sigmoidf_acc(x[e]);
+        const float s = x[e] * sg;
+        const float inv = 1.0f / sqrtf(var[c + e] + eps);
+        const float xh = (s - mean[c + e]) * inv;
+        const float ds = w[c + e] * inv * (d[e] - inv_n * (dbeta[c + e] + xh * dgamma[c + e]));
+        o[e] = ds * sg * (1.0f + x[e] * (1.0f - sg));
+    }
+    reinterpret_cast<f32x4*>(dh)[i] = o;
 }
 
 }  // namespace
@@ -147,6 +322,27 @@ extern "C" int cfm_lstm_fwd_f32(const float* gates_x, const float* w_hh, const i
     return cfm_launch_status();
 }
 
+// Backward of cfm_lstm_fwd_f32 through time: dy (B,T,H) = gradient w.r.t. y; gates / cells as saved by the forward;
+// whh_t (H,4H) = W_hh transposed; dgates (B,T,4H) <- gradient w.r.t. the gate pre-activations (= w.r.t. gates_x: the
+// caller's GEMMs turn it into dX, dW_ih, dW_hh, db); dc_state (B,H) scratch.  Enqueues T launches (t = T-1 .. 0).
+extern "C" int cfm_lstm_bwd_f32(const float* dy, const float* gates, const float* cells, const float* whh_t,
+                                const int64_t* lengths_or_null, float* dgates, float* dc_state, int B, int T, int H,
+                                cfm_stream_t stream) {
+    CFM_REQUIRE(dy && gates && cells && whh_t && dgates && dc_state, CFM_ERR_NULL);
+    CFM_REQUIRE(B > 0 && T > 0 && H > 0 && (H & 3) == 0, CFM_ERR_BAD_SHAPE);
+    CFM_REQUIRE(CFM_ALIGNED16(whh_t) && CFM_ALIGNED16(dgates), CFM_ERR_ALIGN);
+    const LstmBwdArgs a{dy, gates, cells, whh_t, lengths_or_null, dgates, dc_state, B, T, H};
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int rb = B <= 16 ? 1 : (B <= 32 ? 2 : 4);
+    const dim3 grid((unsigned)((H + 15) / 16), (unsigned)((B + 16 * rb - 1) / (16 * rb)));
+    for (int t = T - 1; t >= 0; --t) {
+        if (rb == 1) hipLaunchKernelGGL(lstm_bwd_step_kernel<1>, grid, dim3(512), 0, s, a, t);
+        else if (rb == 2) hipLaunchKernelGGL(lstm_bwd_step_kernel<2>, grid, dim3(512), 0, s, a, t);
+        else hipLaunchKernelGGL(lstm_bwd_step_kernel<4>, grid, dim3(512), 0, s, a, t);
+    }
+    return cfm_launch_status();
+}
+
 extern "C" int cfm_swish_bn_eval_f32(const float* h, const float* bn_mean, const float* bn_var, const float* bn_weight,
                                      const float* bn_bias, float eps, float* out, int64_t rows, int C, cfm_stream_t stream) {
     CFM_REQUIRE(h && bn_mean && bn_var && bn_weight && bn_bias && out, CFM_ERR_NULL);
@@ -155,5 +351,46 @@ extern "C" int cfm_swish_bn_eval_f32(const float* h, const float* bn_mean, const
     const int64_t n4 = rows * C / 4;
     hipLaunchKernelGGL(swish_bn_eval_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
                        h, bn_mean, bn_var, bn_weight, bn_bias, eps, out, n4, C);
+    return cfm_launch_status();
+}
+
+// Batch statistics of swish(h) over `rows` rows (decoder.py:25 in .train()): batch_mean, batch_var (biased); the running
+// buffers (may be NULL) are updated with `momentum` and the unbiased variance.  Normalise with cfm_swish_bn_eval_f32
+// (bn_mean = batch_mean, bn_var = batch_var).  C % 4 == 0.
+extern "C" int cfm_swish_bn_stats_f32(const float* h, float* batch_mean, float* batch_var, float* running_mean_or_null,
+                                      float* running_var_or_null, float momentum, int64_t rows, int C, cfm_stream_t stream) {
+    CFM_REQUIRE(h && batch_mean && batch_var, CFM_ERR_NULL);
+    CFM_REQUIRE(rows > 0 && C > 0 && (C & 3) == 0, CFM_ERR_BAD_SHAPE);
+    CFM_REQUIRE(CFM_ALIGNED16(h) && CFM_ALIGNED16(batch_mean), CFM_ERR_ALIGN);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const dim3 grid((unsigned)((C + 63) / 64), (unsigned)((rows + 63) / 64));
+    const unsigned cb = (unsigned)((C + 255) / 256);
+    if (hipMemsetAsync(batch_mean, 0, sizeof(float) * C, s) != hipSuccess) return CFM_ERR_LAUNCH;
+    if (hipMemsetAsync(batch_var, 0, sizeof(float) * C, s) != hipSuccess) return CFM_ERR_LAUNCH;
+    hipLaunchKernelGGL(swish_bn_reduce_kernel<0>, grid, dim3(256), 0, s, h, nullptr, nullptr, nullptr, 0.f, rows, C, batch_mean,
+                       nullptr);
+    hipLaunchKernelGGL(dec_bn_mean_kernel, dim3(cb), dim3(256), 0, s, batch_mean, 1.0f / (float)rows, C);
+    hipLaunchKernelGGL(swish_bn_reduce_kernel<1>, grid, dim3(256), 0, s, h, nullptr, batch_mean, nullptr, 0.f, rows, C, batch_var,
+                       nullptr);
+    hipLaunchKernelGGL(dec_bn_var_kernel, dim3(cb), dim3(256), 0, s, batch_var, batch_mean, running_mean_or_null,
+                       running_var_or_null, 1.0f / (float)rows, rows > 1 ? (float)rows / (float)(rows - 1) : 1.0f, momentum, C);
+    return cfm_launch_status();
+}
+
+// Backward of z = BatchNorm(swish(h)): dh, dgamma, dbeta (the latter two accumulated: caller zero-fills).  train_stats = 1:
+// bn_mean / bn_var are the batch statistics and the mean/variance coupling is applied; 0: running statistics (constants).
+extern "C" int cfm_swish_bn_bwd_f32(const float* h, const float* dz, const float* bn_mean, const float* bn_var,
+                                    const float* bn_weight, float eps, int train_stats, float* dh, float* dgamma,
+                                    float* dbeta, int64_t rows, int C, cfm_stream_t stream) {
+    CFM_REQUIRE(h && dz && bn_mean && bn_var && bn_weight && dh && dgamma && dbeta, CFM_ERR_NULL);
+    CFM_REQUIRE(rows > 0 && C > 0 && (C & 3) == 0, CFM_ERR_BAD_SHAPE);
+    CFM_REQUIRE(CFM_ALIGNED16(h) && CFM_ALIGNED16(dz) && CFM_ALIGNED16(dh) && CFM_ALIGNED16(bn_mean) && CFM_ALIGNED16(bn_var),
+                CFM_ERR_ALIGN);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const dim3 grid((unsigned)((C + 63) / 64), (unsigned)((rows + 63) / 64));
+    hipLaunchKernelGGL(swish_bn_reduce_kernel<2>, grid, dim3(256), 0, s, h, dz, bn_mean, bn_var, eps, rows, C, dgamma, dbeta);
+    const int64_t n4 = rows * C / 4;
+    hipLaunchKernelGGL(swish_bn_bwd_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, h, dz, bn_mean, bn_var,
+                       bn_weight, dgamma, dbeta, eps, train_stats ? 1.0f / (float)rows : 0.f, dh, n4, C);
     return cfm_launch_status();
 }

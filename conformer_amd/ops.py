@@ -393,6 +393,10 @@ def linear_bwd(x2d, w, dy2d, *, alpha: float = 1.0, Z=None, need_dx: bool = True
     w2 = w.reshape(n, -1)
     dx = None
     prec = mfma16_prec()
+    if dy2d.stride(0) & 3:                        # e.g. the vocabulary projection (N = 370): rows must start 16-byte aligned
+        padded = torch.zeros(m, (n + 3) // 4 * 4, device=dy2d.device, dtype=dy2d.dtype)
+        padded[:, :n] = dy2d
+        dy2d = padded[:, :n]
     if need_dx:
         dx = gemm_bwd(dy2d, False, w2, True, m, k, n, alpha=alpha, Z=Z, drop_p=drop_p, drop_seed=drop_seed, prec=prec)
     dw, db = _zeros_split(x2d.device, x2d.dtype, (n, k), (n,))
@@ -599,3 +603,51 @@ def swish_bn_eval(h, bn_mean, bn_var, bn_weight, bn_bias, eps: float = 1e-5):
                                                  _req(bn_bias, "bn_bias").data_ptr(), eps, out.data_ptr(), h.numel() // C, C,
                                                  _stream()), "cfm_swish_bn_eval_f32")
     return out
+
+
+def lstm_backward(x, w_ih, w_hh, y, gates, cells, dy, lengths=None, need_dx: bool = True):
+    """Backward of lstm_forward(save=True): returns (dx or None, dw_ih, dw_hh, dbias) with dbias = d/d(b_ih) = d/d(b_hh).
+    The time recursion yields dG (B,T,4H); the weight / input gradients are dense GEMMs over all frames."""
+    lib = _lib.load()
+    B, T, D = x.shape
+    H = w_hh.shape[1]
+    dy = _req(dy, "dy")
+    whh_t = w_hh.t().contiguous()                                     # (H,4H): 6.5 MB of glue per step
+    dG = torch.empty(B, T, 4 * H, device=x.device, dtype=x.dtype)
+    dc = torch.empty(B, H, device=x.device, dtype=x.dtype)
+    _lib.check(lib.cfm_lstm_bwd_f32(dy.data_ptr(), gates.data_ptr(), cells.data_ptr(), whh_t.data_ptr(), _p(lengths),
+                                    dG.data_ptr(), dc.data_ptr(), B, T, H, _stream()), "cfm_lstm_bwd_f32")
+    dG2, x2 = dG.view(B * T, 4 * H), x.reshape(B * T, D)
+    h_prev = torch.zeros_like(y)                                      # h_{t-1}: y shifted by one frame per utterance
+    h_prev[:, 1:] = y[:, :-1]
+    prec = mfma16_prec()
+    dx = gemm_bwd(dG2, False, w_ih, True, B * T, D, 4 * H, prec=prec).view(B, T, D) if need_dx else None
+    dw_ih, dw_hh, db = _zeros_split(x.device, x.dtype, (4 * H, D), (4 * H, H), (4 * H,))
+    gemm_bwd(dG2, True, x2, True, 4 * H, D, B * T, allow_split=True, out=dw_ih, prec=prec)
+    gemm_bwd(dG2, True, h_prev.view(B * T, H), True, 4 * H, H, B * T, allow_split=True, out=dw_hh, prec=prec)
+    colsum(dG2, out=db)
+    return dx, dw_ih, dw_hh, db
+
+
+def swish_bn_batch_stats(h, running_mean, running_var, momentum: float = 0.1):
+    """Train-mode BatchNorm statistics of swish(h) over all rows; updates the running buffers in place."""
+    h = _req(h, "h")
+    C = h.shape[-1]
+    mean = torch.empty(C, device=h.device, dtype=h.dtype)
+    var = torch.empty(C, device=h.device, dtype=h.dtype)
+    _lib.check(_lib.load().cfm_swish_bn_stats_f32(h.data_ptr(), mean.data_ptr(), var.data_ptr(), _p(running_mean),
+                                                  _p(running_var), momentum, h.numel() // C, C, _stream()),
+               "cfm_swish_bn_stats_f32")
+    return mean, var
+
+
+def swish_bn_bwd(h, dz, bn_mean, bn_var, bn_weight, eps: float = 1e-5, train_stats: bool = False):
+    """Returns (dh, dgamma, dbeta)."""
+    h = _req(h, "h"); dz = _req(dz, "dz")
+    C = h.shape[-1]
+    dh = torch.empty_like(h)
+    dga, dbe = _zeros_split(h.device, h.dtype, (C,), (C,))
+    _lib.check(_lib.load().cfm_swish_bn_bwd_f32(h.data_ptr(), dz.data_ptr(), bn_mean.data_ptr(), bn_var.data_ptr(),
+                                                bn_weight.data_ptr(), eps, int(train_stats), dh.data_ptr(), dga.data_ptr(),
+                                                dbe.data_ptr(), h.numel() // C, C, _stream()), "cfm_swish_bn_bwd_f32")
+    return dh, dga, dbe

@@ -283,11 +283,22 @@ int cfm_greedy_ctc_decode_f32(const float* logits, const int64_t* lengths_or_nul
 /* N1 decoder (decoder.py:10-27): LSTM recurrence over a packed batch.  gates_x (B,T,4H) = X.W_ih^T + b_ih + b_hh from
  *      one of the GEMM entries; w_hh (4H,H), gate order i|f|g|o; lengths_or_null: frames per utterance (outputs beyond are
  *      0, as pad_packed_sequence returns); y (B,T,H) <- h_t; c_state (B,H) scratch; save_* (B,T,4H)/(B,T,H) or NULL.
- *      H % 4 == 0.  cfm_swish_bn_eval_f32: out = BatchNorm1d(eval)(swish(h)) per channel, rows x C. */
+ *      H % 4 == 0.  cfm_lstm_bwd_f32: dy (B,T,H) -> dgates (B,T,4H) = gradient w.r.t. gates_x, from the saved gates /
+ *      cells and whh_t (H,4H) = W_hh^T; dc_state (B,H) scratch.  cfm_swish_bn_eval_f32: out = BatchNorm1d(eval)(swish(h)) per channel, rows x C. */
 int cfm_lstm_fwd_f32(const float* gates_x, const float* w_hh, const int64_t* lengths_or_null, float* y, float* c_state,
                      float* save_gates_or_null, float* save_c_or_null, int B, int T, int H, cfm_stream_t stream);
+int cfm_lstm_bwd_f32(const float* dy, const float* gates, const float* cells, const float* whh_t,
+                     const int64_t* lengths_or_null, float* dgates, float* dc_state, int B, int T, int H,
+                     cfm_stream_t stream);
 int cfm_swish_bn_eval_f32(const float* h, const float* bn_mean, const float* bn_var, const float* bn_weight,
                           const float* bn_bias, float eps, float* out, int64_t rows, int C, cfm_stream_t stream);
+/*      train mode: cfm_swish_bn_stats_f32 = batch mean / biased variance of swish(h) (+ running update), then
+ *      cfm_swish_bn_eval_f32 with those; cfm_swish_bn_bwd_f32: dh + accumulated dgamma, dbeta (caller zero-fills). */
+int cfm_swish_bn_stats_f32(const float* h, float* batch_mean, float* batch_var, float* running_mean_or_null,
+                           float* running_var_or_null, float momentum, int64_t rows, int C, cfm_stream_t stream);
+int cfm_swish_bn_bwd_f32(const float* h, const float* dz, const float* bn_mean, const float* bn_var,
+                         const float* bn_weight, float eps, int train_stats, float* dh, float* dgamma, float* dbeta,
+                         int64_t rows, int C, cfm_stream_t stream);
 
 /* diagnostics only: cfm_relpos_attention_fwd_f32 + s_memrealtime stamps of one wave (trace: 16*ceil(T/32) uint64) */
 int cfm_debug_attention_trace_f32(const float* q, const float* k, const float* v, int64_t ld, const float* pos,

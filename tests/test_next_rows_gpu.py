@@ -110,7 +110,83 @@ def test_decoder_eval_runs_on_hip_and_matches_oracle(dev):
         y = dec(x.to(dev), L.to(dev))
     assert rel_l2(y, ref) < 2e-5
     assert torch.equal(y.argmax(-1).cpu(), ref.argmax(-1))
-    # training mode keeps the stock modules (documented limit): same numbers up to BatchNorm mode, so only check it runs
-    dec.train()
-    out = dec(x.to(dev), L.to(dev))
-    assert out.shape == y.shape and out.requires_grad
+    # the stock-module path (CPU tensors) computes the same function
+    cpu = Decoder(370, 144, 320, 1).eval()
+    cpu.load_state_dict(dec.state_dict())
+    with torch.no_grad():
+        assert rel_l2(cpu(x, L), ref) < 2e-5
+
+
+@pytest.mark.parametrize("B,T,D,H,ragged", [(1, 1, 16, 8, False), (3, 25, 32, 8, True), (2, 49, 144, 320, True),
+                                            (32, 30, 64, 640, True), (40, 12, 64, 36, True), (70, 7, 32, 16, False)])
+def test_lstm_backward_vs_oracle_autograd(dev, B, T, D, H, ragged):
+    """N1 training: BPTT kernels + GEMMs vs torch autograd through the float64 written-out LSTM."""
+    from conformer_amd.autograd import LstmFn
+    g = torch.Generator().manual_seed(B * 100 + T + 1)
+    x = torch.randn(B, T, D, generator=g)
+    k = 1.0 / H ** 0.5
+    ps = [(torch.rand(4 * H, D, generator=g) * 2 - 1) * k, (torch.rand(4 * H, H, generator=g) * 2 - 1) * k,
+          (torch.rand(4 * H, generator=g) * 2 - 1) * k, (torch.rand(4 * H, generator=g) * 2 - 1) * k]
+    L = None
+    if ragged:
+        L = torch.sort(torch.randint(1, T + 1, (B,), generator=g), descending=True).values
+        L[0] = T
+    w = torch.randn(B, T, H, generator=g)
+    xr = x.double().requires_grad_(True)
+    pr = [p.double().requires_grad_(True) for p in ps]
+    (O.lstm_layer(xr, L, *pr) * w.double()).sum().backward()
+    xd = x.to(dev).requires_grad_(True)
+    pd = [p.to(dev).requires_grad_(True) for p in ps]
+    y = LstmFn.apply(xd, *pd, None if L is None else L.to(dev))
+    (y * w.to(dev)).sum().backward()
+    assert rel_l2(xd.grad, xr.grad) < 2e-5
+    for a, b, name in zip(pd, pr, ("w_ih", "w_hh", "b_ih", "b_hh")):
+        assert rel_l2(a.grad, b.grad) < 2e-5, name
+
+
+@pytest.mark.parametrize("train_bn", [False, True])
+def test_decoder_training_grads_vs_oracle_autograd(dev, train_bn):
+    """N1 training: the whole decoder (LSTM -> Swish -> BatchNorm -> Linear(370)) forward + backward on the gfx950 kernels
+    vs torch autograd through the float64 oracle (BatchNorm with running or with batch statistics)."""
+    from model.modules.decoder import Decoder
+    P = O.make_params(vocab=370, n_mel=80, n_blocks=0, d=64, n_heads=4, ksize=31, lstm_hidden=96, seed=4)
+    dec = Decoder(370, 64, 96, 1)
+    dec.load_state_dict({k[len("decoder."):]: v for k, v in P.items() if k.startswith("decoder.")}, strict=True)
+    dec = dec.to(dev).train()
+    if not train_bn:
+        dec.norm.eval()
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(5, 21, 64, generator=g)
+    L = torch.tensor([21, 21, 13, 8, 2])
+    w = torch.randn(5, 21, 370, generator=g)
+    # float64 oracle with autograd (train-mode BatchNorm written out: batch statistics over all B*T rows)
+    Pd = {k: (v.double().requires_grad_(True) if v.is_floating_point() else v) for k, v in P.items() if k.startswith("decoder.")}
+    xr = x.double().requires_grad_(True)
+    pre = "decoder."
+    y = O.lstm_layer(xr, L, Pd[pre + "lstm.weight_ih_l0"], Pd[pre + "lstm.weight_hh_l0"], Pd[pre + "lstm.bias_ih_l0"],
+                     Pd[pre + "lstm.bias_hh_l0"])
+    s = O.swish(y)
+    if train_bn:
+        flat = s.reshape(-1, s.shape[-1])
+        mean, var = flat.mean(0), flat.var(0, unbiased=False)
+    else:
+        mean, var = Pd[pre + "norm.running_mean"], Pd[pre + "norm.running_var"]
+    z = (s - mean) / torch.sqrt(var + 1e-5) * Pd[pre + "norm.weight"] + Pd[pre + "norm.bias"]
+    ref = z @ Pd[pre + "linear.weight"].t() + Pd[pre + "linear.bias"]
+    (ref * w.double()).sum().backward()
+    rm0 = dec.norm.running_mean.clone()
+    nbt0 = int(dec.norm.num_batches_tracked)
+    xd = x.to(dev).requires_grad_(True)
+    out = dec(xd, L.to(dev))
+    (out * w.to(dev)).sum().backward()
+    assert rel_l2(out, ref) < 2e-5
+    assert rel_l2(xd.grad, xr.grad) < 5e-5
+    for name, p in dec.named_parameters():
+        assert rel_l2(p.grad, Pd[pre + name].grad) < 5e-5, name
+    if train_bn:                                             # running statistics moved (momentum 0.1, unbiased variance)
+        n = 5 * 21
+        assert rel_l2(dec.norm.running_mean, 0.9 * rm0.cpu().double() + 0.1 * mean.detach()) < 1e-5
+        assert rel_l2(dec.norm.running_var, 0.9 * P[pre + "norm.running_var"].double() + 0.1 * var.detach() * n / (n - 1)) < 1e-5
+        assert int(dec.norm.num_batches_tracked) == nbt0 + 1
+    else:
+        assert torch.equal(dec.norm.running_mean, rm0)
