@@ -312,13 +312,8 @@ extern "C" int cfm_lstm_fwd_f32(const float* gates_x, const float* w_hh, const i
     CFM_REQUIRE(CFM_ALIGNED16(w_hh) && CFM_ALIGNED16(y), CFM_ERR_ALIGN);
     const LstmArgs a{gates_x, w_hh, lengths_or_null, y, c_state, save_gates_or_null, save_c_or_null, B, T, H};
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const int rb = B <= 16 ? 1 : (B <= 32 ? 2 : 4);
-    const dim3 grid((unsigned)(H / 4), (unsigned)((B + 16 * rb - 1) / (16 * rb)));
-    for (int t = 0; t < T; ++t) {
-        if (rb == 1) hipLaunchKernelGGL(lstm_step_kernel<1>, grid, dim3(256), 0, s, a, t);
-        else if (rb == 2) hipLaunchKernelGGL(lstm_step_kernel<2>, grid, dim3(256), 0, s, a, t);
-        else hipLaunchKernelGGL(lstm_step_kernel<4>, grid, dim3(256), 0, s, a, t);
-    }
+    const dim3 grid((unsigned)(H / 4), (unsigned)((B + 15) / 16));
+    for (int t = 0; t < T; ++t) hipLaunchKernelGGL(lstm_step_kernel<1>, grid, dim3(256), 0, s, a, t);
     return cfm_launch_status();
 }
 
@@ -333,13 +328,9 @@ extern "C" int cfm_lstm_bwd_f32(const float* dy, const float* gates, const float
     CFM_REQUIRE(CFM_ALIGNED16(whh_t) && CFM_ALIGNED16(dgates), CFM_ERR_ALIGN);
     const LstmBwdArgs a{dy, gates, cells, whh_t, lengths_or_null, dgates, dc_state, B, T, H};
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const int rb = B <= 16 ? 1 : (B <= 32 ? 2 : 4);
-    const dim3 grid((unsigned)((H + 15) / 16), (unsigned)((B + 16 * rb - 1) / (16 * rb)));
-    for (int t = T - 1; t >= 0; --t) {
-        if (rb == 1) hipLaunchKernelGGL(lstm_bwd_step_kernel<1>, grid, dim3(512), 0, s, a, t);
-        else if (rb == 2) hipLaunchKernelGGL(lstm_bwd_step_kernel<2>, grid, dim3(512), 0, s, a, t);
-        else hipLaunchKernelGGL(lstm_bwd_step_kernel<4>, grid, dim3(512), 0, s, a, t);
-    }
+    // 16 utterances x 16 hidden units per workgroup: the step is latency-bound, so more, smaller workgroups win
+    const dim3 grid((unsigned)((H + 15) / 16), (unsigned)((B + 15) / 16));
+    for (int t = T - 1; t >= 0; --t) hipLaunchKernelGGL(lstm_bwd_step_kernel<1>, grid, dim3(512), 0, s, a, t);
     return cfm_launch_status();
 }
 

@@ -38,6 +38,29 @@ def main():
             res[name] = {"wall_ms": (time.perf_counter() - t0) / 10 * 1e3, "device_ms": e0.elapsed_time(e1) / 10}
             res[name + "_out"] = y
     err = float((res.pop("hip_out") - res.pop("stock_miopen_out")).abs().max())
+    # training direction: forward + backward through the decoder (LSTM BPTT, Swish+BN train, vocabulary GEMM)
+    dec._hip_eligible = type(dec)._hip_eligible.__get__(dec)
+    dec.train()
+    xg = x.clone().requires_grad_(True)
+    w = torch.randn(B, 249, 370, device=dev)
+    for name in ("hip_train", "stock_train"):
+        if name == "stock_train":
+            dec._hip_eligible = lambda _x: False
+        def step():
+            for p in dec.parameters():
+                p.grad = None
+            (dec(xg, L) * w).sum().backward()
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        e0.record()
+        for _ in range(5):
+            step()
+        e1.record()
+        torch.cuda.synchronize()
+        res[name] = {"wall_ms": (time.perf_counter() - t0) / 5 * 1e3, "device_ms": e0.elapsed_time(e1) / 5}
     print(json.dumps({"what": f"decoder forward B={B} T'=249 512->640->370, eval", **res, "max_abs_diff": err}))
 
 
