@@ -453,7 +453,9 @@ def relpos_attention_train(qkv, pos, u, v, lengths, n_heads, drop_p: float = 0.0
 
 def relpos_attention_bwd(qkv, pos, u, v, lengths, n_heads, ctx, lse, dctx, drop_p: float = 0.0, seed: int = 0):
     """Backward of the attention core.  Returns (dqkv (B,T,3d), dpos (2T-1,d), du (H,dh), dv (H,dh)).
-    Round-1 form: batched MFMA GEMMs over re-materialised (B,H,T,T) tensors (attention_bwd_f32.hip)."""
+    Round-1 form: batched MFMA GEMMs over re-materialised (B,H,T,T) tensors (attention_bwd_f32.hip).
+    Under autocast the products that are LINEAR in the incoming gradient (dP, dV, dK, dQ, dPos) run on the 16-bit matrix
+    pipe; the two score products stay fp32 so that the recomputed probabilities match the fp32 forward's log-sum-exp."""
     lib = _lib.load()
     B, T, d3 = qkv.shape
     d = d3 // 3
@@ -483,6 +485,7 @@ def relpos_attention_bwd(qkv, pos, u, v, lengths, n_heads, ctx, lse, dctx, drop_
     sBH_sq = (H * T * T4, T * T4)     # (b,h) offsets into (B,H,T,T4)
     sBH_pf = (T * P4, B * T * P4)     # (b,h) offsets into (H,B,T,P4)
     nb = B * H
+    lp = mfma16_prec()
     # content[b,h] = Qu_bh . K_bh^T        (T x T4; padded columns read clamped K rows, masked later)
     gemm_bwd(qu, False, qkv, False, T, T4, dh, out=content, lda=d, ldb=d3, ldc=T4, nbatch=nb, nb1=H,
              sa=sBH_rows, sb=sBH_qkv, sc=sBH_sq, b_ptr=kp)
@@ -491,7 +494,7 @@ def relpos_attention_bwd(qkv, pos, u, v, lengths, n_heads, ctx, lse, dctx, drop_
              sa=sBH_rows, sb=(0, dh), sc=sBH_pf)
     # dP[b,h] = dO_bh . V_bh^T
     gemm_bwd(dctx, False, qkv, False, T, T4, dh, out=dP, lda=d, ldb=d3, ldc=T4, nbatch=nb, nb1=H,
-             sa=sBH_rows, sb=sBH_qkv, sc=sBH_sq, b_ptr=vp)
+             sa=sBH_rows, sb=sBH_qkv, sc=sBH_sq, b_ptr=vp, prec=lp)
     _lib.check(lib.cfm_attn_softmax_bwd_f32(content.data_ptr(), posfull.data_ptr(), dP.data_ptr(), lse.data_ptr(),
                                             Dr.data_ptr(), _p(lengths), scale, B, T, H, T4, P4, float(drop_p), int(seed),
                                             _stream()),
@@ -501,24 +504,24 @@ def relpos_attention_bwd(qkv, pos, u, v, lengths, n_heads, ctx, lse, dctx, drop_
     dq_p = dqkv.data_ptr(); dk_p = dq_p + f * d; dv_p = dq_p + 2 * f * d
     # dV_bh = P_bh^T . dO_bh               (A = P contraction-major over queries; B = dO contraction-major)
     gemm_bwd(Pm, True, dctx, True, T, dh, T, out=dqkv, lda=T4, ldb=d, ldc=d3, nbatch=nb, nb1=H,
-             sa=sBH_sq, sb=sBH_rows, sc=sBH_qkv, c_ptr=dv_p)
+             sa=sBH_sq, sb=sBH_rows, sc=sBH_qkv, c_ptr=dv_p, prec=lp)
     # dK_bh = dS_bh^T . Qu_bh
     gemm_bwd(dS, True, qu, True, T, dh, T, out=dqkv, lda=T4, ldb=d, ldc=d3, nbatch=nb, nb1=H,
-             sa=sBH_sq, sb=sBH_rows, sc=sBH_qkv, c_ptr=dk_p)
+             sa=sBH_sq, sb=sBH_rows, sc=sBH_qkv, c_ptr=dk_p, prec=lp)
     # dQu_bh = dS_bh . K_bh                (contraction over keys: dS index-major, K contraction-major)
     gemm_bwd(dS, False, qkv, True, T, dh, T, out=dqkv, lda=T4, ldb=d3, ldc=d3, nbatch=nb, nb1=H,
-             sa=sBH_sq, sb=sBH_qkv, sc=sBH_qkv, b_ptr=kp, c_ptr=dq_p)
+             sa=sBH_sq, sb=sBH_qkv, sc=sBH_qkv, b_ptr=kp, c_ptr=dq_p, prec=lp)
     du, dvb, dpos = _zeros_split(dev, dt, (H, dh), (H, dh), (P, d))
     colsum(dqkv, rows=N, cols=d, ld=d3, out=du)
     # dQv_bh = dposfull_hb . Pm_h          (contraction over the 2T-1 relative positions)
     dqv = torch.empty(N, d, device=dev, dtype=dt)
     gemm_bwd(dpf, False, pos, True, T, dh, P, out=dqv, lda=P4, ldb=ldp, ldc=d, nbatch=nb, nb1=H,
-             sa=sBH_pf, sb=(0, dh), sc=sBH_rows)
+             sa=sBH_pf, sb=(0, dh), sc=sBH_rows, prec=lp)
     colsum(dqv, out=dvb)
     _lib.check(lib.cfm_add_strided_f32(dq_p, d3, dqv.data_ptr(), d, N, d, _stream()), "cfm_add_strided_f32")
     # dPm_h = sum_{b,i} dposfull_h[(b,i), :]^T . Qv_h[(b,i), :]     (contraction over B*T rows, split + atomics)
     gemm_bwd(dpf, True, qv, True, P, dh, N, out=dpos, lda=P4, ldb=d, ldc=d, allow_split=True, nbatch=H, nb1=H,
-             sa=(0, B * T * P4), sb=(0, dh), sc=(0, dh))
+             sa=(0, B * T * P4), sb=(0, dh), sc=(0, dh), prec=lp)
     return dqkv, dpos, du, dvb
 
 
