@@ -193,6 +193,27 @@ def test_encoder_cfg2_full_size_properties(dev):
     assert torch.equal(y2[:31], y[:31])
 
 
+def test_encoder_long_utterance_vs_oracle(dev):
+    """BASELINE cfg-5 input size (T = 20000 mel frames -> T' = 4999) as ONE non-streaming forward (the reference has no
+    chunked/streaming code): a 1-block d=144 encoder, B=2 ragged, against the oracle -- the maximum-size edge of the
+    stem, the relative-position table (9997 rows) and the attention ring."""
+    meta = dict(vocab=8, n_mel=80, n_blocks=1, d=144, n_heads=4, ksize=31, lstm_hidden=8, seed=12)
+    P = O.make_params(**meta, with_decoder=False)
+    from model.modules.encoder import Encoder
+    enc = Encoder(80, 1, 144, 4, 31, 0.0)
+    enc.load_state_dict({k[len("encoder."):]: v for k, v in P.items()}, strict=True)
+    enc = enc.to(dev).eval()
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 80, 20000, generator=g)
+    L = torch.tensor([20000, 12345])
+    with torch.no_grad(), torch.inference_mode():
+        y, L2 = enc(x.to(dev), L.to(dev))
+    with torch.no_grad():
+        ref, R2 = O.encoder_forward(x, L, P, 1, 4)
+    assert y.shape == (2, 4999, 144) and torch.equal(L2.cpu(), R2)
+    assert rel_l2(y, ref) < 1e-4
+
+
 def test_unbuilt_training_features_are_refused_loudly(dev):
     """No silent fallback: what has no kernels yet raises (train-mode dropout under no_grad; gradient w.r.t. the input)."""
     from model.modules.encoder import Encoder

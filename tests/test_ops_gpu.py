@@ -78,7 +78,8 @@ def test_relpos_table(ops, T, d):
 ATT_CASES = [  # B, T, H, dh, lengths
     (2, 1, 4, 8, [1, 1]), (3, 7, 4, 8, [7, 5, 1]), (2, 48, 4, 8, [48, 33]), (2, 49, 4, 36, [49, 39]),
     (2, 70, 1, 64, [70, 2]), (2, 33, 2, 16, None), (2, 130, 2, 32, [130, 64]), (2, 249, 8, 64, [249, 131]),
-    (1, 300, 2, 64, [300]),
+    (1, 300, 2, 64, [300]), (2, 40, 2, 8, [40, 0]),          # lengths 0: the reference's uniform-softmax degenerate case
+    (1, 4999, 1, 36, [4999]),                                # BASELINE cfg-5 utterance length (T = 20000 mel frames)
 ]
 
 
