@@ -14,8 +14,11 @@
 
 namespace {
 
-template <typename T16, int BM, int BN, bool AROW, bool BROW, int EPI, int GATHER = 0, bool SPLITK = false>
+// B16 (contraction-major B only): B is already stored in the 16-bit type (cached weight cast for dX = dY.W; a 16-bit
+// activation for dW): a thread loads a 4(k) x 8(index) block with four 16-byte loads and writes eight 8-byte k-runs.
+template <typename T16, int BM, int BN, bool AROW, bool BROW, int EPI, int GATHER = 0, bool SPLITK = false, bool B16 = false>
 __global__ __launch_bounds__(256, 2) void gemm_bwd_mfma16_kernel(const BwdArgs g) {
+    static_assert(!B16 || (!BROW && GATHER == 0), "16-bit B operand: contraction-major, no gather");
     using x8 = typename Lowp<T16>::x8;
     using x4 = typename Lowp<T16>::x4;
     constexpr int TM = BM / 64, TN = BN / 64, BK = 64;
@@ -34,6 +37,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bwd_mfma16_kernel(const BwdArgs g
     const int zb0 = blockIdx.z / g.nb1, zb1 = blockIdx.z % g.nb1;
     const float* Ab = g.A + zb0 * g.sa0 + zb1 * g.sa1;
     const float* Bb = g.B + zb0 * g.sb0 + zb1 * g.sb1;
+    const T16* Bh = reinterpret_cast<const T16*>(g.B) + zb0 * g.sb0 + zb1 * g.sb1;
     float* Cb = g.C + zb0 * g.sc0 + zb1 * g.sc1;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -134,15 +138,45 @@ __global__ __launch_bounds__(256, 2) void gemm_bwd_mfma16_kernel(const BwdArgs g
             }
         }
     };
-    f32x4 ra[NA], rb[NB];
+    // 16-bit contraction-major B: slot = (k group kg of 4 rows, 8-index chunk ch); BN/8 chunks per k row, 16 k groups
+    constexpr int CPR8 = BN / 8;
+    const int hkg = tid / CPR8, hch = tid - hkg * CPR8;       // threads >= 16*CPR8 idle (BN = 64)
+    x8 rbh[4];                                                 // (dead and eliminated when !B16)
+    auto load_b16 = [&](int64_t k0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int64_t k = k0 + hkg * 4 + j;
+            const int idx = j0 + 8 * hch;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) rbh[j][e] = (T16)0.f;
+            if (hkg < 16 && k < kend && idx < g.J) {
+                const T16* s = Bh + k * g.ldb + idx;
+                if (idx + 7 < g.J) rbh[j] = *reinterpret_cast<const x8*>(s);
+                else
+                    for (int e = 0; e < 8 && idx + e < g.J; ++e) rbh[j][e] = s[e];     // ragged index edge
+            }
+        }
+    };
+    auto store_b16 = [&](T16* S) {
+        if (hkg >= 16) return;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            x4 run;
+            run[0] = rbh[0][e]; run[1] = rbh[1][e]; run[2] = rbh[2][e]; run[3] = rbh[3][e];
+            *reinterpret_cast<x4*>(S + lds_off(8 * hch + e, hkg * 4)) = run;
+        }
+    };
+    f32x4 ra[NA], rb[B16 ? 1 : NB];
     auto load_tile = [&](int kt) {
         const int64_t k0 = kbeg + (int64_t)kt * BK;
         load_operand(ra, Ab, g.lda, i0, g.I, AROW, BM, k0, GATHER == 2 ? 2 : 0);
-        load_operand(rb, Bb, g.ldb, j0, g.J, BROW, BN, k0, GATHER == 1 ? 1 : 0);
+        if constexpr (B16) load_b16(k0);
+        else load_operand(rb, Bb, g.ldb, j0, g.J, BROW, BN, k0, GATHER == 1 ? 1 : 0);
     };
     auto store_tile = [&](int buf) {
         store_operand(ra, As + buf * BM * BK, AROW, BM);
-        store_operand(rb, Bs + buf * BN * BK, BROW, BN);
+        if constexpr (B16) store_b16(Bs + buf * BN * BK);
+        else store_operand(rb, Bs + buf * BN * BK, BROW, BN);
     };
 
     f32x16 acc[TM][TN];
@@ -186,7 +220,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bwd_mfma16_kernel(const BwdArgs g
     else bwd_epilogue_rows<BM, BN, EPI, GATHER, TM, TN>(g, Cb, acc, i0, j0, wr, wc, li, hf);
 }
 
-template <typename T16, int BM, int BN, bool AROW, bool BROW, int EPI, int GATHER = 0>
+template <typename T16, int BM, int BN, bool AROW, bool BROW, int EPI, int GATHER = 0, bool B16 = false>
 int launch_one(BwdArgs g, hipStream_t s) {
     constexpr bool kCanSplit = EPI == BEPI_SCALE && GATHER != 2;
     g.tiles_i = (unsigned)((g.I + BM - 1) / BM);
@@ -202,29 +236,33 @@ int launch_one(BwdArgs g, hipStream_t s) {
     const dim3 grid(tiles, (unsigned)splits, (unsigned)g.nbatch);
     if constexpr (kCanSplit) {
         if (splits > 1) {
-            hipLaunchKernelGGL((gemm_bwd_mfma16_kernel<T16, BM, BN, AROW, BROW, EPI, GATHER, true>), grid, dim3(256), 0, s, g);
+            hipLaunchKernelGGL((gemm_bwd_mfma16_kernel<T16, BM, BN, AROW, BROW, EPI, GATHER, true, B16>), grid, dim3(256), 0, s, g);
             return cfm_launch_status();
         }
     }
-    hipLaunchKernelGGL((gemm_bwd_mfma16_kernel<T16, BM, BN, AROW, BROW, EPI, GATHER, false>), grid, dim3(256), 0, s, g);
+    hipLaunchKernelGGL((gemm_bwd_mfma16_kernel<T16, BM, BN, AROW, BROW, EPI, GATHER, false, B16>), grid, dim3(256), 0, s, g);
     return cfm_launch_status();
 }
 
-template <typename T16, bool AROW, bool BROW, int EPI>
+template <typename T16, bool AROW, bool BROW, int EPI, bool B16 = false>
 int launch_layout(const BwdArgs& g, hipStream_t s) {
     const int64_t t128 = (int64_t)((g.I + 127) / 128) * ((g.J + 127) / 128) * g.nbatch;
     int tile = cfm_bwd_debug_tile();
     if (tile < 0) tile = (t128 >= 512 && g.I >= 96 && g.J >= 96) ? 0 : 3;
-    if (tile == 0) return launch_one<T16, 128, 128, AROW, BROW, EPI>(g, s);
-    if (tile == 1) return launch_one<T16, 128, 64, AROW, BROW, EPI>(g, s);
-    return launch_one<T16, 64, 64, AROW, BROW, EPI>(g, s);
+    if (tile == 0) return launch_one<T16, 128, 128, AROW, BROW, EPI, 0, B16>(g, s);
+    if (tile == 1) return launch_one<T16, 128, 64, AROW, BROW, EPI, 0, B16>(g, s);
+    return launch_one<T16, 64, 64, AROW, BROW, EPI, 0, B16>(g, s);
 }
 
 template <typename T16>
 int gemm_bwd_dispatch(BwdArgs& g, int a_col, int b_col, hipStream_t s) {
     if (g.Z) {
         g.splits = 1;
-        return launch_layout<T16, true, false, BEPI_DSWISH>(g, s);
+        return g.b16 ? launch_layout<T16, true, false, BEPI_DSWISH, true>(g, s) : launch_layout<T16, true, false, BEPI_DSWISH>(g, s);
+    }
+    if (g.b16) {
+        if (!b_col) return CFM_ERR_UNSUPPORTED;
+        return a_col ? launch_layout<T16, false, false, BEPI_SCALE, true>(g, s) : launch_layout<T16, true, false, BEPI_SCALE, true>(g, s);
     }
     if (!a_col && !b_col) return launch_layout<T16, true, true, BEPI_SCALE>(g, s);
     if (!a_col && b_col) return launch_layout<T16, true, false, BEPI_SCALE>(g, s);
@@ -258,8 +296,8 @@ int conv2_bwd_input(const float* dz2, const float* w2c, float* dh1, int B, int F
 }  // namespace
 
 // Argument rules of cfm_gemm_bwd_batched_f32; prec = CFM_PREC_BF16 | CFM_PREC_FP16.
-extern "C" int cfm_gemm_bwd_batched_mfma16_f32(int prec, const float* A, int a_col, int64_t lda, const float* B, int b_col,
-                                               int64_t ldb, const float* Z_or_null, int64_t ldz, float alpha, float* C,
+extern "C" int cfm_gemm_bwd_batched_mfma16_f32(int prec, const float* A, int a_col, int64_t lda, const void* B, int b_col,
+                                               int b_is_16bit, int64_t ldb, const float* Z_or_null, int64_t ldz, float alpha, float* C,
                                                int64_t ldc, int I, int J, int64_t Kc, int allow_split, int accumulate,
                                                int nbatch, int nb1, int64_t sa0, int64_t sa1, int64_t sb0, int64_t sb1,
                                                int64_t sc0, int64_t sc1, float drop_p, uint64_t drop_seed,
@@ -268,11 +306,13 @@ extern "C" int cfm_gemm_bwd_batched_mfma16_f32(int prec, const float* A, int a_c
     CFM_REQUIRE(I > 0 && J > 0 && Kc > 0 && nbatch > 0 && nb1 > 0 && nbatch % nb1 == 0 && nbatch <= 65535, CFM_ERR_BAD_SHAPE);
     CFM_REQUIRE((ldc & 3) == 0 && (lda & 3) == 0 && (ldb & 3) == 0, CFM_ERR_BAD_SHAPE);
     CFM_REQUIRE(((sa0 | sa1 | sb0 | sb1 | sc0 | sc1) & 3) == 0, CFM_ERR_BAD_SHAPE);
+    CFM_REQUIRE(!b_is_16bit || (((ldb | sb0 | sb1) & 7) == 0 && b_col), CFM_ERR_BAD_SHAPE);
     CFM_REQUIRE(CFM_ALIGNED16(A) && CFM_ALIGNED16(B) && CFM_ALIGNED16(C), CFM_ERR_ALIGN);
     CFM_REQUIRE(!Z_or_null || (CFM_ALIGNED16(Z_or_null) && (ldz & 3) == 0), CFM_ERR_ALIGN);
     CFM_REQUIRE(!Z_or_null || (!a_col && b_col && nbatch == 1), CFM_ERR_UNSUPPORTED);
     BwdArgs g{};
-    g.A = A; g.B = B; g.Z = Z_or_null; g.C = C; g.I = I; g.J = J; g.Kc = Kc;
+    g.b16 = b_is_16bit != 0;
+    g.A = A; g.B = static_cast<const float*>(B); g.Z = Z_or_null; g.C = C; g.I = I; g.J = J; g.Kc = Kc;
     g.lda = lda; g.ldb = ldb; g.ldz = ldz; g.ldc = ldc; g.alpha = alpha;
     g.splits = (allow_split && !accumulate) ? 0 : 1;
     g.accumulate = accumulate; g.nbatch = nbatch; g.nb1 = nb1; g.drop_p = drop_p; g.drop_seed = drop_seed;

@@ -14,7 +14,9 @@
 
 namespace {
 
-template <typename T16, int BM, int BN, int EPI, bool CONV>
+// W16: the weight operand is already stored in the 16-bit type (a cached cast of the fp32 master weights, made once per
+// optimizer step): half the L2->LDS bytes of the operand that every row tile re-reads, and no conversion.
+template <typename T16, int BM, int BN, int EPI, bool CONV, bool W16>
 __global__ __launch_bounds__(256, 2) void gemm_mfma16_kernel(const GemmArgs g) {
     using x8 = typename Lowp<T16>::x8;
     using x4 = typename Lowp<T16>::x4;
@@ -38,13 +40,23 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma16_kernel(const GemmArgs g) {
 
     // ---- staging: 16 lanes cover the 256 B of one tile row; pass p handles rows srow + 16 p
     const int srow = tid >> 4, sch = tid & 15;
+    constexpr int NBH = BN / 32;                              // W16: 16-byte loads per thread per K-tile (8 lanes per row)
+    const int hrow = tid >> 3, hch = tid & 7;
     const float* a_ptr[NA];
-    const float* w_ptr[NB];
+    const float* w_ptr[W16 ? 1 : NB];
+    const T16* wh_ptr[W16 ? NBH : 1];
 #pragma unroll
     for (int p = 0; p < NA; ++p) a_ptr[p] = a_row_ptr<CONV>(g, m0 + srow + 16 * p);
+    if (W16) {
 #pragma unroll
-    for (int p = 0; p < NB; ++p) w_ptr[p] = w_row_ptr<EPI, BN>(g, n0, srow + 16 * p);
-    f32x4 ra[NA], rb[NB];
+        for (int p = 0; p < NBH; ++p)
+            wh_ptr[p] = reinterpret_cast<const T16*>(g.W) + (int64_t)w_row_index<EPI, BN>(g, n0, hrow + 32 * p) * g.K;
+    } else {
+#pragma unroll
+        for (int p = 0; p < NB; ++p) w_ptr[p] = w_row_ptr<EPI, BN>(g, n0, srow + 16 * p);
+    }
+    f32x4 ra[NA], rb[W16 ? 1 : NB];
+    x8 rbh[W16 ? NBH : 1];
     auto load_tile = [&](int kt) {
         const int k = kt * BK + sch * 4;
         const int64_t aoff = a_k_offset<CONV>(g, kt * BK) + sch * 4;
@@ -52,17 +64,34 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma16_kernel(const GemmArgs g) {
 #pragma unroll
         for (int p = 0; p < NA; ++p)
             ra[p] = ok ? *reinterpret_cast<const f32x4*>(a_ptr[p] + aoff) : f32x4{0.f, 0.f, 0.f, 0.f};
+        if (W16) {
+            const int kh = kt * BK + hch * 8;                  // K % 8 == 0: a 16-byte chunk is all in or all out
 #pragma unroll
-        for (int p = 0; p < NB; ++p)
-            rb[p] = ok ? *reinterpret_cast<const f32x4*>(w_ptr[p] + k) : f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int p = 0; p < NBH; ++p) {
+                if (kh < g.K) rbh[p] = *reinterpret_cast<const x8*>(wh_ptr[p] + kh);
+                else
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) rbh[p][e] = (T16)0.f;
+            }
+        } else {
+#pragma unroll
+            for (int p = 0; p < NB; ++p)
+                rb[p] = ok ? *reinterpret_cast<const f32x4*>(w_ptr[p] + k) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
     };
     auto store_tile = [&](int buf) {
 #pragma unroll
         for (int p = 0; p < NA; ++p)
             *reinterpret_cast<x4*>(As + (buf * BM + srow + 16 * p) * ROWB + sch * 4) = Lowp<T16>::cvt4(ra[p]);
+        if (W16) {
 #pragma unroll
-        for (int p = 0; p < NB; ++p)
-            *reinterpret_cast<x4*>(Bs + (buf * BN + srow + 16 * p) * ROWB + sch * 4) = Lowp<T16>::cvt4(rb[p]);
+            for (int p = 0; p < NBH; ++p)
+                *reinterpret_cast<x8*>(Bs + (buf * BN + hrow + 32 * p) * ROWB + hch * 8) = rbh[p];
+        } else {
+#pragma unroll
+            for (int p = 0; p < NB; ++p)
+                *reinterpret_cast<x4*>(Bs + (buf * BN + srow + 16 * p) * ROWB + sch * 4) = Lowp<T16>::cvt4(rb[p]);
+        }
     };
 
     f32x16 acc[TM][TN];
@@ -105,31 +134,39 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma16_kernel(const GemmArgs g) {
 }
 
 template <typename T16, int BM, int BN, int EPI, bool CONV>
-int launch_cfg(GemmArgs g, hipStream_t s) {
+int launch_cfg(GemmArgs g, bool w16, hipStream_t s) {
     const int ncols = EPI == EPI_GLU ? g.n_out : g.N;
     const int bn = EPI == EPI_GLU ? BN / 2 : BN;
     g.tiles_m = (unsigned)((g.M + BM - 1) / BM);
     g.tiles_n = (unsigned)((ncols + bn - 1) / bn);
-    hipLaunchKernelGGL((gemm_mfma16_kernel<T16, BM, BN, EPI, CONV>), dim3(g.tiles_m * g.tiles_n), dim3(256), 0, s, g);
+    if (w16) hipLaunchKernelGGL((gemm_mfma16_kernel<T16, BM, BN, EPI, CONV, true>), dim3(g.tiles_m * g.tiles_n), dim3(256), 0, s, g);
+    else hipLaunchKernelGGL((gemm_mfma16_kernel<T16, BM, BN, EPI, CONV, false>), dim3(g.tiles_m * g.tiles_n), dim3(256), 0, s, g);
     return cfm_launch_status();
 }
 
 template <typename T16, int EPI, bool CONV>
-int launch_t(const GemmArgs& g, hipStream_t s) {
+int launch_t(const GemmArgs& g, bool w16, hipStream_t s) {
     const int ncols = EPI == EPI_GLU ? g.n_out : g.N;
     const int bn = EPI == EPI_GLU ? 64 : 128;
     const int64_t t128 = ((g.M + 127) / 128) * ((ncols + bn - 1) / bn);
     if constexpr (EPI == EPI_GLU) {
-        return t128 >= 512 ? launch_cfg<T16, 128, 128, EPI, CONV>(g, s) : launch_cfg<T16, 64, 128, EPI, CONV>(g, s);
+        return t128 >= 512 ? launch_cfg<T16, 128, 128, EPI, CONV>(g, w16, s) : launch_cfg<T16, 64, 128, EPI, CONV>(g, w16, s);
     } else {
-        return t128 >= 512 ? launch_cfg<T16, 128, 128, EPI, CONV>(g, s) : launch_cfg<T16, 64, 64, EPI, CONV>(g, s);
+        return t128 >= 512 ? launch_cfg<T16, 128, 128, EPI, CONV>(g, w16, s) : launch_cfg<T16, 64, 64, EPI, CONV>(g, w16, s);
     }
 }
 
+template <typename T16>
+__global__ __launch_bounds__(256) void cast16_kernel(const float* __restrict__ src, T16* __restrict__ dst, int64_t n4) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    *reinterpret_cast<typename Lowp<T16>::x4*>(dst + 4 * i) = Lowp<T16>::cvt4(reinterpret_cast<const f32x4*>(src)[i]);
+}
+
 template <int EPI, bool CONV>
-int launch(int prec, const GemmArgs& g, hipStream_t s) {
-    if (prec == CFM_PREC_BF16) return launch_t<__bf16, EPI, CONV>(g, s);
-    if (prec == CFM_PREC_FP16) return launch_t<_Float16, EPI, CONV>(g, s);
+int launch(int prec, const GemmArgs& g, bool w16, hipStream_t s) {
+    if (prec == CFM_PREC_BF16) return launch_t<__bf16, EPI, CONV>(g, w16, s);
+    if (prec == CFM_PREC_FP16) return launch_t<_Float16, EPI, CONV>(g, w16, s);
     return CFM_ERR_UNSUPPORTED;
 }
 
@@ -138,31 +175,33 @@ int launch(int prec, const GemmArgs& g, hipStream_t s) {
 // prec: CFM_PREC_BF16 | CFM_PREC_FP16.  epi: 0 bias | 1 bias+swish | 2 bias+relu | 3 bias+GLU (N = n_out columns of C,
 // W has 2*n_out rows) | 4 alpha*y + R.  Same layouts and argument rules as the fp32 entry points (cfm_gemm_train_f32 for
 // Z_or_null / drop_p / drop_seed); results differ from them by the 16-bit rounding of A and W only.
-extern "C" int cfm_gemm_mfma16_f32(int prec, int epi, const float* A, const float* W, const float* bias,
+extern "C" int cfm_gemm_mfma16_f32(int prec, int epi, const float* A, const void* W, int w_is_16bit, const float* bias,
                                    const float* R_or_null, float alpha, float* C, float* Z_or_null, int64_t M, int N, int K,
                                    int64_t lda, int64_t ldr, int64_t ldc, float drop_p, uint64_t drop_seed,
                                    cfm_stream_t stream) {
     CFM_REQUIRE(A && W && bias && C, CFM_ERR_NULL);
+    CFM_REQUIRE(!w_is_16bit || (K & 7) == 0, CFM_ERR_BAD_SHAPE);
+    const bool w16 = w_is_16bit != 0;
     CFM_REQUIRE(M > 0 && N > 0 && K > 0 && (K & 3) == 0 && (lda & 3) == 0 && lda >= K && ldc >= N, CFM_ERR_BAD_SHAPE);
     CFM_REQUIRE(drop_p >= 0.f && drop_p < 1.f, CFM_ERR_BAD_SHAPE);
     CFM_REQUIRE(CFM_ALIGNED16(A) && CFM_ALIGNED16(W), CFM_ERR_ALIGN);
     GemmArgs g{};
-    g.A = A; g.W = W; g.bias = bias; g.R = R_or_null; g.C = C; g.M = M; g.K = K; g.lda = lda; g.ldr = ldr; g.ldc = ldc;
-    g.alpha = alpha; g.Zsave = Z_or_null; g.drop_p = drop_p; g.drop_seed = drop_seed;
+    g.A = A; g.W = static_cast<const float*>(W); g.bias = bias; g.R = R_or_null; g.C = C; g.M = M; g.K = K; g.lda = lda;
+    g.ldr = ldr; g.ldc = ldc; g.alpha = alpha; g.Zsave = Z_or_null; g.drop_p = drop_p; g.drop_seed = drop_seed;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (epi == EPI_GLU) {
         g.n_out = N; g.N = 2 * N;
-        return launch<EPI_GLU, false>(prec, g, s);
+        return launch<EPI_GLU, false>(prec, g, w16, s);
     }
     g.N = N;
     switch (epi) {
-        case EPI_BIAS: return launch<EPI_BIAS, false>(prec, g, s);
-        case EPI_SWISH: return launch<EPI_SWISH, false>(prec, g, s);
-        case EPI_RELU: return launch<EPI_RELU, false>(prec, g, s);
+        case EPI_BIAS: return launch<EPI_BIAS, false>(prec, g, w16, s);
+        case EPI_SWISH: return launch<EPI_SWISH, false>(prec, g, w16, s);
+        case EPI_RELU: return launch<EPI_RELU, false>(prec, g, w16, s);
         case EPI_RESID:
             CFM_REQUIRE(R_or_null != nullptr, CFM_ERR_NULL);
             CFM_REQUIRE(ldr >= N, CFM_ERR_BAD_SHAPE);
-            return launch<EPI_RESID, false>(prec, g, s);
+            return launch<EPI_RESID, false>(prec, g, w16, s);
         default: return CFM_ERR_UNSUPPORTED;
     }
 }
@@ -178,5 +217,19 @@ extern "C" int cfm_subsample_conv2_relu_mfma16_f32(int prec, const float* h1, co
     g.cT1 = T1; g.cF1 = F1; g.cC = C; g.cT2 = (T1 - 1) / 2; g.cF2 = (F1 - 1) / 2;
     g.A = h1; g.W = w2p; g.bias = b2; g.C = h2;
     g.M = (int64_t)B * g.cT2 * g.cF2; g.N = C; g.K = 9 * C; g.lda = 0; g.ldc = C; g.alpha = 1.f;
-    return launch<EPI_RELU, true>(prec, g, static_cast<hipStream_t>(stream));
+    return launch<EPI_RELU, true>(prec, g, false, static_cast<hipStream_t>(stream));
+}
+
+// dst (16-bit, prec) <- RNE(src) for n fp32 values (n % 4 == 0): the per-optimizer-step cast of the master weights that
+// the w_is_16bit / b_is_16bit operands of the 16-bit GEMM entries consume.
+extern "C" int cfm_cast16_f32(int prec, const float* src, void* dst, int64_t n, cfm_stream_t stream) {
+    CFM_REQUIRE(src && dst, CFM_ERR_NULL);
+    CFM_REQUIRE(n > 0 && (n & 3) == 0, CFM_ERR_BAD_SHAPE);
+    CFM_REQUIRE(CFM_ALIGNED16(src) && (reinterpret_cast<uintptr_t>(dst) & 7) == 0, CFM_ERR_ALIGN);
+    const dim3 grid((unsigned)((n / 4 + 255) / 256));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (prec == CFM_PREC_BF16) hipLaunchKernelGGL(cast16_kernel<__bf16>, grid, dim3(256), 0, s, src, static_cast<__bf16*>(dst), n / 4);
+    else if (prec == CFM_PREC_FP16) hipLaunchKernelGGL(cast16_kernel<_Float16>, grid, dim3(256), 0, s, src, static_cast<_Float16*>(dst), n / 4);
+    else return CFM_ERR_UNSUPPORTED;
+    return cfm_launch_status();
 }

@@ -34,7 +34,7 @@ __device__ __forceinline__ const float* a_row_ptr(const GemmArgs& g, int64_t m) 
 }
 
 template <int EPI, int BN>
-__device__ __forceinline__ const float* w_row_ptr(const GemmArgs& g, int n0, int r) {   // r = LDS row of the W tile
+__device__ __forceinline__ int w_row_index(const GemmArgs& g, int n0, int r) {          // r = LDS row of the W tile
     int n;
     if (EPI == EPI_GLU) {                                // wave wc: n-tile 0 = value cols, n-tile 1 = gate cols
         const int j = r & 31, nt = (r >> 5) & 1, w = r >> 6;
@@ -45,7 +45,12 @@ __device__ __forceinline__ const float* w_row_ptr(const GemmArgs& g, int n0, int
         n = n0 + r;
         if (n >= g.N) n = g.N - 1;
     }
-    return g.W + (int64_t)n * g.K;
+    return n;
+}
+
+template <int EPI, int BN>
+__device__ __forceinline__ const float* w_row_ptr(const GemmArgs& g, int n0, int r) {
+    return g.W + (int64_t)w_row_index<EPI, BN>(g, n0, r) * g.K;
 }
 
 template <bool CONV>

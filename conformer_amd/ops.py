@@ -5,6 +5,7 @@ kernels on torch's current stream.  Inputs on the wrong device/dtype raise; ther
 """
 from __future__ import annotations
 
+import weakref
 from typing import Optional, Tuple
 
 import torch
@@ -72,9 +73,36 @@ def bf16_mfma_active() -> bool:
     return mfma16_prec() == PREC_BF16
 
 
+_W16_CACHE = {}        # data_ptr -> (weakref(base tensor), version, prec, shape, 16-bit tensor): per-optimizer-step weight casts
+_DT16 = {PREC_BF16: torch.bfloat16, PREC_FP16: torch.float16}
+
+
+def weight16(w: torch.Tensor, prec: int) -> Optional[torch.Tensor]:
+    """The weight matrix rounded to the 16-bit matrix-pipe type, cached until the parameter changes in place (optimizer
+    step / load_state_dict bump `_version`).  None when the 16-bit operand path does not apply (K % 8 != 0)."""
+    if w.shape[-1] % 8 or w.numel() % 4:
+        return None
+    key = w.data_ptr()
+    base = w._base if w._base is not None else w     # views are re-created per call; the owning tensor identifies the weight
+    hit = _W16_CACHE.get(key)
+    # (a freed temporary -- e.g. last step's fused QKV matrix -- can hand its address to a new tensor: the weak reference
+    # to the owner tells the two apart; `_version` catches in-place updates of a live parameter)
+    if hit is not None and hit[0]() is base and hit[1] == w._version and hit[2] == prec and hit[3] == w.shape:
+        return hit[4]
+    out = torch.empty(w.shape, device=w.device, dtype=_DT16[prec])
+    _lib.check(_lib.load().cfm_cast16_f32(prec, w.data_ptr(), out.data_ptr(), w.numel(), _stream()), "cfm_cast16_f32")
+    if len(_W16_CACHE) > 4096:
+        for k in [k for k, v in _W16_CACHE.items() if v[0]() is None]:
+            del _W16_CACHE[k]
+    _W16_CACHE[key] = (weakref.ref(base), w._version, prec, w.shape, out)
+    return out
+
+
 def _mfma16_gemm(prec: int, epi: int, a, w2, b, c, m, n, k, res=None, alpha: float = 1.0, z=None, drop_p: float = 0.0,
                  seed: int = 0):
-    st = _lib.load().cfm_gemm_mfma16_f32(prec, epi, a.data_ptr(), w2.data_ptr(), b.data_ptr(), _p(res), alpha, c.data_ptr(),
+    w16 = weight16(w2, prec)
+    st = _lib.load().cfm_gemm_mfma16_f32(prec, epi, a.data_ptr(), (w2 if w16 is None else w16).data_ptr(), int(w16 is not None),
+                                         b.data_ptr(), _p(res), alpha, c.data_ptr(),
                                          _p(z), m, n, k, k, n, n, float(drop_p), int(seed), _stream())
     _lib.check(st, "cfm_gemm_mfma16_f32")
     return c
@@ -364,24 +392,27 @@ def colsum(x2d, alpha: float = 1.0, rows=None, cols=None, ld=None, out=None):
 def gemm_bwd(A, a_col: bool, B, b_col: bool, I: int, J: int, Kc: int, *, alpha: float = 1.0, Z=None, out=None,
              lda=None, ldb=None, ldc=None, ldz=None, allow_split: bool = False, accumulate: bool = False,
              nbatch: int = 1, nb1: int = 1, sa=(0, 0), sb=(0, 0), sc=(0, 0), a_ptr=None, b_ptr=None, c_ptr=None,
-             drop_p: float = 0.0, drop_seed: int = 0, prec: int = 0):
+             drop_p: float = 0.0, drop_seed: int = 0, prec: int = 0, b16: bool = False):
     """C (I,J) (+)= alpha * sum_k A(i,k) B(j,k) [* swish'(Z)]; *_col selects the contraction-major layout.
     Pointers default to the tensors' data_ptr(); explicit *_ptr / ld* let callers address sub-blocks (head slices).
-    prec: PREC_F32 (fp32 MFMA) | PREC_BF16 | PREC_FP16 (operands rounded while staged, fp32 accumulate)."""
+    prec: PREC_F32 (fp32 MFMA) | PREC_BF16 | PREC_FP16 (operands rounded while staged, fp32 accumulate).
+    b16: B is a tensor already stored in the 16-bit type of `prec` (contraction-major only; ldb in elements)."""
     lda = A.stride(-2) if lda is None else lda
     ldb = B.stride(-2) if ldb is None else ldb
     if out is None:
         out = (torch.zeros if allow_split else torch.empty)(I, J, device=A.device, dtype=A.dtype)
     ldc = out.stride(-2) if ldc is None else ldc
     ldz = 0 if Z is None else (Z.stride(-2) if ldz is None else ldz)
-    args = (A.data_ptr() if a_ptr is None else a_ptr, int(a_col), lda, B.data_ptr() if b_ptr is None else b_ptr, int(b_col),
-            ldb, _p(Z), ldz, alpha, out.data_ptr() if c_ptr is None else c_ptr, ldc, I, J, Kc, int(allow_split),
+    head = (A.data_ptr() if a_ptr is None else a_ptr, int(a_col), lda, B.data_ptr() if b_ptr is None else b_ptr, int(b_col))
+    tail = (ldb, _p(Z), ldz, alpha, out.data_ptr() if c_ptr is None else c_ptr, ldc, I, J, Kc, int(allow_split),
             int(accumulate), nbatch, nb1, sa[0], sa[1], sb[0], sb[1], sc[0], sc[1], float(drop_p), int(drop_seed),
             _stream())
     if prec:
-        _lib.check(_lib.load().cfm_gemm_bwd_batched_mfma16_f32(prec, *args), "cfm_gemm_bwd_batched_mfma16_f32")
+        _lib.check(_lib.load().cfm_gemm_bwd_batched_mfma16_f32(prec, *head, int(b16), *tail), "cfm_gemm_bwd_batched_mfma16_f32")
     else:
-        _lib.check(_lib.load().cfm_gemm_bwd_batched_f32(*args), "cfm_gemm_bwd_batched_f32")
+        if b16:
+            raise _lib.ConformerHipError("a 16-bit B operand needs a 16-bit precision mode")
+        _lib.check(_lib.load().cfm_gemm_bwd_batched_f32(*head, *tail), "cfm_gemm_bwd_batched_f32")
     return out
 
 
@@ -398,7 +429,9 @@ def linear_bwd(x2d, w, dy2d, *, alpha: float = 1.0, Z=None, need_dx: bool = True
         padded[:, :n] = dy2d
         dy2d = padded[:, :n]
     if need_dx:
-        dx = gemm_bwd(dy2d, False, w2, True, m, k, n, alpha=alpha, Z=Z, drop_p=drop_p, drop_seed=drop_seed, prec=prec)
+        w16 = weight16(w2, prec) if prec else None              # the cast the forward made (same parameter version)
+        dx = gemm_bwd(dy2d, False, w2 if w16 is None else w16, True, m, k, n, alpha=alpha, Z=Z, drop_p=drop_p,
+                      drop_seed=drop_seed, prec=prec, b16=w16 is not None)
     dw, db = _zeros_split(x2d.device, x2d.dtype, (n, k), (n,))
     gemm_bwd(dy2d, True, x2d, True, n, k, m, alpha=alpha, allow_split=True, out=dw, prec=prec)
     colsum(dy2d, alpha, out=db)

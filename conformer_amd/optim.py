@@ -72,6 +72,9 @@ class FusedAdam(torch.optim.Optimizer):
             _lib.check(_lib.load().cfm_adam_step_f32(ctypes.addressof(arr), len(plist), float(group["lr"]), b1, b2, group["eps"],
                                                      1.0 - b1 ** step, math.sqrt(1.0 - b2 ** step), ops._stream()),
                        "cfm_adam_step_f32")
+            # the kernel wrote through raw pointers: tell autograd (and every cache keyed on `_version`: the packed / fused /
+            # 16-bit weight copies of the modules and of ops.weight16) that the parameters changed in place
+            torch.autograd.graph.increment_version(plist)
         return loss
 
     def _sync_steps(self) -> None:

@@ -124,13 +124,16 @@ int cfm_pack_linear_weight_f32(const float* wl, float* wlp, int d_out, int C, in
  *      forms need C % 64 == 0). */
 #define CFM_PREC_BF16 1
 #define CFM_PREC_FP16 2
-int cfm_gemm_mfma16_f32(int prec, int epi, const float* A, const float* W, const float* bias, const float* R_or_null,
-                        float alpha, float* C, float* Z_or_null, int64_t M, int N, int K, int64_t lda, int64_t ldr,
-                        int64_t ldc, float drop_p, uint64_t drop_seed, cfm_stream_t stream);
+int cfm_gemm_mfma16_f32(int prec, int epi, const float* A, const void* W, int w_is_16bit, const float* bias,
+                        const float* R_or_null, float alpha, float* C, float* Z_or_null, int64_t M, int N, int K,
+                        int64_t lda, int64_t ldr, int64_t ldc, float drop_p, uint64_t drop_seed, cfm_stream_t stream);
+/*      w_is_16bit / b_is_16bit: that operand is already stored in `prec` (cfm_cast16_f32 of the fp32 master weights, once
+ *      per optimizer step): half the bytes of the operand every row tile re-reads; results are bit-identical. K % 8 == 0. */
+int cfm_cast16_f32(int prec, const float* src, void* dst, int64_t n, cfm_stream_t stream);
 int cfm_subsample_conv2_relu_mfma16_f32(int prec, const float* h1, const float* w2p, const float* b2, float* h2, int B,
                                         int F1, int T1, int C, cfm_stream_t stream);
-int cfm_gemm_bwd_batched_mfma16_f32(int prec, const float* A, int a_col, int64_t lda, const float* B, int b_col,
-                                    int64_t ldb, const float* Z_or_null, int64_t ldz, float alpha, float* C,
+int cfm_gemm_bwd_batched_mfma16_f32(int prec, const float* A, int a_col, int64_t lda, const void* B, int b_col,
+                                    int b_is_16bit, int64_t ldb, const float* Z_or_null, int64_t ldz, float alpha, float* C,
                                     int64_t ldc, int I, int J, int64_t Kc, int allow_split, int accumulate,
                                     int nbatch, int nb1, int64_t sa0, int64_t sa1, int64_t sb0, int64_t sb1,
                                     int64_t sc0, int64_t sc1, float drop_p, uint64_t drop_seed, cfm_stream_t stream);

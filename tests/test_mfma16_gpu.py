@@ -82,6 +82,18 @@ def test_mfma16_gemm_bwd_layouts(dev, I, J, Kc, dt16):
             assert rel_l2(out2[:, :J], ref) < 2e-5, ("split", a_col, b_col)
             ops.gemm_bwd(Ad, a_col, Bd, b_col, I, J, Kc, out=out2, accumulate=True, prec=prec)
             assert rel_l2(out2[:, :J], 2 * ref) < 2e-5, ("acc", a_col, b_col)
+    # B already stored in the 16-bit type (cached weight cast), contraction-major, padded leading dimension
+    J8 = (J + 7) // 8 * 8
+    B16 = torch.zeros(Kc, J8, dtype=dt16)
+    B16[:, :J] = Bm.t().to(dt16)
+    for a_col in (False, True):
+        out = torch.full((I, Jp), 7.0, device=dev)
+        ops.gemm_bwd(lay(A, a_col), a_col, B16.to(dev), True, I, J, Kc, alpha=0.5, out=out, prec=prec, b16=True)
+        assert rel_l2(out[:, :J], 0.5 * ref) < 2e-5, ("b16", a_col)
+        assert (out[:, J:] == 7.0).all()
+        out2 = torch.zeros(I, Jp, device=dev)
+        ops.gemm_bwd(lay(A, a_col), a_col, B16.to(dev), True, I, J, Kc, out=out2, allow_split=True, prec=prec, b16=True)
+        assert rel_l2(out2[:, :J], ref) < 2e-5, ("b16 split", a_col)
     Z = rnd(I, Jp, seed=3)
     dz = ops.gemm_bwd(lay(A, False), False, lay(Bm, True), True, I, J, Kc, Z=Z.to(dev), out=torch.empty(I, Jp, device=dev),
                       prec=prec)

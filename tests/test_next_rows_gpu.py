@@ -27,7 +27,9 @@ def test_fused_adam_matches_torch_adam(dev):
     for k in range(4):
         for p, gr in zip(ps, grads[k]):
             p.grad = gr.to(dev)
+        versions = [p._version for p in ps]
         opt.step()
+        assert all(p._version > v for p, v in zip(ps, versions))        # caches keyed on _version must see the update
     for p, r in zip(ps, ref):
         assert rel_l2(p, r) < 2e-6
     # state layout interchanges with torch.optim.Adam (manager.py:34-40 saves optimizer.state_dict())
@@ -190,3 +192,62 @@ def test_decoder_training_grads_vs_oracle_autograd(dev, train_bn):
         assert int(dec.norm.num_batches_tracked) == nbt0 + 1
     else:
         assert torch.equal(dec.norm.running_mean, rm0)
+
+
+def test_weight_caches_follow_the_fused_optimizer(dev):
+    """The cached 16-bit weight copy (ops.weight16) and the modules' packed weights are keyed on the parameter version:
+    a FusedAdam step (raw-pointer kernel) must invalidate them."""
+    from conformer_amd import ops
+    from conformer_amd.optim import FusedAdam
+    w = torch.nn.Parameter(torch.randn(64, 64, device=dev))
+    a, b = torch.randn(8, 64, device=dev), torch.zeros(64, device=dev)
+    opt = FusedAdam([w], lr=0.5)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y0 = ops.linear(a, w.detach(), b)
+        w.grad = torch.ones_like(w)
+        opt.step()
+        y1 = ops.linear(a, w.detach(), b)
+    ref = a.double().cpu() @ w.detach().double().cpu().t()
+    assert rel_l2(y1, ref) < 1e-2 and rel_l2(y0, ref) > 1e-1
+    # a temporary weight whose address is recycled by the allocator must not hit the stale entry of its predecessor
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        for k in range(4):
+            tmp = torch.full((64, 64), float(k + 1), device=dev)
+            y = ops.linear(a, tmp, b)
+            assert rel_l2(y, (k + 1.0) * a.double().cpu().sum(-1, keepdim=True).expand(8, 64)) < 1e-2, k
+            del tmp, y
+
+
+@pytest.mark.parametrize("amp", [None, torch.bfloat16])
+def test_training_trajectory_fused_adam_equals_torch_adam(dev, amp):
+    """Five full training steps of a tiny Conformer (fwd + CTC + bwd + optimizer) with FusedAdam vs torch.optim.Adam: the
+    loss trajectories agree (weights are not compared: parameters with mathematically zero gradients -- key/pos projection
+    biases, biases in front of a train-mode BatchNorm -- get Adam-amplified summation noise) -- guards every weight-derived cache (fused QKV, packed conv / linear
+    weights, 16-bit weight copies) against going stale when the optimizer writes parameters through raw pointers."""
+    from conformer_amd.optim import FusedAdam
+    from model.conformer import Conformer
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(3, 80, 120, generator=g).to(dev)
+    L = torch.tensor([120, 101, 77], device=dev)
+    tg = torch.randint(1, 30, (3, 6), generator=g).to(dev)
+    tl = torch.tensor([6, 5, 3], device=dev)
+    crit = torch.nn.CTCLoss(blank=0, zero_infinity=True)
+    runs = {}
+    for name in ("torch", "fused"):
+        torch.manual_seed(1)
+        m = Conformer(30, 80, 2, 64, 4, 7, 32, 1, 0.0).to(dev).train()
+        opt = (FusedAdam if name == "fused" else torch.optim.Adam)(m.parameters(), lr=1e-2)
+        losses = []
+        for _ in range(5):
+            with torch.autocast("cuda", dtype=amp, enabled=amp is not None):
+                logits, out_len = m(x, L)
+            loss = crit(logits.float().log_softmax(-1).transpose(0, 1), tg, out_len, tl)
+            opt.zero_grad(set_to_none=True)
+            loss.backward()
+            opt.step()
+            losses.append(float(loss.detach()))
+        runs[name] = losses
+    tol = 1e-4 if amp is None else 2e-2
+    assert runs["torch"][4] < runs["torch"][0]                             # it trains
+    for a, b in zip(runs["torch"], runs["fused"]):
+        assert abs(a - b) < tol * abs(a), (runs["torch"], runs["fused"])
