@@ -1,0 +1,288 @@
+// Relative-position attention forward on the 16-bit matrix pipe (bf16 / fp16): the torch.autocast arithmetic of
+// attention.py:47-72 -- Q, K, V and the projected positions are rounded to the 16-bit type for the three products
+// (fp32 accumulation), the softmax runs in fp32, the probabilities are rounded for P.V.  All tensors in HBM stay fp32.
+//
+// Same algorithm and orientation as attention_f32.hip (flash-style, queries on lanes, relative shift = per-lane column
+// skew through a per-wave LDS tile, K / V / positional ring staged in LDS and shared by 4 waves); what changes:
+//   * v_mfma_f32_32x32x16_{bf16,f16}: 4 steps per 64-dim product instead of 32 -> 16 MFMAs per key tile instead of 128,
+//     so the kernel is bound by the staging / skew / softmax instruction stream, not by the matrix pipe;
+//   * K and the ring are staged as 16-bit rows of 144 B (conflict-free 16-byte fragment reads: 8 dims per lane per step);
+//   * V is staged TRANSPOSED ([dim][key], 16-bit): the P.V product contracts over keys, and a lane's accumulator
+//     registers hold keys {16s + 8(e>>2) + 4hf + (e&3)}, e = 0..7, for step s -- the V^T fragment is two 8-byte reads
+//     in exactly that key order, so P goes from the softmax registers to the MFMA without any shuffle;
+//   * (Q+u), (Q+v) live in 16 VGPRs each (64 in the fp32 kernel): 48 KB LDS + ~130 VGPRs -> 3 workgroups per CU.
+#include "cfm_common.h"
+#include <math.h>
+
+namespace {
+
+constexpr int KROWH = 72;                // LDS row (16-bit elements) of the K tile and the P ring: 64 + 8 pad = 144 B
+constexpr int VROWH = 40;                // LDS row of V^T: 32 keys + 8 pad = 80 B
+constexpr int RINGH = 160;
+
+struct Attn16Args {
+    const float* q; const float* k; const float* v; int64_t ld;
+    const float* pos; int64_t ldp; const float* u; const float* vb;
+    const int64_t* lengths; float* ctx; int64_t ldo; float* lse;
+    int B, T, H, dh; float inv_sqrt_dh;
+    float drop_p; unsigned long long drop_seed;
+};
+
+template <typename T16>
+__global__ __launch_bounds__(256, 3) void relpos_attn_fwd_mfma16_kernel(const Attn16Args a) {
+    using x8 = typename Lowp<T16>::x8;
+    using x4 = typename Lowp<T16>::x4;
+    __shared__ __attribute__((aligned(16))) T16 smem16[32 * KROWH + 64 * VROWH + RINGH * KROWH];
+    __shared__ __attribute__((aligned(16))) float gsm[4 * 32 * 32];
+    T16* Ks = smem16;                            // [32 keys][KROWH]
+    T16* Vt = Ks + 32 * KROWH;                   // [64 dims][VROWH]   (V transposed)
+    T16* Pr = Vt + 64 * VROWH;                   // [RINGH][KROWH]
+    float* gs = gsm + (threadIdx.x >> 6) * 1024; // per-wave skew tile [32][32]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, hf = lane >> 5;
+    const int bh = blockIdx.y, b = bh / a.H, h = bh % a.H;
+    const int T = a.T, dh = a.dh;
+    const int q0 = blockIdx.x * 128;
+    const int i0 = q0 + wave * 32;
+    const bool active = i0 < T;
+
+    int klen = T;
+    bool uniform = false;
+    if (a.lengths) {
+        const int64_t L = a.lengths[b];
+        if (L <= 0) uniform = true;
+        else if (L < T) klen = (int)L;
+    }
+    const int ntiles = (klen + 31) / 32;
+
+    const float* kbase = a.k + (int64_t)b * T * a.ld + h * dh;
+    const float* vbase = a.v + (int64_t)b * T * a.ld + h * dh;
+    const float* pbase = a.pos + h * dh;
+    const int jmax = 2 * T - 2;
+    const int ring_bias = RINGH * ((T + 128 + q0) / RINGH + 2);
+
+    // ---- cooperative staging: thread -> (row srow + 16*pass, 4-dim chunk sch) of a 32-row x 64-dim fp32 tile
+    const int srow = tid >> 4, sch = tid & 15;
+    const bool sok = sch * 4 < dh;
+    f32x4 pk[2], pv[2], pp[2];
+    auto prefetch = [&](int kt) {
+        const int k0 = kt * 32;
+        const int jnew = T - 1 - q0 + k0;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int r = srow + 16 * p;
+            const int key = min(k0 + r, T - 1);
+            const int j = max(0, min(jnew + r, jmax));
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            pk[p] = sok ? *reinterpret_cast<const f32x4*>(kbase + (int64_t)key * a.ld + sch * 4) : z;
+            pv[p] = sok ? *reinterpret_cast<const f32x4*>(vbase + (int64_t)key * a.ld + sch * 4) : z;
+            pp[p] = sok ? *reinterpret_cast<const f32x4*>(pbase + (int64_t)j * a.ldp + sch * 4) : z;
+        }
+    };
+    auto commit = [&](int kt) {
+        const int k0 = kt * 32;
+        const int jnew = T - 1 - q0 + k0;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int r = srow + 16 * p;
+            *reinterpret_cast<x4*>(Ks + r * KROWH + sch * 4) = Lowp<T16>::cvt4(pk[p]);
+            const x4 vv = Lowp<T16>::cvt4(pv[p]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) Vt[(sch * 4 + e) * VROWH + r] = vv[e];          // transpose while staging
+            const int slot = (jnew + r + ring_bias) % RINGH;
+            *reinterpret_cast<x4*>(Pr + slot * KROWH + sch * 4) = Lowp<T16>::cvt4(pp[p]);
+        }
+    };
+
+    {   // prologue: ring rows [jlo, jlo+127] of tile 0 (the top 32 rows arrive with prefetch(0))
+        const int jlo = T - 1 - q0 - 128;
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            const int r = srow + 16 * p;
+            const int j = max(0, min(jlo + r, jmax));
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            const f32x4 val = sok ? *reinterpret_cast<const f32x4*>(pbase + (int64_t)j * a.ldp + sch * 4) : z;
+            const int slot = (jlo + r + ring_bias) % RINGH;
+            *reinterpret_cast<x4*>(Pr + slot * KROWH + sch * 4) = Lowp<T16>::cvt4(val);
+        }
+    }
+    prefetch(0);
+    commit(0);
+    if (ntiles > 1) prefetch(1);
+    __syncthreads();
+
+    // ---- (Q+u)^T, (Q+v)^T as MFMA B operands: lane (query li, half hf) holds dims 16s + 8hf + {0..7} at step s
+    x8 qu[4], qv[4];
+    {
+        const int qi = min(i0 + li, T - 1);
+        const float* qrow = a.q + ((int64_t)b * T + qi) * a.ld + h * dh;
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int dd = 16 * s + 8 * hf + 4 * half;
+                f32x4 x = {0.f, 0.f, 0.f, 0.f}, uu = x, vv = x;
+                if (dd < dh) {
+                    x = *reinterpret_cast<const f32x4*>(qrow + dd);
+                    uu = *reinterpret_cast<const f32x4*>(a.u + h * dh + dd);
+                    vv = *reinterpret_cast<const f32x4*>(a.vb + h * dh + dd);
+                }
+                const x4 cu = Lowp<T16>::cvt4(x + uu), cv = Lowp<T16>::cvt4(x + vv);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { qu[s][4 * half + e] = cu[e]; qv[s][4 * half + e] = cv[e]; }
+            }
+    }
+
+    f32x16 o[2];
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[n][r] = 0.f;
+    float mrow = -INFINITY, lrow = 0.f;
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+    for (int kt = 0; kt < ntiles; ++kt) {
+        const int k0 = kt * 32;
+        if (active) {
+            const int jbase = T - 1 - i0 + k0 + 31;
+            auto band = [&](int mt) {
+                const int slot = (jbase - (32 * mt + li) + ring_bias) % RINGH;
+                const T16* prow = Pr + slot * KROWH + 8 * hf;
+                f32x16 ga = zero16;
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+                    ga = Lowp<T16>::mfma(*reinterpret_cast<const x8*>(prow + 16 * s), qv[s], ga);
+                return ga;
+            };
+            auto spill_band = [&](const f32x16& ga) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) gs[((r & 3) + 8 * (r >> 2) + 4 * hf) * 32 + li] = ga[r];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            };
+            float sk[16];
+            spill_band(band(0));
+            const f32x16 g1 = band(1);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int jj = li - ((r & 3) + 8 * (r >> 2) + 4 * hf) + 31;
+                sk[r] = gs[(jj & 31) * 32 + li];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            spill_band(g1);
+            f32x16 sc = zero16;
+            {
+                const T16* krow = Ks + li * KROWH + 8 * hf;
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+                    sc = Lowp<T16>::mfma(*reinterpret_cast<const x8*>(krow + 16 * s), qu[s], sc);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int jj = li - ((r & 3) + 8 * (r >> 2) + 4 * hf) + 31;
+                const float g1v = gs[(jj & 31) * 32 + li];
+                sk[r] = (jj >> 5) ? g1v : sk[r];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            // ---- scale + mask, online softmax
+            float p[16];
+            float tmax = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int kk = (r & 3) + 8 * (r >> 2) + 4 * hf;
+                float s = (sc[r] + sk[r]) * a.inv_sqrt_dh;
+                if (uniform) s = 0.f;
+                if (k0 + kk >= klen) s = -INFINITY;
+                p[r] = s;
+                tmax = fmaxf(tmax, s);
+            }
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+            const float mnew = fmaxf(mrow, tmax);
+            const float alpha = exp_fast(mrow - mnew);
+            float psum = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { p[r] = exp_fast(p[r] - mnew); psum += p[r]; }
+            psum += __shfl_xor(psum, 32, 64);
+            lrow = lrow * alpha + psum;
+            mrow = mnew;
+            if (a.drop_p > 0.f) {
+                const float inv_keep = 1.0f / (1.0f - a.drop_p);
+                const unsigned long long rowbase = ((unsigned long long)bh * T + (unsigned)(i0 + li)) * (unsigned long long)T;
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    p[r] *= dropout_keep(a.drop_seed, rowbase + (unsigned)(k0 + (r & 3) + 8 * (r >> 2) + 4 * hf), a.drop_p, inv_keep);
+            }
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[n][r] *= alpha;
+            // ---- O^T += V^T . P^T : step s contracts the 16 keys held in registers 8s..8s+7 of both lane halves
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                x8 pb;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) pb[e] = (T16)p[8 * s + e];
+#pragma unroll
+                for (int n = 0; n < 2; ++n) {
+                    const T16* vrow = Vt + (32 * n + li) * VROWH + 16 * s + 4 * hf;
+                    const x4 lo = *reinterpret_cast<const x4*>(vrow), hi = *reinterpret_cast<const x4*>(vrow + 8);
+                    x8 va;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { va[e] = lo[e]; va[4 + e] = hi[e]; }
+                    o[n] = Lowp<T16>::mfma(va, pb, o[n]);
+                }
+            }
+        }
+        if (kt + 1 < ntiles) {
+            __syncthreads();
+            commit(kt + 1);
+            __syncthreads();
+            if (kt + 2 < ntiles) prefetch(kt + 2);
+        }
+    }
+
+    if (active && i0 + li < T) {
+        const float inv = 1.0f / lrow;
+        float* orow = a.ctx + ((int64_t)b * T + i0 + li) * a.ldo + h * dh;
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const int dd = 32 * n + 8 * gq + 4 * hf;
+                if (dd < dh) {
+                    f32x4 out = {o[n][4 * gq] * inv, o[n][4 * gq + 1] * inv, o[n][4 * gq + 2] * inv, o[n][4 * gq + 3] * inv};
+                    *reinterpret_cast<f32x4*>(orow + dd) = out;
+                }
+            }
+        if (a.lse && hf == 0) a.lse[((int64_t)b * a.H + h) * T + i0 + li] = mrow + logf(lrow);
+    }
+}
+
+}  // namespace
+
+// 16-bit-MFMA form of cfm_relpos_attention_train_f32 (prec = CFM_PREC_BF16 | CFM_PREC_FP16; lse_or_null; drop_p may be 0).
+extern "C" int cfm_relpos_attention_mfma16_f32(int prec, const float* q, const float* k, const float* v, int64_t ld,
+                                               const float* pos, int64_t ldp, const float* u, const float* vbias,
+                                               const int64_t* lengths_or_null, float* ctx, int64_t ldo, float* lse_or_null,
+                                               int B, int T, int H, int dh, float drop_p, uint64_t drop_seed,
+                                               cfm_stream_t stream) {
+    CFM_REQUIRE(q && k && v && pos && u && vbias && ctx, CFM_ERR_NULL);
+    CFM_REQUIRE(B > 0 && T > 0 && H > 0 && dh > 0 && (dh & 3) == 0, CFM_ERR_BAD_SHAPE);
+    CFM_REQUIRE((ld & 3) == 0 && (ldp & 3) == 0 && (ldo & 3) == 0 && drop_p >= 0.f && drop_p < 1.f, CFM_ERR_BAD_SHAPE);
+    CFM_REQUIRE(dh <= 64, CFM_ERR_UNSUPPORTED);
+    CFM_REQUIRE(CFM_ALIGNED16(q) && CFM_ALIGNED16(k) && CFM_ALIGNED16(v) && CFM_ALIGNED16(pos) && CFM_ALIGNED16(u) &&
+                CFM_ALIGNED16(vbias) && CFM_ALIGNED16(ctx), CFM_ERR_ALIGN);
+    CFM_REQUIRE((int64_t)B * H <= 65535 && T < (1 << 28), CFM_ERR_UNSUPPORTED);
+    const Attn16Args a{q, k, v, ld, pos, ldp, u, vbias, lengths_or_null, ctx, ldo, lse_or_null, B, T, H, dh,
+                       1.0f / sqrtf((float)dh), drop_p, drop_seed};
+    const dim3 grid((unsigned)((T + 127) / 128), (unsigned)(B * H)), block(256);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (prec == CFM_PREC_BF16) hipLaunchKernelGGL(relpos_attn_fwd_mfma16_kernel<__bf16>, grid, block, 0, s, a);
+    else if (prec == CFM_PREC_FP16) hipLaunchKernelGGL(relpos_attn_fwd_mfma16_kernel<_Float16>, grid, block, 0, s, a);
+    else return CFM_ERR_UNSUPPORTED;
+    return cfm_launch_status();
+}

@@ -199,6 +199,13 @@ def relpos_attention(qkv: torch.Tensor, pos: torch.Tensor, u: torch.Tensor, v: t
         lengths = _req(lengths, "lengths", torch.int64)
     ctx = torch.empty(B, T, d, device=qkv.device, dtype=qkv.dtype)
     base = qkv.data_ptr()
+    prec = mfma16_prec()
+    if prec:
+        st = _lib.load().cfm_relpos_attention_mfma16_f32(prec, base, base + 4 * d, base + 8 * d, d3, pos.data_ptr(), ldp,
+                                                         u.data_ptr(), v.data_ptr(), _p(lengths), ctx.data_ptr(), d, None,
+                                                         B, T, n_heads, dh, 0.0, 0, _stream())
+        _lib.check(st, "cfm_relpos_attention_mfma16_f32")
+        return ctx
     st = _lib.load().cfm_relpos_attention_fwd_f32(base, base + 4 * d, base + 8 * d, d3, pos.data_ptr(), ldp,
                                                   u.data_ptr(), v.data_ptr(), _p(lengths), ctx.data_ptr(), d, None,
                                                   B, T, n_heads, dh, _stream())
@@ -477,6 +484,14 @@ def relpos_attention_train(qkv, pos, u, v, lengths, n_heads, drop_p: float = 0.0
     ctx = torch.empty(B, T, d, device=qkv.device, dtype=qkv.dtype)
     lse = torch.empty(B, n_heads, T, device=qkv.device, dtype=qkv.dtype)
     base = qkv.data_ptr()
+    prec = mfma16_prec()
+    if prec:
+        st = _lib.load().cfm_relpos_attention_mfma16_f32(prec, base, base + 4 * d, base + 8 * d, d3, pos.data_ptr(),
+                                                         pos.stride(0), u.data_ptr(), v.data_ptr(), _p(lengths),
+                                                         ctx.data_ptr(), d, lse.data_ptr(), B, T, n_heads, dh, float(drop_p),
+                                                         int(seed), _stream())
+        _lib.check(st, "cfm_relpos_attention_mfma16_f32")
+        return ctx, lse
     st = _lib.load().cfm_relpos_attention_train_f32(base, base + 4 * d, base + 8 * d, d3, pos.data_ptr(), pos.stride(0),
                                                     u.data_ptr(), v.data_ptr(), _p(lengths), ctx.data_ptr(), d,
                                                     lse.data_ptr(), B, T, n_heads, dh, float(drop_p), int(seed), _stream())
@@ -487,8 +502,8 @@ def relpos_attention_train(qkv, pos, u, v, lengths, n_heads, drop_p: float = 0.0
 def relpos_attention_bwd(qkv, pos, u, v, lengths, n_heads, ctx, lse, dctx, drop_p: float = 0.0, seed: int = 0):
     """Backward of the attention core.  Returns (dqkv (B,T,3d), dpos (2T-1,d), du (H,dh), dv (H,dh)).
     Round-1 form: batched MFMA GEMMs over re-materialised (B,H,T,T) tensors (attention_bwd_f32.hip).
-    Under autocast the products that are LINEAR in the incoming gradient (dP, dV, dK, dQ, dPos) run on the 16-bit matrix
-    pipe; the two score products stay fp32 so that the recomputed probabilities match the fp32 forward's log-sum-exp."""
+    Under autocast every product runs on the 16-bit matrix pipe with the operand rounding of the 16-bit forward kernel
+    (attention_mfma16.hip), so the recomputed probabilities match the forward's log-sum-exp."""
     lib = _lib.load()
     B, T, d3 = qkv.shape
     d = d3 // 3
@@ -521,10 +536,10 @@ def relpos_attention_bwd(qkv, pos, u, v, lengths, n_heads, ctx, lse, dctx, drop_
     lp = mfma16_prec()
     # content[b,h] = Qu_bh . K_bh^T        (T x T4; padded columns read clamped K rows, masked later)
     gemm_bwd(qu, False, qkv, False, T, T4, dh, out=content, lda=d, ldb=d3, ldc=T4, nbatch=nb, nb1=H,
-             sa=sBH_rows, sb=sBH_qkv, sc=sBH_sq, b_ptr=kp)
+             sa=sBH_rows, sb=sBH_qkv, sc=sBH_sq, b_ptr=kp, prec=lp)
     # posfull[h,b] = Qv_bh . Pm_h^T        (T x P4)
     gemm_bwd(qv, False, pos, False, T, P4, dh, out=posfull, lda=d, ldb=ldp, ldc=P4, nbatch=nb, nb1=H,
-             sa=sBH_rows, sb=(0, dh), sc=sBH_pf)
+             sa=sBH_rows, sb=(0, dh), sc=sBH_pf, prec=lp)
     # dP[b,h] = dO_bh . V_bh^T
     gemm_bwd(dctx, False, qkv, False, T, T4, dh, out=dP, lda=d, ldb=d3, ldc=T4, nbatch=nb, nb1=H,
              sa=sBH_rows, sb=sBH_qkv, sc=sBH_sq, b_ptr=vp, prec=lp)

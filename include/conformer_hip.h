@@ -130,6 +130,10 @@ int cfm_gemm_mfma16_f32(int prec, int epi, const float* A, const void* W, int w_
 /*      w_is_16bit / b_is_16bit: that operand is already stored in `prec` (cfm_cast16_f32 of the fp32 master weights, once
  *      per optimizer step): half the bytes of the operand every row tile re-reads; results are bit-identical. K % 8 == 0. */
 int cfm_cast16_f32(int prec, const float* src, void* dst, int64_t n, cfm_stream_t stream);
+int cfm_relpos_attention_mfma16_f32(int prec, const float* q, const float* k, const float* v, int64_t ld,
+                                    const float* pos, int64_t ldp, const float* u, const float* vbias,
+                                    const int64_t* lengths_or_null, float* ctx, int64_t ldo, float* lse_or_null, int B,
+                                    int T, int H, int dh, float drop_p, uint64_t drop_seed, cfm_stream_t stream);
 int cfm_subsample_conv2_relu_mfma16_f32(int prec, const float* h1, const float* w2p, const float* b2, float* h2, int B,
                                         int F1, int T1, int C, cfm_stream_t stream);
 int cfm_gemm_bwd_batched_mfma16_f32(int prec, const float* A, int a_col, int64_t lda, const void* B, int b_col,

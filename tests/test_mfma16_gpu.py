@@ -196,3 +196,45 @@ def test_cfg1_model_bf16_argmax_and_drift(dev):
     assert rel_l2(enc, g["enc"]) < 2e-2
     mism = (logits.argmax(-1).cpu() != g["argmax"]).float().mean().item()
     assert mism < 0.02, mism
+
+
+@pytest.mark.parametrize("dt16", DT)
+@pytest.mark.parametrize("B,T,H,dh,lengths", [(2, 1, 4, 8, [1, 1]), (3, 7, 4, 8, [7, 5, 1]), (2, 49, 4, 36, [49, 39]),
+                                             (2, 130, 2, 32, [130, 64]), (2, 249, 8, 64, [249, 131]), (2, 40, 2, 8, [40, 0]),
+                                             (1, 300, 2, 64, None)])
+def test_mfma16_attention_forward(dev, B, T, H, dh, lengths, dt16):
+    """16-bit-MFMA attention vs the float64 oracle fed the ROUNDED q+u, q+v, k, v and positions (the probabilities are
+    rounded once more inside the kernel for P.V: tolerance 2^-8 / 2^-11) and vs the unrounded oracle (16-bit budget)."""
+    from conformer_amd import ops
+    d = H * dh
+    qkv = rnd(B, T, 3 * d, seed=11) * 0.5
+    pos = rnd(2 * T - 1, d, seed=12) * 0.5
+    u, v = rnd(H, dh, seed=13) * 0.3, rnd(H, dh, seed=14) * 0.3
+    L = None if lengths is None else torch.tensor(lengths, dtype=torch.int64)
+    G = lambda t: t.to(dev)
+    with torch.autocast("cuda", dtype=dt16):
+        ctx = ops.relpos_attention(G(qkv), G(pos), G(u), G(v), None if L is None else G(L), H)
+        ctx2, lse = ops.relpos_attention_train(G(qkv), G(pos), G(u), G(v), None if L is None else G(L), H)
+    assert torch.equal(ctx, ctx2) and torch.isfinite(lse).all()
+    r16 = lambda t: t.to(dt16).double()
+    q, k, vv = (t.reshape(B, T, H, dh) for t in qkv.split(d, dim=-1))
+    zero = torch.zeros(H, dh, dtype=torch.float64)
+    # oracle on rounded operands: scores from r16(q+u).r16(k) + r16(q+v).r16(p); the biases are folded into two query sets,
+    # which relpos_attention_core cannot express, so compose it from its parts
+    import math
+    qu, qv = r16(q + u), r16(q + v)
+    kk, vr, pp = r16(k), r16(vv), r16(pos).view(2 * T - 1, H, dh)
+    content = torch.einsum("bihc,bkhc->bhik", qu, kk)
+    full = torch.einsum("bihc,jhc->bhij", qv, pp)
+    i = torch.arange(T)[:, None]; kx = torch.arange(T)[None, :]
+    posb = full.gather(-1, ((T - 1) - (i - kx)).expand(B, H, T, T))
+    s = (content + posb) / math.sqrt(dh)
+    if L is not None:
+        pad = torch.arange(T)[None, :] >= L[:, None]
+        s = s.masked_fill(pad[:, None, None, :], torch.finfo(torch.float32).min)
+    ref16 = torch.einsum("bhik,bkhc->bihc", torch.softmax(s, -1), vr).reshape(B, T, d)
+    ref = O.relpos_attention_core(q.double(), k.double(), vv.double(), pos.double().view(2 * T - 1, H, dh), u.double(),
+                                  v.double(), L)
+    tol_p = 6e-3 if dt16 == torch.bfloat16 else 8e-4
+    assert rel_l2(ctx, ref16) < tol_p
+    assert rel_l2(ctx, ref) < (2e-2 if dt16 == torch.bfloat16 else 3e-3)
