@@ -5,6 +5,7 @@ kernels on torch's current stream.  Inputs on the wrong device/dtype raise; ther
 """
 from __future__ import annotations
 
+import threading
 import weakref
 from typing import Optional, Tuple
 
@@ -32,7 +33,8 @@ def _p(t: Optional[torch.Tensor]) -> Optional[int]:
 
 
 PREC_F32, PREC_BF16, PREC_FP16 = 0, 1, 2          # CFM_PREC_* of include/conformer_hip.h (0 = the fp32 MFMA path)
-_forced_prec: Optional[int] = None
+_tls = threading.local()       # .forced: precision pinned by `precision(...)` for the current thread (autograd runs the
+                               # backward on its own device thread: a process-global would race between threads)
 
 
 def mfma16_prec() -> int:
@@ -40,8 +42,9 @@ def mfma16_prec() -> int:
     dtype (bf16, or fp16 as the reference's `--fp16 1` does, train.py:6,217,232) and run on the 16-bit matrix pipe with
     fp32 accumulation and fp32 tensors -- the arithmetic autocast gives nn.Linear / Conv.  Backward passes run under
     `precision(...)` with the value their forward saw (autocast is not active inside autograd's backward)."""
-    if _forced_prec is not None:
-        return _forced_prec
+    forced = getattr(_tls, "forced", None)
+    if forced is not None:
+        return forced
     if not torch.is_autocast_enabled("cuda"):
         return PREC_F32
     dt = torch.get_autocast_dtype("cuda")
@@ -59,13 +62,12 @@ class precision:
         self.prec, self.prev = prec, None
 
     def __enter__(self):
-        global _forced_prec
-        self.prev, _forced_prec = _forced_prec, self.prec
+        self.prev = getattr(_tls, "forced", None)
+        _tls.forced = self.prec
         return self
 
     def __exit__(self, *exc):
-        global _forced_prec
-        _forced_prec = self.prev
+        _tls.forced = self.prev
         return False
 
 
