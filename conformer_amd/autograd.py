@@ -109,11 +109,11 @@ class FeedForwardFn(Function):
     @staticmethod
     @_fwd_prec
     def forward(ctx, x, ln_w, ln_b, w1, b1, w2, b2, alpha, eps, drop_p=0.0):
-        h0, mean, rstd = ops.layernorm_train(x, ln_w, ln_b, eps)
+        h0, mean, rstd = ops.layernorm_train(x, ln_w, ln_b, eps, for_gemm=True)
         ctx.drop_p = float(drop_p)
         ctx.seeds = ops.new_seeds(2) if ctx.drop_p > 0.0 else (0, 0)
         # h = drop1(swish(z)); out = alpha * drop2(h.W2^T + b2) + x     (ffn.py:17-21)
-        h, z = ops.linear_train("swish", h0, w1, b1, drop_p=ctx.drop_p, seed=ctx.seeds[0], save_z=True)
+        h, z = ops.linear_train("swish", h0, w1, b1, drop_p=ctx.drop_p, seed=ctx.seeds[0], save_z=True, for_gemm=True)
         out = ops.linear_train("residual", h, w2, b2, residual=x, alpha=alpha, drop_p=ctx.drop_p, seed=ctx.seeds[1])
         ctx.save_for_backward(x, ln_w, mean, rstd, h0, z, h, w1, w2)
         ctx.alpha = alpha
@@ -140,7 +140,7 @@ class SelfAttentionFn(Function):
     @staticmethod
     @_fwd_prec
     def forward(ctx, x, ln_w, ln_b, wq, bq, wk, bk, wv, bv, pos, u, vb, wo, bo, lengths, n_heads, eps, drop_p=0.0):
-        h0, mean, rstd = ops.layernorm_train(x, ln_w, ln_b, eps)
+        h0, mean, rstd = ops.layernorm_train(x, ln_w, ln_b, eps, for_gemm=True)
         wqkv = torch.cat([wq, wk, wv], dim=0)
         bqkv = torch.cat([bq, bk, bv], dim=0)
         qkv = ops.linear(h0, wqkv, bqkv)
@@ -182,7 +182,7 @@ class ConvModuleFn(Function):
     @_fwd_prec
     def forward(ctx, x, ln_w, ln_b, w1, b1, wd, bd, bn_w, bn_b, bn_mean, bn_var, w2, b2, eps_ln, eps_bn, train_bn,
                 momentum, drop_p=0.0):
-        h0, mean, rstd = ops.layernorm_train(x, ln_w, ln_b, eps_ln)
+        h0, mean, rstd = ops.layernorm_train(x, ln_w, ln_b, eps_ln, for_gemm=True)
         z = ops.linear(h0, w1, b1)                                  # (B,T,2C) pre-activation kept for GLU'
         g = ops.glu_fwd(z)
         if train_bn:

@@ -16,8 +16,11 @@ namespace {
 
 // W16: the weight operand is already stored in the 16-bit type (a cached cast of the fp32 master weights, made once per
 // optimizer step): half the L2->LDS bytes of the operand that every row tile re-reads, and no conversion.
-template <typename T16, int BM, int BN, int EPI, bool CONV, bool W16>
+// A16 (with W16, plain rows only): the activation operand is a 16-bit tensor too (LayerNorm / Swish outputs written in
+// the 16-bit type by their producers), lda in elements.
+template <typename T16, int BM, int BN, int EPI, bool CONV, bool W16, bool A16 = false>
 __global__ __launch_bounds__(256, 2) void gemm_mfma16_kernel(const GemmArgs g) {
+    static_assert(!A16 || (W16 && !CONV), "16-bit A operand: plain rows, together with 16-bit weights");
     using x8 = typename Lowp<T16>::x8;
     using x4 = typename Lowp<T16>::x4;
     constexpr int TM = BM / 64, TN = BN / 64, BK = 64;
@@ -42,11 +45,22 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma16_kernel(const GemmArgs g) {
     const int srow = tid >> 4, sch = tid & 15;
     constexpr int NBH = BN / 32;                              // W16: 16-byte loads per thread per K-tile (8 lanes per row)
     const int hrow = tid >> 3, hch = tid & 7;
-    const float* a_ptr[NA];
+    constexpr int NAH = BM / 32;
+    const float* a_ptr[A16 ? 1 : NA];
+    const T16* ah_ptr[A16 ? NAH : 1];
     const float* w_ptr[W16 ? 1 : NB];
     const T16* wh_ptr[W16 ? NBH : 1];
+    if (A16) {
 #pragma unroll
-    for (int p = 0; p < NA; ++p) a_ptr[p] = a_row_ptr<CONV>(g, m0 + srow + 16 * p);
+        for (int p = 0; p < NAH; ++p) {
+            int64_t m = m0 + hrow + 32 * p;
+            if (m >= g.M) m = g.M - 1;
+            ah_ptr[p] = reinterpret_cast<const T16*>(g.A) + m * g.lda;
+        }
+    } else {
+#pragma unroll
+        for (int p = 0; p < NA; ++p) a_ptr[p] = a_row_ptr<CONV>(g, m0 + srow + 16 * p);
+    }
     if (W16) {
 #pragma unroll
         for (int p = 0; p < NBH; ++p)
@@ -55,17 +69,27 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma16_kernel(const GemmArgs g) {
 #pragma unroll
         for (int p = 0; p < NB; ++p) w_ptr[p] = w_row_ptr<EPI, BN>(g, n0, srow + 16 * p);
     }
-    f32x4 ra[NA], rb[W16 ? 1 : NB];
-    x8 rbh[W16 ? NBH : 1];
+    f32x4 ra[A16 ? 1 : NA], rb[W16 ? 1 : NB];
+    x8 rah[A16 ? NAH : 1], rbh[W16 ? NBH : 1];
     auto load_tile = [&](int kt) {
         const int k = kt * BK + sch * 4;
         const int64_t aoff = a_k_offset<CONV>(g, kt * BK) + sch * 4;
         const bool ok = k < g.K;
+        const int kh = kt * BK + hch * 8;                      // K % 8 == 0: a 16-byte chunk is all in or all out
+        if (A16) {
 #pragma unroll
-        for (int p = 0; p < NA; ++p)
-            ra[p] = ok ? *reinterpret_cast<const f32x4*>(a_ptr[p] + aoff) : f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int p = 0; p < NAH; ++p) {
+                if (kh < g.K) rah[p] = *reinterpret_cast<const x8*>(ah_ptr[p] + kh);
+                else
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) rah[p][e] = (T16)0.f;
+            }
+        } else {
+#pragma unroll
+            for (int p = 0; p < NA; ++p)
+                ra[p] = ok ? *reinterpret_cast<const f32x4*>(a_ptr[p] + aoff) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
         if (W16) {
-            const int kh = kt * BK + hch * 8;                  // K % 8 == 0: a 16-byte chunk is all in or all out
 #pragma unroll
             for (int p = 0; p < NBH; ++p) {
                 if (kh < g.K) rbh[p] = *reinterpret_cast<const x8*>(wh_ptr[p] + kh);
@@ -80,9 +104,15 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma16_kernel(const GemmArgs g) {
         }
     };
     auto store_tile = [&](int buf) {
+        if (A16) {
 #pragma unroll
-        for (int p = 0; p < NA; ++p)
-            *reinterpret_cast<x4*>(As + (buf * BM + srow + 16 * p) * ROWB + sch * 4) = Lowp<T16>::cvt4(ra[p]);
+            for (int p = 0; p < NAH; ++p)
+                *reinterpret_cast<x8*>(As + (buf * BM + hrow + 32 * p) * ROWB + hch * 8) = rah[p];
+        } else {
+#pragma unroll
+            for (int p = 0; p < NA; ++p)
+                *reinterpret_cast<x4*>(As + (buf * BM + srow + 16 * p) * ROWB + sch * 4) = Lowp<T16>::cvt4(ra[p]);
+        }
         if (W16) {
 #pragma unroll
             for (int p = 0; p < NBH; ++p)
@@ -134,25 +164,33 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma16_kernel(const GemmArgs g) {
 }
 
 template <typename T16, int BM, int BN, int EPI, bool CONV>
-int launch_cfg(GemmArgs g, bool w16, hipStream_t s) {
+int launch_cfg(GemmArgs g, int src16, hipStream_t s) {          // src16: 0 = fp32 operands, 1 = 16-bit W, 2 = 16-bit A and W
     const int ncols = EPI == EPI_GLU ? g.n_out : g.N;
     const int bn = EPI == EPI_GLU ? BN / 2 : BN;
     g.tiles_m = (unsigned)((g.M + BM - 1) / BM);
     g.tiles_n = (unsigned)((ncols + bn - 1) / bn);
-    if (w16) hipLaunchKernelGGL((gemm_mfma16_kernel<T16, BM, BN, EPI, CONV, true>), dim3(g.tiles_m * g.tiles_n), dim3(256), 0, s, g);
-    else hipLaunchKernelGGL((gemm_mfma16_kernel<T16, BM, BN, EPI, CONV, false>), dim3(g.tiles_m * g.tiles_n), dim3(256), 0, s, g);
+    const dim3 grid(g.tiles_m * g.tiles_n);
+    if constexpr (!CONV) {
+        if (src16 == 2) {
+            hipLaunchKernelGGL((gemm_mfma16_kernel<T16, BM, BN, EPI, CONV, true, true>), grid, dim3(256), 0, s, g);
+            return cfm_launch_status();
+        }
+    }
+    if (src16 == 1) hipLaunchKernelGGL((gemm_mfma16_kernel<T16, BM, BN, EPI, CONV, true>), grid, dim3(256), 0, s, g);
+    else if (src16 == 0) hipLaunchKernelGGL((gemm_mfma16_kernel<T16, BM, BN, EPI, CONV, false>), grid, dim3(256), 0, s, g);
+    else return CFM_ERR_UNSUPPORTED;
     return cfm_launch_status();
 }
 
 template <typename T16, int EPI, bool CONV>
-int launch_t(const GemmArgs& g, bool w16, hipStream_t s) {
+int launch_t(const GemmArgs& g, int src16, hipStream_t s) {
     const int ncols = EPI == EPI_GLU ? g.n_out : g.N;
     const int bn = EPI == EPI_GLU ? 64 : 128;
     const int64_t t128 = ((g.M + 127) / 128) * ((ncols + bn - 1) / bn);
     if constexpr (EPI == EPI_GLU) {
-        return t128 >= 512 ? launch_cfg<T16, 128, 128, EPI, CONV>(g, w16, s) : launch_cfg<T16, 64, 128, EPI, CONV>(g, w16, s);
+        return t128 >= 512 ? launch_cfg<T16, 128, 128, EPI, CONV>(g, src16, s) : launch_cfg<T16, 64, 128, EPI, CONV>(g, src16, s);
     } else {
-        return t128 >= 512 ? launch_cfg<T16, 128, 128, EPI, CONV>(g, w16, s) : launch_cfg<T16, 64, 64, EPI, CONV>(g, w16, s);
+        return t128 >= 512 ? launch_cfg<T16, 128, 128, EPI, CONV>(g, src16, s) : launch_cfg<T16, 64, 64, EPI, CONV>(g, src16, s);
     }
 }
 
@@ -164,9 +202,9 @@ __global__ __launch_bounds__(256) void cast16_kernel(const float* __restrict__ s
 }
 
 template <int EPI, bool CONV>
-int launch(int prec, const GemmArgs& g, bool w16, hipStream_t s) {
-    if (prec == CFM_PREC_BF16) return launch_t<__bf16, EPI, CONV>(g, w16, s);
-    if (prec == CFM_PREC_FP16) return launch_t<_Float16, EPI, CONV>(g, w16, s);
+int launch(int prec, const GemmArgs& g, int src16, hipStream_t s) {
+    if (prec == CFM_PREC_BF16) return launch_t<__bf16, EPI, CONV>(g, src16, s);
+    if (prec == CFM_PREC_FP16) return launch_t<_Float16, EPI, CONV>(g, src16, s);
     return CFM_ERR_UNSUPPORTED;
 }
 
@@ -175,33 +213,35 @@ int launch(int prec, const GemmArgs& g, bool w16, hipStream_t s) {
 // prec: CFM_PREC_BF16 | CFM_PREC_FP16.  epi: 0 bias | 1 bias+swish | 2 bias+relu | 3 bias+GLU (N = n_out columns of C,
 // W has 2*n_out rows) | 4 alpha*y + R.  Same layouts and argument rules as the fp32 entry points (cfm_gemm_train_f32 for
 // Z_or_null / drop_p / drop_seed); results differ from them by the 16-bit rounding of A and W only.
-extern "C" int cfm_gemm_mfma16_f32(int prec, int epi, const float* A, const void* W, int w_is_16bit, const float* bias,
-                                   const float* R_or_null, float alpha, float* C, float* Z_or_null, int64_t M, int N, int K,
-                                   int64_t lda, int64_t ldr, int64_t ldc, float drop_p, uint64_t drop_seed,
-                                   cfm_stream_t stream) {
+extern "C" int cfm_gemm_mfma16_f32(int prec, int epi, const void* A, int a_is_16bit, const void* W, int w_is_16bit,
+                                   const float* bias, const float* R_or_null, float alpha, void* C, int c_is_16bit,
+                                   float* Z_or_null, int64_t M, int N, int K, int64_t lda, int64_t ldr, int64_t ldc,
+                                   float drop_p, uint64_t drop_seed, cfm_stream_t stream) {
     CFM_REQUIRE(A && W && bias && C, CFM_ERR_NULL);
     CFM_REQUIRE(!w_is_16bit || (K & 7) == 0, CFM_ERR_BAD_SHAPE);
-    const bool w16 = w_is_16bit != 0;
+    CFM_REQUIRE(!a_is_16bit || (w_is_16bit && (lda & 7) == 0), CFM_ERR_BAD_SHAPE);
+    const int src16 = a_is_16bit ? 2 : (w_is_16bit ? 1 : 0);
     CFM_REQUIRE(M > 0 && N > 0 && K > 0 && (K & 3) == 0 && (lda & 3) == 0 && lda >= K && ldc >= N, CFM_ERR_BAD_SHAPE);
     CFM_REQUIRE(drop_p >= 0.f && drop_p < 1.f, CFM_ERR_BAD_SHAPE);
     CFM_REQUIRE(CFM_ALIGNED16(A) && CFM_ALIGNED16(W), CFM_ERR_ALIGN);
     GemmArgs g{};
-    g.A = A; g.W = static_cast<const float*>(W); g.bias = bias; g.R = R_or_null; g.C = C; g.M = M; g.K = K; g.lda = lda;
+    g.A = static_cast<const float*>(A); g.W = static_cast<const float*>(W); g.bias = bias; g.R = R_or_null;
+    g.C = static_cast<float*>(C); g.c_prec = c_is_16bit ? prec : 0; g.M = M; g.K = K; g.lda = lda;
     g.ldr = ldr; g.ldc = ldc; g.alpha = alpha; g.Zsave = Z_or_null; g.drop_p = drop_p; g.drop_seed = drop_seed;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (epi == EPI_GLU) {
         g.n_out = N; g.N = 2 * N;
-        return launch<EPI_GLU, false>(prec, g, w16, s);
+        return launch<EPI_GLU, false>(prec, g, src16, s);
     }
     g.N = N;
     switch (epi) {
-        case EPI_BIAS: return launch<EPI_BIAS, false>(prec, g, w16, s);
-        case EPI_SWISH: return launch<EPI_SWISH, false>(prec, g, w16, s);
-        case EPI_RELU: return launch<EPI_RELU, false>(prec, g, w16, s);
+        case EPI_BIAS: return launch<EPI_BIAS, false>(prec, g, src16, s);
+        case EPI_SWISH: return launch<EPI_SWISH, false>(prec, g, src16, s);
+        case EPI_RELU: return launch<EPI_RELU, false>(prec, g, src16, s);
         case EPI_RESID:
             CFM_REQUIRE(R_or_null != nullptr, CFM_ERR_NULL);
             CFM_REQUIRE(ldr >= N, CFM_ERR_BAD_SHAPE);
-            return launch<EPI_RESID, false>(prec, g, w16, s);
+            return launch<EPI_RESID, false>(prec, g, src16, s);
         default: return CFM_ERR_UNSUPPORTED;
     }
 }
@@ -217,7 +257,7 @@ extern "C" int cfm_subsample_conv2_relu_mfma16_f32(int prec, const float* h1, co
     g.cT1 = T1; g.cF1 = F1; g.cC = C; g.cT2 = (T1 - 1) / 2; g.cF2 = (F1 - 1) / 2;
     g.A = h1; g.W = w2p; g.bias = b2; g.C = h2;
     g.M = (int64_t)B * g.cT2 * g.cF2; g.N = C; g.K = 9 * C; g.lda = 0; g.ldc = C; g.alpha = 1.f;
-    return launch<EPI_RELU, true>(prec, g, false, static_cast<hipStream_t>(stream));
+    return launch<EPI_RELU, true>(prec, g, 0, static_cast<hipStream_t>(stream));
 }
 
 // dst (16-bit, prec) <- RNE(src) for n fp32 values (n % 4 == 0): the per-optimizer-step cast of the master weights that

@@ -16,6 +16,7 @@ struct GemmArgs {
     int cT2, cF2, cT1, cF1, cC;     // conv mode geometry
     unsigned tiles_m, tiles_n;
     int occ_cap;                    // 0 = natural; else blocks/CU cap enforced through a dynamic-LDS pad
+    int c_prec;                     // 0: C is fp32; CFM_PREC_BF16 / CFM_PREC_FP16: C is stored in that 16-bit type (ldc in elements)
     unsigned long long* trace;      // diagnostics: per-block {start, end} s_memrealtime stamps + HW id, or NULL
 };
 
@@ -74,7 +75,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const f32x16 (&
                                               int wr, int wc, int li, int hf) {
     const int ncols = EPI == EPI_GLU ? g.n_out : g.N;
     const bool vec_ok = ((g.ldc & 3) == 0) && ((ncols & 3) == 0) && (EPI != EPI_RESID || (g.ldr & 3) == 0) &&
-                        ((reinterpret_cast<uintptr_t>(g.C) & 15) == 0) &&
+                        ((reinterpret_cast<uintptr_t>(g.C) & (g.c_prec ? 7 : 15)) == 0) &&
                         (EPI != EPI_RESID || (reinterpret_cast<uintptr_t>(g.R) & 15) == 0);
 #pragma unroll
     for (int mt = 0; mt < TM; ++mt) {
@@ -118,7 +119,13 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const f32x16 (&
                         }
                         if (EPI == EPI_RELU) v[e] = fmaxf(v[e], 0.f);
                     }
-                    *reinterpret_cast<f32x4*>(g.C + row * g.ldc + col) = f32x4{v[0], v[1], v[2], v[3]};
+                    if (g.c_prec == 0) *reinterpret_cast<f32x4*>(g.C + row * g.ldc + col) = f32x4{v[0], v[1], v[2], v[3]};
+                    else if (g.c_prec == CFM_PREC_BF16)
+                        *reinterpret_cast<Lowp<__bf16>::x4*>(reinterpret_cast<__bf16*>(g.C) + row * g.ldc + col) =
+                            Lowp<__bf16>::cvt4(f32x4{v[0], v[1], v[2], v[3]});
+                    else
+                        *reinterpret_cast<Lowp<_Float16>::x4*>(reinterpret_cast<_Float16*>(g.C) + row * g.ldc + col) =
+                            Lowp<_Float16>::cvt4(f32x4{v[0], v[1], v[2], v[3]});
                 } else {                                                       // odd leading dims / widths: scalar path
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
@@ -133,7 +140,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const f32x16 (&
                         if (EPI == EPI_SWISH && g.Zsave) g.Zsave[row * g.ldc + col + e] = x;
                         if (EPI == EPI_SWISH) x = swishf_acc(x) * keep;
                         if (EPI == EPI_RELU) x = fmaxf(x, 0.f);
-                        g.C[row * g.ldc + col + e] = x;
+                        if (g.c_prec == 0) g.C[row * g.ldc + col + e] = x;
+                        else if (g.c_prec == CFM_PREC_BF16) reinterpret_cast<__bf16*>(g.C)[row * g.ldc + col + e] = (__bf16)x;
+                        else reinterpret_cast<_Float16*>(g.C)[row * g.ldc + col + e] = (_Float16)x;
                     }
                 }
             }

@@ -106,7 +106,7 @@ class MultiHeadSelfAttentionModule(nn.Module):
                                            a.out_proj.weight, a.out_proj.bias, lengths, a.n_heads, self.layer_norm.eps,
                                            active_dropout(self.dropout))
             return out if residual is not None else out - x
-        xn = ops.layernorm(x, self.layer_norm.weight, self.layer_norm.bias, self.layer_norm.eps)
+        xn = ops.layernorm(x, self.layer_norm.weight, self.layer_norm.bias, self.layer_norm.eps, for_gemm=True)
         return self.attention.fused(xn, pos_table, lengths, residual, pos_projected)
 
     def forward(self, x: torch.Tensor, pos_embedding: torch.Tensor, mask: Optional[torch.Tensor] = None):

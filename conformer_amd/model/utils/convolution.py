@@ -44,7 +44,7 @@ class ConvolutionModule(nn.Module):
                                       "track_running_stats=True) is built")
         if train_bn and not ag.needs_grad(self, x, residual):
             # .train() under no_grad: still batch statistics + running-stat update (nn.BatchNorm1d semantics)
-            h = ops.layernorm(x, self.layer_norm.weight, self.layer_norm.bias, self.layer_norm.eps)
+            h = ops.layernorm(x, self.layer_norm.weight, self.layer_norm.bias, self.layer_norm.eps, for_gemm=True)
             g = ops.linear_glu(h, self.pointwise_conv_1.weight, self.pointwise_conv_1.bias)
             bm, bv = ops.dwconv_bn_batch_stats(g, self.deepwise_conv.weight, self.deepwise_conv.bias, bn.running_mean,
                                                bn.running_var, bn.momentum)
@@ -66,7 +66,7 @@ class ConvolutionModule(nn.Module):
             if train_bn:
                 bn.num_batches_tracked += 1
             return out if residual is not None else out - x
-        h = ops.layernorm(x, self.layer_norm.weight, self.layer_norm.bias, self.layer_norm.eps)
+        h = ops.layernorm(x, self.layer_norm.weight, self.layer_norm.bias, self.layer_norm.eps, for_gemm=True)
         g = ops.linear_glu(h, self.pointwise_conv_1.weight, self.pointwise_conv_1.bias)
         s = ops.dwconv_bn_swish(g, self.deepwise_conv.weight, self.deepwise_conv.bias, bn.weight, bn.bias,
                                 bn.running_mean, bn.running_var, bn.eps)

@@ -36,8 +36,8 @@ class FeedForwardModule(nn.Module):
                                          float(alpha), self.layer_norm.eps, active_dropout(self.dropout_1))
             # the Function always folds `+ x`; a stand-alone call (no residual) removes it again
             return out if residual is not None else out - x
-        h = ops.layernorm(x, self.layer_norm.weight, self.layer_norm.bias, self.layer_norm.eps)
-        h = ops.linear(h, self.hidden_linear.weight, self.hidden_linear.bias, act="swish")
+        h = ops.layernorm(x, self.layer_norm.weight, self.layer_norm.bias, self.layer_norm.eps, for_gemm=True)
+        h = ops.linear(h, self.hidden_linear.weight, self.hidden_linear.bias, act="swish", for_gemm=True)
         if residual is None:
             return ops.linear(h, self.out_linear.weight, self.out_linear.bias)
         return ops.linear_residual(h, self.out_linear.weight, self.out_linear.bias, residual, alpha)

@@ -33,6 +33,7 @@ def _p(t: Optional[torch.Tensor]) -> Optional[int]:
 
 
 PREC_F32, PREC_BF16, PREC_FP16 = 0, 1, 2          # CFM_PREC_* of include/conformer_hip.h (0 = the fp32 MFMA path)
+_DT16 = {PREC_BF16: torch.bfloat16, PREC_FP16: torch.float16}
 _tls = threading.local()       # .forced: precision pinned by `precision(...)` for the current thread (autograd runs the
                                # backward on its own device thread: a process-global would race between threads)
 
@@ -76,9 +77,6 @@ def bf16_mfma_active() -> bool:
 
 
 _W16_CACHE = {}        # data_ptr -> (weakref(base tensor), version, prec, shape, 16-bit tensor): per-optimizer-step weight casts
-_DT16 = {PREC_BF16: torch.bfloat16, PREC_FP16: torch.float16}
-
-
 def weight16(w: torch.Tensor, prec: int) -> Optional[torch.Tensor]:
     """The weight matrix rounded to the 16-bit matrix-pipe type, cached until the parameter changes in place (optimizer
     step / load_state_dict bump `_version`).  None when the 16-bit operand path does not apply (K % 8 != 0)."""
@@ -100,12 +98,22 @@ def weight16(w: torch.Tensor, prec: int) -> Optional[torch.Tensor]:
     return out
 
 
+def out16_ok(k: int) -> int:
+    """Precision in which a producer may write a tensor that only feeds GEMM operands with contraction length k (0: keep fp32)."""
+    prec = mfma16_prec()
+    return prec if prec and k % 8 == 0 else 0
+
+
 def _mfma16_gemm(prec: int, epi: int, a, w2, b, c, m, n, k, res=None, alpha: float = 1.0, z=None, drop_p: float = 0.0,
                  seed: int = 0):
     w16 = weight16(w2, prec)
-    st = _lib.load().cfm_gemm_mfma16_f32(prec, epi, a.data_ptr(), (w2 if w16 is None else w16).data_ptr(), int(w16 is not None),
-                                         b.data_ptr(), _p(res), alpha, c.data_ptr(),
-                                         _p(z), m, n, k, k, n, n, float(drop_p), int(seed), _stream())
+    a16 = a.dtype != torch.float32
+    if a16 and (w16 is None or a.dtype != _DT16[prec]):
+        raise _lib.ConformerHipError(f"16-bit A operand ({a.dtype}) does not match the precision mode / weight shape")
+    st = _lib.load().cfm_gemm_mfma16_f32(prec, epi, a.data_ptr(), int(a16), (w2 if w16 is None else w16).data_ptr(),
+                                         int(w16 is not None), b.data_ptr(), _p(res), alpha, c.data_ptr(),
+                                         int(c.dtype != torch.float32), _p(z), m, n, k, k, n, n, float(drop_p), int(seed),
+                                         _stream())
     _lib.check(st, "cfm_gemm_mfma16_f32")
     return c
 
@@ -115,10 +123,18 @@ def subsampled_length(n: int) -> int:
 
 
 def layernorm(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, eps: float = 1e-5,
-              out: Optional[torch.Tensor] = None) -> torch.Tensor:
+              out: Optional[torch.Tensor] = None, for_gemm: bool = False) -> torch.Tensor:
+    """for_gemm: the result only feeds GEMM operands -- under autocast it is written in the 16-bit matrix-pipe type (the
+    GEMM would round it to that type anyway: identical results, half the bytes)."""
     x = _req(x, "x"); weight = _req(weight, "weight"); bias = _req(bias, "bias")
     d = x.shape[-1]
     rows = x.numel() // d
+    p16 = out16_ok(d) if for_gemm and out is None else 0
+    if p16:
+        y = torch.empty(x.shape, device=x.device, dtype=_DT16[p16])
+        _lib.check(_lib.load().cfm_layernorm_fwd_out16_f32(p16, x.data_ptr(), weight.data_ptr(), bias.data_ptr(), y.data_ptr(),
+                                                           None, None, rows, d, eps, _stream()), "cfm_layernorm_fwd_out16_f32")
+        return y
     y = torch.empty_like(x) if out is None else out
     st = _lib.load().cfm_layernorm_fwd_f32(x.data_ptr(), weight.data_ptr(), bias.data_ptr(), y.data_ptr(),
                                            None, None, rows, d, eps, _stream())
@@ -127,7 +143,8 @@ def layernorm(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, eps: fl
 
 
 def _gemm_common(a: torch.Tensor, w: torch.Tensor, b: torch.Tensor):
-    a = _req(a, "A"); w = _req(w, "W"); b = _req(b, "bias")
+    a = _req(a, "A", a.dtype if isinstance(a, torch.Tensor) and a.dtype in _DT16.values() else torch.float32)
+    w = _req(w, "W"); b = _req(b, "bias")
     k = a.shape[-1]
     m = a.numel() // k
     w2 = w.reshape(w.shape[0], -1)
@@ -136,11 +153,12 @@ def _gemm_common(a: torch.Tensor, w: torch.Tensor, b: torch.Tensor):
     return a, w2, b, m, w2.shape[0], k
 
 
-def linear(a, w, b, act: str = "none") -> torch.Tensor:
-    """y = act(a @ w.T + b); act in {none, swish, relu}."""
+def linear(a, w, b, act: str = "none", for_gemm: bool = False) -> torch.Tensor:
+    """y = act(a @ w.T + b); act in {none, swish, relu}.  for_gemm: see layernorm (y feeds a GEMM of contraction length n)."""
     a, w2, b, m, n, k = _gemm_common(a, w, b)
-    c = torch.empty(*a.shape[:-1], n, device=a.device, dtype=a.dtype)
     prec = mfma16_prec()
+    p16 = out16_ok(n) if for_gemm else 0
+    c = torch.empty(*a.shape[:-1], n, device=a.device, dtype=_DT16[p16] if p16 else torch.float32)
     if prec:
         return _mfma16_gemm(prec, {"none": 0, "swish": 1, "relu": 2}[act], a, w2, b, c, m, n, k)
     fn = {"none": "cfm_gemm_bias_f32", "swish": "cfm_gemm_bias_swish_f32", "relu": "cfm_gemm_bias_relu_f32"}[act]
@@ -153,7 +171,7 @@ def linear_glu(a, w, b) -> torch.Tensor:
     """(a @ Wv.T + bv) * sigmoid(a @ Wg.T + bg) with W = [Wv; Wg] (pointwise Conv1d(d->2d) + GLU)."""
     a, w2, b, m, n2, k = _gemm_common(a, w, b)
     n = n2 // 2
-    c = torch.empty(*a.shape[:-1], n, device=a.device, dtype=a.dtype)
+    c = torch.empty(*a.shape[:-1], n, device=a.device, dtype=torch.float32)
     prec = mfma16_prec()
     if prec:
         return _mfma16_gemm(prec, 3, a, w2, b, c, m, n, k)
@@ -167,7 +185,7 @@ def linear_residual(a, w, b, res: torch.Tensor, alpha: float = 1.0) -> torch.Ten
     """alpha * (a @ w.T + b) + res."""
     a, w2, b, m, n, k = _gemm_common(a, w, b)
     res = _req(res, "residual")
-    c = torch.empty(*a.shape[:-1], n, device=a.device, dtype=a.dtype)
+    c = torch.empty(*a.shape[:-1], n, device=a.device, dtype=torch.float32)
     prec = mfma16_prec()
     if prec:
         return _mfma16_gemm(prec, 4, a, w2, b, c, m, n, k, res, alpha)
@@ -287,14 +305,21 @@ def _zeros_split(device, dtype, *shapes):
     return outs
 
 
-def layernorm_train(x, weight, bias, eps: float = 1e-5):
-    """LayerNorm forward that also returns the per-row mean / rstd the backward needs."""
+def layernorm_train(x, weight, bias, eps: float = 1e-5, for_gemm: bool = False):
+    """LayerNorm forward that also returns the per-row mean / rstd the backward needs (for_gemm: see layernorm)."""
     x = _req(x, "x"); weight = _req(weight, "weight"); bias = _req(bias, "bias")
     d = x.shape[-1]
     rows = x.numel() // d
-    y = torch.empty_like(x)
     mean = torch.empty(rows, device=x.device, dtype=x.dtype)
     rstd = torch.empty(rows, device=x.device, dtype=x.dtype)
+    p16 = out16_ok(d) if for_gemm else 0
+    if p16:
+        y = torch.empty(x.shape, device=x.device, dtype=_DT16[p16])
+        _lib.check(_lib.load().cfm_layernorm_fwd_out16_f32(p16, x.data_ptr(), weight.data_ptr(), bias.data_ptr(), y.data_ptr(),
+                                                           mean.data_ptr(), rstd.data_ptr(), rows, d, eps, _stream()),
+                   "cfm_layernorm_fwd_out16_f32")
+        return y, mean, rstd
+    y = torch.empty_like(x)
     st = _lib.load().cfm_layernorm_fwd_f32(x.data_ptr(), weight.data_ptr(), bias.data_ptr(), y.data_ptr(),
                                            mean.data_ptr(), rstd.data_ptr(), rows, d, eps, _stream())
     _lib.check(st, "cfm_layernorm_fwd_f32")
@@ -337,12 +362,13 @@ def new_seeds(n: int):
 
 
 def linear_train(epi: str, a, w, b, *, residual=None, alpha: float = 1.0, drop_p: float = 0.0, seed: int = 0,
-                 save_z: bool = False):
+                 save_z: bool = False, for_gemm: bool = False):
     """Training forward GEMM with dropout fused in the epilogue.  epi: 'bias' | 'swish' | 'residual'.
-    Returns C (and Z, the pre-activation, when save_z)."""
+    Returns C (and Z, the pre-activation, when save_z).  for_gemm: see layernorm."""
     a, w2, b, m, n, k = _gemm_common(a, w, b)
-    c = torch.empty(*a.shape[:-1], n, device=a.device, dtype=a.dtype)
-    z = torch.empty_like(c) if save_z else None
+    p16 = out16_ok(n) if for_gemm else 0
+    c = torch.empty(*a.shape[:-1], n, device=a.device, dtype=_DT16[p16] if p16 else torch.float32)
+    z = torch.empty(*a.shape[:-1], n, device=a.device, dtype=torch.float32) if save_z else None
     code = {"bias": 0, "swish": 1, "residual": 4}[epi]
     if residual is not None:
         residual = _req(residual, "residual")
@@ -441,8 +467,9 @@ def linear_bwd(x2d, w, dy2d, *, alpha: float = 1.0, Z=None, need_dx: bool = True
         w16 = weight16(w2, prec) if prec else None              # the cast the forward made (same parameter version)
         dx = gemm_bwd(dy2d, False, w2 if w16 is None else w16, True, m, k, n, alpha=alpha, Z=Z, drop_p=drop_p,
                       drop_seed=drop_seed, prec=prec, b16=w16 is not None)
-    dw, db = _zeros_split(x2d.device, x2d.dtype, (n, k), (n,))
-    gemm_bwd(dy2d, True, x2d, True, n, k, m, alpha=alpha, allow_split=True, out=dw, prec=prec)
+    dw, db = _zeros_split(dy2d.device, dy2d.dtype, (n, k), (n,))
+    gemm_bwd(dy2d, True, x2d, True, n, k, m, alpha=alpha, allow_split=True, out=dw, prec=prec,
+             b16=x2d.dtype != torch.float32)            # x saved in the 16-bit type by its producer (for_gemm)
     colsum(dy2d, alpha, out=db)
     return dx, dw.view_as(w), db
 

@@ -124,11 +124,17 @@ int cfm_pack_linear_weight_f32(const float* wl, float* wlp, int d_out, int C, in
  *      forms need C % 64 == 0). */
 #define CFM_PREC_BF16 1
 #define CFM_PREC_FP16 2
-int cfm_gemm_mfma16_f32(int prec, int epi, const float* A, const void* W, int w_is_16bit, const float* bias,
-                        const float* R_or_null, float alpha, float* C, float* Z_or_null, int64_t M, int N, int K,
-                        int64_t lda, int64_t ldr, int64_t ldc, float drop_p, uint64_t drop_seed, cfm_stream_t stream);
+int cfm_gemm_mfma16_f32(int prec, int epi, const void* A, int a_is_16bit, const void* W, int w_is_16bit,
+                        const float* bias, const float* R_or_null, float alpha, void* C, int c_is_16bit,
+                        float* Z_or_null, int64_t M, int N, int K, int64_t lda, int64_t ldr, int64_t ldc,
+                        float drop_p, uint64_t drop_seed, cfm_stream_t stream);
 /*      w_is_16bit / b_is_16bit: that operand is already stored in `prec` (cfm_cast16_f32 of the fp32 master weights, once
- *      per optimizer step): half the bytes of the operand every row tile re-reads; results are bit-identical. K % 8 == 0. */
+ *      per optimizer step): half the bytes of the operand every row tile re-reads; results are bit-identical. K % 8 == 0.
+ *      a_is_16bit (needs w_is_16bit; lda % 8 == 0, in elements): A is a 16-bit tensor written by its producer
+ *      (cfm_layernorm_fwd_out16_f32, or a GEMM with c_is_16bit).  c_is_16bit: C is stored in `prec` (ldc in elements). */
+int cfm_layernorm_fwd_out16_f32(int prec, const float* x, const float* gamma, const float* beta, void* y16,
+                                float* mean_or_null, float* rstd_or_null, int64_t rows, int d, float eps,
+                                cfm_stream_t stream);
 int cfm_cast16_f32(int prec, const float* src, void* dst, int64_t n, cfm_stream_t stream);
 int cfm_relpos_attention_mfma16_f32(int prec, const float* q, const float* k, const float* v, int64_t ld,
                                     const float* pos, int64_t ldp, const float* u, const float* vbias,
