@@ -16,11 +16,11 @@ namespace {
 
 // W16: the weight operand is already stored in the 16-bit type (a cached cast of the fp32 master weights, made once per
 // optimizer step): half the L2->LDS bytes of the operand that every row tile re-reads, and no conversion.
-// A16 (with W16, plain rows only): the activation operand is a 16-bit tensor too (LayerNorm / Swish outputs written in
-// the 16-bit type by their producers), lda in elements.
+// A16 (with W16): the activation operand is a 16-bit tensor too (LayerNorm / Swish / stem conv1 outputs written in the
+// 16-bit type by their producers), lda in elements; the stem's implicit-GEMM gather uses the same element offsets.
 template <typename T16, int BM, int BN, int EPI, bool CONV, bool W16, bool A16 = false>
 __global__ __launch_bounds__(256, 2) void gemm_mfma16_kernel(const GemmArgs g) {
-    static_assert(!A16 || (W16 && !CONV), "16-bit A operand: plain rows, together with 16-bit weights");
+    static_assert(!A16 || W16, "16-bit A operand comes together with 16-bit weights");
     using x8 = typename Lowp<T16>::x8;
     using x4 = typename Lowp<T16>::x4;
     constexpr int TM = BM / 64, TN = BN / 64, BK = 64;
@@ -53,9 +53,7 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma16_kernel(const GemmArgs g) {
     if (A16) {
 #pragma unroll
         for (int p = 0; p < NAH; ++p) {
-            int64_t m = m0 + hrow + 32 * p;
-            if (m >= g.M) m = g.M - 1;
-            ah_ptr[p] = reinterpret_cast<const T16*>(g.A) + m * g.lda;
+            ah_ptr[p] = reinterpret_cast<const T16*>(g.A) + (a_row_ptr<CONV>(g, m0 + hrow + 32 * p) - g.A);   // element offset
         }
     } else {
 #pragma unroll
@@ -77,9 +75,10 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma16_kernel(const GemmArgs g) {
         const bool ok = k < g.K;
         const int kh = kt * BK + hch * 8;                      // K % 8 == 0: a 16-byte chunk is all in or all out
         if (A16) {
+            const int64_t ahoff = a_k_offset<CONV>(g, kt * BK) + hch * 8;
 #pragma unroll
             for (int p = 0; p < NAH; ++p) {
-                if (kh < g.K) rah[p] = *reinterpret_cast<const x8*>(ah_ptr[p] + kh);
+                if (kh < g.K) rah[p] = *reinterpret_cast<const x8*>(ah_ptr[p] + ahoff);
                 else
 #pragma unroll
                     for (int e = 0; e < 8; ++e) rah[p][e] = (T16)0.f;
@@ -170,13 +169,8 @@ int launch_cfg(GemmArgs g, int src16, hipStream_t s) {          // src16: 0 = fp
     g.tiles_m = (unsigned)((g.M + BM - 1) / BM);
     g.tiles_n = (unsigned)((ncols + bn - 1) / bn);
     const dim3 grid(g.tiles_m * g.tiles_n);
-    if constexpr (!CONV) {
-        if (src16 == 2) {
-            hipLaunchKernelGGL((gemm_mfma16_kernel<T16, BM, BN, EPI, CONV, true, true>), grid, dim3(256), 0, s, g);
-            return cfm_launch_status();
-        }
-    }
-    if (src16 == 1) hipLaunchKernelGGL((gemm_mfma16_kernel<T16, BM, BN, EPI, CONV, true>), grid, dim3(256), 0, s, g);
+    if (src16 == 2) hipLaunchKernelGGL((gemm_mfma16_kernel<T16, BM, BN, EPI, CONV, true, true>), grid, dim3(256), 0, s, g);
+    else if (src16 == 1) hipLaunchKernelGGL((gemm_mfma16_kernel<T16, BM, BN, EPI, CONV, true>), grid, dim3(256), 0, s, g);
     else if (src16 == 0) hipLaunchKernelGGL((gemm_mfma16_kernel<T16, BM, BN, EPI, CONV, false>), grid, dim3(256), 0, s, g);
     else return CFM_ERR_UNSUPPORTED;
     return cfm_launch_status();
@@ -246,18 +240,22 @@ extern "C" int cfm_gemm_mfma16_f32(int prec, int epi, const void* A, int a_is_16
     }
 }
 
-// 16-bit-MFMA form of cfm_subsample_conv2_relu_f32 (C % 64 == 0).
-extern "C" int cfm_subsample_conv2_relu_mfma16_f32(int prec, const float* h1, const float* w2p, const float* b2, float* h2,
-                                                   int B, int F1, int T1, int C, cfm_stream_t stream) {
+// 16-bit-MFMA form of cfm_subsample_conv2_relu_f32 (C % 64 == 0).  h1_is_16bit (with w_is_16bit): h1 comes from
+// cfm_subsample_conv1_relu_out16_f32; h2_is_16bit: h2 is stored in `prec` (it feeds the input Linear's 16-bit A operand).
+extern "C" int cfm_subsample_conv2_relu_mfma16_f32(int prec, const void* h1, int h1_is_16bit, const void* w2p, int w_is_16bit,
+                                                   const float* b2, void* h2, int h2_is_16bit, int B, int F1, int T1, int C,
+                                                   cfm_stream_t stream) {
     CFM_REQUIRE(h1 && w2p && b2 && h2, CFM_ERR_NULL);
     CFM_REQUIRE(B > 0 && F1 >= 3 && T1 >= 3 && C > 0, CFM_ERR_BAD_SHAPE);
     CFM_REQUIRE(C % 64 == 0, CFM_ERR_UNSUPPORTED);
-    CFM_REQUIRE(CFM_ALIGNED16(h1) && CFM_ALIGNED16(w2p) && CFM_ALIGNED16(h2), CFM_ERR_ALIGN);
+    CFM_REQUIRE(!h1_is_16bit || w_is_16bit, CFM_ERR_BAD_SHAPE);
+    CFM_REQUIRE(CFM_ALIGNED16(h1) && CFM_ALIGNED16(w2p) && (reinterpret_cast<uintptr_t>(h2) & 7) == 0, CFM_ERR_ALIGN);
     GemmArgs g{};
     g.cT1 = T1; g.cF1 = F1; g.cC = C; g.cT2 = (T1 - 1) / 2; g.cF2 = (F1 - 1) / 2;
-    g.A = h1; g.W = w2p; g.bias = b2; g.C = h2;
+    g.A = static_cast<const float*>(h1); g.W = static_cast<const float*>(w2p); g.bias = b2; g.C = static_cast<float*>(h2);
+    g.c_prec = h2_is_16bit ? prec : 0;
     g.M = (int64_t)B * g.cT2 * g.cF2; g.N = C; g.K = 9 * C; g.lda = 0; g.ldc = C; g.alpha = 1.f;
-    return launch<EPI_RELU, true>(prec, g, 0, static_cast<hipStream_t>(stream));
+    return launch<EPI_RELU, true>(prec, g, h1_is_16bit ? 2 : (w_is_16bit ? 1 : 0), static_cast<hipStream_t>(stream));
 }
 
 // dst (16-bit, prec) <- RNE(src) for n fp32 values (n % 4 == 0): the per-optimizer-step cast of the master weights that

@@ -6,8 +6,9 @@
 
 namespace {
 
+template <typename TOUT>     // float, or the 16-bit matrix-pipe type when h1 only feeds the 16-bit conv2 GEMM (inference under autocast)
 __global__ __launch_bounds__(256) void conv1_relu_kernel(const float* __restrict__ x, const float* __restrict__ w1,
-                                                         const float* __restrict__ b1, float* __restrict__ h1,
+                                                         const float* __restrict__ b1, TOUT* __restrict__ h1,
                                                          int B, int F, int T, int C, int F1, int T1, int ppb) {
     const int c4n = C >> 2;
     const int c4 = threadIdx.x % c4n;
@@ -40,7 +41,8 @@ __global__ __launch_bounds__(256) void conv1_relu_kernel(const float* __restrict
             o.w = fmaf(w[3][j], xv[j], o.w);
         }
         o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
-        *reinterpret_cast<f32x4*>(h1 + pos * C + c4 * 4) = o;
+        if constexpr (sizeof(TOUT) == 4) *reinterpret_cast<f32x4*>(h1 + pos * C + c4 * 4) = o;
+        else *reinterpret_cast<typename Lowp<TOUT>::x4*>(h1 + pos * C + c4 * 4) = Lowp<TOUT>::cvt4(o);
     }
 }
 
@@ -201,8 +203,31 @@ extern "C" int cfm_subsample_conv1_relu_f32(const float* x, const float* w1, con
     const int64_t npos = (int64_t)B * T1 * F1;
     int64_t blocks = (npos + ppb - 1) / ppb;
     if (blocks > 256 * 32) blocks = 256 * 32;
-    hipLaunchKernelGGL(conv1_relu_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), x, w1,
+    hipLaunchKernelGGL(conv1_relu_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), x, w1,
                        b1, h1, B, F, T, C, F1, T1, ppb);
+    return cfm_launch_status();
+}
+
+// cfm_subsample_conv1_relu_f32 with h1 written in the 16-bit type `prec` (the A operand of cfm_subsample_conv2_relu_mfma16_f32
+// with a_is_16bit): 0.64 GB instead of 1.28 GB at cfg-2.
+extern "C" int cfm_subsample_conv1_relu_out16_f32(int prec, const float* x, const float* w1, const float* b1, void* h1, int B,
+                                                  int F, int T, int C, cfm_stream_t stream) {
+    CFM_REQUIRE(x && w1 && b1 && h1, CFM_ERR_NULL);
+    CFM_REQUIRE(B > 0 && F >= 3 && T >= 3 && C > 0 && (C & 3) == 0 && C <= 1024, CFM_ERR_BAD_SHAPE);
+    const int F1 = (F - 1) / 2, T1 = (T - 1) / 2;
+    const int ppb = 256 / (C / 4) > 0 ? 256 / (C / 4) : 0;
+    CFM_REQUIRE(ppb > 0, CFM_ERR_UNSUPPORTED);
+    const int64_t npos = (int64_t)B * T1 * F1;
+    int64_t blocks = (npos + ppb - 1) / ppb;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (prec == CFM_PREC_BF16)
+        hipLaunchKernelGGL(conv1_relu_kernel<__bf16>, dim3((unsigned)blocks), dim3(256), 0, s, x, w1, b1, static_cast<__bf16*>(h1),
+                           B, F, T, C, F1, T1, ppb);
+    else if (prec == CFM_PREC_FP16)
+        hipLaunchKernelGGL(conv1_relu_kernel<_Float16>, dim3((unsigned)blocks), dim3(256), 0, s, x, w1, b1,
+                           static_cast<_Float16*>(h1), B, F, T, C, F1, T1, ppb);
+    else return CFM_ERR_UNSUPPORTED;
     return cfm_launch_status();
 }
 

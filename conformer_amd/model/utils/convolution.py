@@ -106,6 +106,8 @@ class ConvolutionSubsampling(nn.Module):
     def forward(self, x: torch.Tensor, lengths: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
         """Reference-compatible output layout (feature index c*F' + f); off the hot path (one permute copy)."""
         h = self.channel_last(x)
+        if h.dtype != torch.float32:                # inference under autocast keeps the stem output in the 16-bit type
+            h = h.float()
         B, T2, _ = h.shape
         C = self.conv_1.out_channels
         h = h.view(B, T2, -1, C).transpose(2, 3).reshape(B, T2, -1)

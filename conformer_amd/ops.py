@@ -271,10 +271,17 @@ def subsample_stem(x: torch.Tensor, w1, b1, w2p, b2) -> torch.Tensor:
     F1, T1 = (F - 1) // 2, (T - 1) // 2
     F2, T2 = (F1 - 1) // 2, (T1 - 1) // 2
     lib = _lib.load()
-    h1 = torch.empty(B, T1, F1, C, device=x.device, dtype=x.dtype)
-    _lib.check(lib.cfm_subsample_conv1_relu_f32(x.data_ptr(), w1.data_ptr(), b1.data_ptr(), h1.data_ptr(), B, F, T, C,
-                                                _stream()), "cfm_subsample_conv1_relu_f32")
-    h2 = torch.empty(B, T2, F2 * C, device=x.device, dtype=x.dtype)
+    p16 = out16_ok(C) if C % 64 == 0 else 0       # inference under autocast: h1 and h2 only feed 16-bit GEMM operands
+    if p16:
+        h1 = torch.empty(B, T1, F1, C, device=x.device, dtype=_DT16[p16])
+        _lib.check(lib.cfm_subsample_conv1_relu_out16_f32(p16, x.data_ptr(), w1.data_ptr(), b1.data_ptr(), h1.data_ptr(), B, F,
+                                                          T, C, _stream()), "cfm_subsample_conv1_relu_out16_f32")
+        h2 = torch.empty(B, T2, F2 * C, device=x.device, dtype=_DT16[p16])
+    else:
+        h1 = torch.empty(B, T1, F1, C, device=x.device, dtype=x.dtype)
+        _lib.check(lib.cfm_subsample_conv1_relu_f32(x.data_ptr(), w1.data_ptr(), b1.data_ptr(), h1.data_ptr(), B, F, T, C,
+                                                    _stream()), "cfm_subsample_conv1_relu_f32")
+        h2 = torch.empty(B, T2, F2 * C, device=x.device, dtype=x.dtype)
     _conv2_relu(lib, h1, w2p, b2, h2, B, F1, T1, C)
     return h2
 
@@ -282,8 +289,11 @@ def subsample_stem(x: torch.Tensor, w1, b1, w2p, b2) -> torch.Tensor:
 def _conv2_relu(lib, h1, w2p, b2, h2, B, F1, T1, C):
     prec = mfma16_prec()
     if prec and C % 64 == 0:
-        _lib.check(lib.cfm_subsample_conv2_relu_mfma16_f32(prec, h1.data_ptr(), w2p.data_ptr(), b2.data_ptr(), h2.data_ptr(),
-                                                           B, F1, T1, C, _stream()), "cfm_subsample_conv2_relu_mfma16_f32")
+        w16 = weight16(w2p, prec)
+        _lib.check(lib.cfm_subsample_conv2_relu_mfma16_f32(prec, h1.data_ptr(), int(h1.dtype != torch.float32),
+                                                           (w2p if w16 is None else w16).data_ptr(), int(w16 is not None),
+                                                           b2.data_ptr(), h2.data_ptr(), int(h2.dtype != torch.float32), B, F1,
+                                                           T1, C, _stream()), "cfm_subsample_conv2_relu_mfma16_f32")
     else:
         _lib.check(lib.cfm_subsample_conv2_relu_f32(h1.data_ptr(), w2p.data_ptr(), b2.data_ptr(), h2.data_ptr(), B, F1, T1,
                                                     C, _stream()), "cfm_subsample_conv2_relu_f32")
@@ -604,7 +614,8 @@ def relpos_attention_bwd(qkv, pos, u, v, lengths, n_heads, ctx, lse, dctx, drop_
 
 # ---- conv-subsampling stem: training forward (keeps h1, h2) and backward -------------------------------------------
 def subsample_stem_train(x, w1, b1, w2p, b2):
-    """Like subsample_stem but also returns h1 (B,T1,F1,C), needed by the backward."""
+    """Like subsample_stem but also returns h1 (B,T1,F1,C), needed by the backward (both fp32: the stem's gradient
+    kernels read them)."""
     x = _req(x, "x")
     B, F, T = x.shape
     C = w1.shape[0]

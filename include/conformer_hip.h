@@ -140,8 +140,11 @@ int cfm_relpos_attention_mfma16_f32(int prec, const float* q, const float* k, co
                                     const float* pos, int64_t ldp, const float* u, const float* vbias,
                                     const int64_t* lengths_or_null, float* ctx, int64_t ldo, float* lse_or_null, int B,
                                     int T, int H, int dh, float drop_p, uint64_t drop_seed, cfm_stream_t stream);
-int cfm_subsample_conv2_relu_mfma16_f32(int prec, const float* h1, const float* w2p, const float* b2, float* h2, int B,
-                                        int F1, int T1, int C, cfm_stream_t stream);
+int cfm_subsample_conv2_relu_mfma16_f32(int prec, const void* h1, int h1_is_16bit, const void* w2p, int w_is_16bit,
+                                        const float* b2, void* h2, int h2_is_16bit, int B, int F1, int T1, int C,
+                                        cfm_stream_t stream);
+int cfm_subsample_conv1_relu_out16_f32(int prec, const float* x, const float* w1, const float* b1, void* h1, int B, int F,
+                                       int T, int C, cfm_stream_t stream);
 int cfm_gemm_bwd_batched_mfma16_f32(int prec, const float* A, int a_col, int64_t lda, const void* B, int b_col,
                                     int b_is_16bit, int64_t ldb, const float* Z_or_null, int64_t ldz, float alpha, float* C,
                                     int64_t ldc, int I, int J, int64_t Kc, int allow_split, int accumulate,

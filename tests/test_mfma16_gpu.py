@@ -238,3 +238,25 @@ def test_mfma16_attention_forward(dev, B, T, H, dh, lengths, dt16):
     tol_p = 6e-3 if dt16 == torch.bfloat16 else 8e-4
     assert rel_l2(ctx, ref16) < tol_p
     assert rel_l2(ctx, ref) < (2e-2 if dt16 == torch.bfloat16 else 3e-3)
+
+
+@pytest.mark.parametrize("dt16", DT)
+def test_mfma16_stem_inference_keeps_16bit_activations(dev, dt16):
+    """Inference under autocast: conv1 writes h1 in the 16-bit type, conv2 consumes it and writes a 16-bit h2 that the
+    input Linear consumes -- against the fp32 path (operand + one output rounding)."""
+    from conformer_amd import ops
+    g = torch.Generator().manual_seed(3)
+    C = 64
+    x = torch.randn(2, 80, 103, generator=g).to(dev)
+    w1, b1 = (torch.randn(C, 1, 3, 3, generator=g) / 3).to(dev), (torch.randn(C, generator=g) * 0.1).to(dev)
+    w2, b2 = (torch.randn(C, C, 3, 3, generator=g) / math.sqrt(9 * C)).to(dev), (torch.randn(C, generator=g) * 0.1).to(dev)
+    wl, bl = (torch.randn(48, 19 * C, generator=g) / math.sqrt(19 * C)).to(dev), torch.zeros(48, device=dev)
+    w2p = ops.pack_conv2_weight(w2)
+    ref_h2 = ops.subsample_stem(x, w1, b1, w2p, b2)
+    ref = ops.linear(ref_h2, wl, bl)
+    with torch.autocast("cuda", dtype=dt16):
+        h2 = ops.subsample_stem(x, w1, b1, w2p, b2)
+        y = ops.linear(h2, wl, bl)
+    assert h2.dtype == dt16 and y.dtype == torch.float32
+    tol = 1e-2 if dt16 == torch.bfloat16 else 2e-3
+    assert rel_l2(h2.float(), ref_h2) < tol and rel_l2(y, ref) < tol
