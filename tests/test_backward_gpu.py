@@ -5,6 +5,7 @@ Tolerance: fp32 kernels with atomics-based reductions: 5e-5 rel-L2 per gradient 
 import pytest
 import torch
 
+from oracle import conformer_oracle as O
 from tests.util import cfg_params, load_golden, rel_l2
 
 pytestmark = pytest.mark.gpu
@@ -173,3 +174,43 @@ def test_encoder_grads_vs_reference_golden(dev):
             assert rel_l2(p.grad, ref) < 2e-4, n
         checked += 1
     assert checked > 60
+
+
+@pytest.mark.parametrize("d,H,K,B,T,train_bn", [(256, 4, 15, 3, 61, False), (96, 8, 7, 2, 33, True), (512, 8, 31, 2, 100, True),
+                                                (64, 1, 3, 2, 5, False), (144, 4, 31, 1, 17, False)])
+def test_block_forward_backward_other_geometries_vs_oracle_autograd(dev, d, H, K, B, T, train_bn):
+    """Shapes the goldens do not cover (Conformer-M width, head sizes 12 / 64 / 36, kernel sizes 3 / 7 / 15, one head,
+    B = 1, train-mode BatchNorm): the block's output, input gradient and every parameter gradient against torch autograd
+    through the float64 oracle (itself pinned by the reference's goldens at the other shapes)."""
+    from model.utils.block import ConformerBlock
+    from model.utils.position import RelativePositionalEncoding
+    P = O.make_params(vocab=8, n_mel=80, n_blocks=1, d=d, n_heads=H, ksize=K, lstm_hidden=8, seed=d + K, with_decoder=False)
+    blk = "encoder.layers.0."
+    m = ConformerBlock(d, H, K).to(dev)
+    m.load_state_dict({k[len(blk):]: v for k, v in P.items() if k.startswith(blk)})
+    m.train()
+    if not train_bn:
+        m.conv.batch_norm.eval()
+    g = torch.Generator().manual_seed(T)
+    x = torch.randn(B, T, d, generator=g)
+    w = torch.randn(B, T, d, generator=g)
+    L = torch.sort(torch.randint(1, T + 1, (B,), generator=g), descending=True).values
+    L[0] = T
+    Pd = {k: (v.double().requires_grad_(True) if v.is_floating_point() and k.startswith(blk) and "running" not in k
+              and "div_term" not in k else (v.double() if v.is_floating_point() else v)) for k, v in P.items()}
+    xr = x.double().requires_grad_(True)
+    pe = O.relpos_table(T, Pd["encoder.rel_pe.div_term"])
+    ref = O.conformer_block(xr, pe, L, Pd, blk, H, training=train_bn)
+    (ref * w.double()).sum().backward()
+    xd = x.to(dev).requires_grad_(True)
+    rel = RelativePositionalEncoding(d).to(dev)
+    y = m.fused(xd, rel.table(T), L.to(dev))
+    (y * w.to(dev)).sum().backward()
+    assert rel_l2(y, ref) < 2e-5
+    assert rel_l2(xd.grad, xr.grad) < 1e-4
+    for n, p in m.named_parameters():
+        r = Pd[blk + n].grad
+        if r is None or float(r.norm()) < 1e-6 * max(1.0, float(Pd[blk + n].detach().norm())):
+            assert p.grad is None or float(p.grad.abs().max()) < 1e-3, n      # mathematically-zero gradients
+        else:
+            assert rel_l2(p.grad, r) < 2e-4, n
