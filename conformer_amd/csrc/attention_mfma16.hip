@@ -29,7 +29,7 @@ struct Attn16Args {
 };
 
 template <typename T16>
-__global__ __launch_bounds__(256, 3) void relpos_attn_fwd_mfma16_kernel(const Attn16Args a) {
+__global__ __launch_bounds__(256, 2) void relpos_attn_fwd_mfma16_kernel(const Attn16Args a) {
     using x8 = typename Lowp<T16>::x8;
     using x4 = typename Lowp<T16>::x4;
     __shared__ __attribute__((aligned(16))) T16 smem16[32 * KROWH + 64 * VROWH + RINGH * KROWH];
