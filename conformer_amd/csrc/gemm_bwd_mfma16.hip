@@ -248,7 +248,13 @@ template <typename T16, bool AROW, bool BROW, int EPI, bool B16 = false>
 int launch_layout(const BwdArgs& g, hipStream_t s) {
     const int64_t t128 = (int64_t)((g.I + 127) / 128) * ((g.J + 127) / 128) * g.nbatch;
     int tile = cfm_bwd_debug_tile();
-    if (tile < 0) tile = (t128 >= 512 && g.I >= 96 && g.J >= 96) ? 0 : 3;
+    if (tile < 0) {
+        // measured (tools/gemm_tune.py bwd16, M = 7968 and 15936): dX-type products switch to 128x128 from ~400 tiles;
+        // weight-gradient products (both operands contraction-major, split-K) with a narrow dY (I <= 512) want 128x64
+        // (the 512 x 2048 FFN-out gradient: 113 vs 163 us at M = 15936), the wide-dY ones 64x64
+        if (!AROW && !BROW && g.nbatch == 1 && g.I <= 512 && g.I >= 96 && g.J >= 512) tile = 1;
+        else tile = (t128 >= 400 && g.I >= 96 && g.J >= 96) ? 0 : 3;
+    }
     if (tile == 0) return launch_one<T16, 128, 128, AROW, BROW, EPI, 0, B16>(g, s);
     if (tile == 1) return launch_one<T16, 128, 64, AROW, BROW, EPI, 0, B16>(g, s);
     return launch_one<T16, 64, 64, AROW, BROW, EPI, 0, B16>(g, s);

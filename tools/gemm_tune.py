@@ -109,7 +109,7 @@ def bwd_sweep(prec=0):
     from conformer_amd import ops
     lib = _lib.load()
     dev = torch.device("cuda:0")
-    M = 7968
+    M = int(os.environ.get("TUNE_M", "7968"))
     cases = []
     for (N, K) in [(2048, 512), (512, 2048), (1536, 512), (512, 512), (1024, 512)]:
         cases.append((f"dX  M x{K:5d} (Kc={N:5d})", False, True, M, K, N, False))      # dY (M,N) . W (N,K)
