@@ -16,7 +16,10 @@ namespace {
 
 // B16 (contraction-major B only): B is already stored in the 16-bit type (cached weight cast for dX = dY.W; a 16-bit
 // activation for dW): a thread loads a 4(k) x 8(index) block with four 16-byte loads and writes eight 8-byte k-runs.
-template <typename T16, int BM, int BN, bool AROW, bool BROW, int EPI, int GATHER = 0, bool SPLITK = false, bool B16 = false>
+// ALIGNED: Kc % 4 == 0 for index-major operands, I / J % 4 == 0 for contraction-major ones (J % 8 with B16): every 16-byte
+// chunk is entirely inside or outside the valid range, so only the unconditional-load + select path is compiled.
+template <typename T16, int BM, int BN, bool AROW, bool BROW, int EPI, int GATHER = 0, bool SPLITK = false, bool B16 = false,
+          bool ALIGNED = false>
 __global__ __launch_bounds__(256, 2) void gemm_bwd_mfma16_kernel(const BwdArgs g) {
     static_assert(!B16 || (!BROW && GATHER == 0), "16-bit B operand: contraction-major, no gather");
     using x8 = typename Lowp<T16>::x8;
@@ -64,24 +67,39 @@ __global__ __launch_bounds__(256, 2) void gemm_bwd_mfma16_kernel(const BwdArgs g
 
     // ---- global -> registers.  ROW: pass p = row (tid>>4) + 16p, k chunk (tid&15)*4.
     //      COL: pass p = 4x4 block: k group kg = (slot / cpr), idx chunk ch = slot % cpr, slot = tid + 256*(p>>2), k row kg*4 + (p&3)
-    auto load_operand = [&](auto& regs, const float* X, int64_t ld, int idx0, int IDX, bool row, int bt, int64_t k0,
-                            int gather) {
+    // Every load below is UNCONDITIONAL: out-of-range rows / taps / contraction indices read a clamped (valid) address
+    // and are zeroed by a select afterwards.  (Conditional loads compile to one branch + s_waitcnt vmcnt(0) per load: the
+    // first version of this kernel had 160-280 branches and ~80 full memory waits per tile around its 4-16 MFMAs.)
+    // The select-based path needs 16-byte chunks that are entirely inside or outside the valid range: Kc % 4 == 0 for
+    // index-major operands, IDX % 4 == 0 for contraction-major ones; ragged shapes take the element-wise path.
+    const bool kfast = ALIGNED || (g.Kc & 3) == 0;
+    // (the zeroing select is applied at staging time, AFTER the MFMAs of the current tile: `keep` carries one bit per
+    // register; selecting right after the load would make the wave wait for the load before it multiplies)
+    auto load_operand = [&](auto& regs, unsigned& keep, const float* X, int64_t ld, int idx0, int IDX, bool row, int bt,
+                            int64_t k0, int gather) {
         constexpr int NV = sizeof(regs) / sizeof(f32x4);
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+        keep = ~0u;
 #pragma unroll
         for (int p = 0; p < NV; ++p) {
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            f32x4 v = zero;
             if (gather == 2) {                                         // A rows of dz2 per (class row, tap); C % 64 == 0
                 const int tap = (int)(k0 / g.cC);
                 const int co = (int)(k0 - (int64_t)tap * g.cC) + (tid & 15) * 4;
                 const int t2 = g2_a[p] + g.tap_dt[tap], f2 = g2_c[p] + g.tap_df[tap];
-                if (t2 >= 0 && t2 < g.cT2 && f2 >= 0 && f2 < g.cF2)
-                    v = *reinterpret_cast<const f32x4*>(X + (((int64_t)g2_b[p] * g.cT2 + t2) * g.cF2 + f2) * g.cC + co);
+                const bool ok = t2 >= 0 && t2 < g.cT2 && f2 >= 0 && f2 < g.cF2;
+                const int t2c = min(max(t2, 0), g.cT2 - 1), f2c = min(max(f2, 0), g.cF2 - 1);
+                v = *reinterpret_cast<const f32x4*>(X + (((int64_t)g2_b[p] * g.cT2 + t2c) * g.cF2 + f2c) * g.cC + co);
+                if (!ok) keep &= ~(1u << p);
             } else if (row) {
-                int idx = idx0 + (tid >> 4) + 16 * p;
+                const int idx = min(idx0 + (tid >> 4) + 16 * p, IDX - 1);
                 const int64_t k = k0 + (tid & 15) * 4;
-                if (idx >= IDX) idx = IDX - 1;
-                if (k + 3 < kend) v = *reinterpret_cast<const f32x4*>(X + (int64_t)idx * ld + k);
-                else if (k < kend) {                                   // ragged end of the contraction
+                if (ALIGNED || kfast) {
+                    v = *reinterpret_cast<const f32x4*>(X + (int64_t)idx * ld + min(k, g.Kc - 4));
+                    if (k >= kend) keep &= ~(1u << p);
+                } else if (k + 3 < kend) {
+                    v = *reinterpret_cast<const f32x4*>(X + (int64_t)idx * ld + k);
+                } else if (k < kend) {                                 // ragged end of the contraction
                     const float* s = X + (int64_t)idx * ld + k;
                     v.x = s[0];
                     if (k + 1 < kend) v.y = s[1];
@@ -93,24 +111,29 @@ __global__ __launch_bounds__(256, 2) void gemm_bwd_mfma16_kernel(const BwdArgs g
                 const int kg = slot / cpr, ch = slot - kg * cpr;
                 const int64_t k = k0 + kg * 4 + (p & 3);
                 const int idx = idx0 + 4 * ch;
-                if (k < kend && idx < IDX) {
-                    if (gather == 1) {                                 // B = im2col(h1): k = output position m, idx = (tap, ci)
-                        const int f2 = (int)(k % g.cF2);
-                        const int64_t bt2 = k / g.cF2;
-                        const int t2 = (int)(bt2 % g.cT2);
-                        const int64_t b = bt2 / g.cT2;
-                        const int tap = idx / g.cC, ci = idx - tap * g.cC;
-                        const int kf = tap / 3, ktp = tap - 3 * kf;
-                        v = *reinterpret_cast<const f32x4*>(
-                            X + (((b * g.cT1 + 2 * t2 + ktp) * g.cF1 + 2 * f2 + kf) * (int64_t)g.cC) + ci);
-                    } else {
-                        const float* s = X + k * ld + idx;
-                        if (idx + 3 < IDX) v = *reinterpret_cast<const f32x4*>(s);
-                        else {                                         // ragged index edge: zero-filled
-                            v.x = s[0];
-                            if (idx + 1 < IDX) v.y = s[1];
-                            if (idx + 2 < IDX) v.z = s[2];
-                        }
+                const int64_t kc = min(k, kend - 1);
+                const bool ok = k < kend && idx < IDX;
+                if (gather == 1) {                                     // B = im2col(h1): k = output position m, idx = (tap, ci)
+                    const int idc = min(idx, IDX - 4);                 // IDX = 9C: chunks are never ragged
+                    const int f2 = (int)(kc % g.cF2);
+                    const int64_t bt2 = kc / g.cF2;
+                    const int t2 = (int)(bt2 % g.cT2);
+                    const int64_t b = bt2 / g.cT2;
+                    const int tap = idc / g.cC, ci = idc - tap * g.cC;
+                    const int kf = tap / 3, ktp = tap - 3 * kf;
+                    v = *reinterpret_cast<const f32x4*>(
+                        X + (((b * g.cT1 + 2 * t2 + ktp) * g.cF1 + 2 * f2 + kf) * (int64_t)g.cC) + ci);
+                    if (!ok) keep &= ~(1u << p);
+                } else if (ALIGNED || (IDX & 3) == 0) {
+                    v = *reinterpret_cast<const f32x4*>(X + kc * ld + min(idx, IDX - 4));
+                    if (!ok) keep &= ~(1u << p);
+                } else if (ok) {
+                    const float* s = X + k * ld + idx;
+                    if (idx + 3 < IDX) v = *reinterpret_cast<const f32x4*>(s);
+                    else {                                             // ragged index edge: zero-filled
+                        v.x = s[0];
+                        if (idx + 1 < IDX) v.y = s[1];
+                        if (idx + 2 < IDX) v.z = s[2];
                     }
                 }
             }
@@ -118,8 +141,11 @@ __global__ __launch_bounds__(256, 2) void gemm_bwd_mfma16_kernel(const BwdArgs g
         }
     };
     // ---- registers -> LDS (16-bit)
-    auto store_operand = [&](const auto& regs, T16* S, bool row, int bt) {
-        constexpr int NV = sizeof(regs) / sizeof(f32x4);
+    auto store_operand = [&](const auto& regs_in, unsigned keep, T16* S, bool row, int bt) {
+        constexpr int NV = sizeof(regs_in) / sizeof(f32x4);
+        f32x4 regs[NV];
+#pragma unroll
+        for (int p = 0; p < NV; ++p) regs[p] = ((keep >> p) & 1u) ? regs_in[p] : f32x4{0.f, 0.f, 0.f, 0.f};
         if (row) {
 #pragma unroll
             for (int p = 0; p < NV; ++p)
@@ -142,14 +168,22 @@ __global__ __launch_bounds__(256, 2) void gemm_bwd_mfma16_kernel(const BwdArgs g
     constexpr int CPR8 = BN / 8;
     const int hkg = tid / CPR8, hch = tid - hkg * CPR8;       // threads >= 16*CPR8 idle (BN = 64)
     x8 rbh[4];                                                 // (dead and eliminated when !B16)
+    unsigned keep_a = ~0u, keep_b = ~0u;
     auto load_b16 = [&](int64_t k0) {
+        keep_b = ~0u;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int64_t k = k0 + hkg * 4 + j;
             const int idx = j0 + 8 * hch;
+            x8 zero8;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) rbh[j][e] = (T16)0.f;
-            if (hkg < 16 && k < kend && idx < g.J) {
+            for (int e = 0; e < 8; ++e) zero8[e] = (T16)0.f;
+            rbh[j] = zero8;
+            const bool ok = hkg < 16 && k < kend && idx < g.J;
+            if (ALIGNED || (g.J & 7) == 0) {                       // unconditional clamped load + select (see load_operand)
+                rbh[j] = *reinterpret_cast<const x8*>(Bh + min(k, kend - 1) * g.ldb + min(idx, g.J - 8));
+                if (!ok) keep_b &= ~(1u << j);
+            } else if (ok) {
                 const T16* s = Bh + k * g.ldb + idx;
                 if (idx + 7 < g.J) rbh[j] = *reinterpret_cast<const x8*>(s);
                 else
@@ -159,24 +193,26 @@ __global__ __launch_bounds__(256, 2) void gemm_bwd_mfma16_kernel(const BwdArgs g
     };
     auto store_b16 = [&](T16* S) {
         if (hkg >= 16) return;
+        const T16 z16 = (T16)0.f;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             x4 run;
-            run[0] = rbh[0][e]; run[1] = rbh[1][e]; run[2] = rbh[2][e]; run[3] = rbh[3][e];
+            run[0] = (keep_b & 1u) ? rbh[0][e] : z16; run[1] = (keep_b & 2u) ? rbh[1][e] : z16;
+            run[2] = (keep_b & 4u) ? rbh[2][e] : z16; run[3] = (keep_b & 8u) ? rbh[3][e] : z16;
             *reinterpret_cast<x4*>(S + lds_off(8 * hch + e, hkg * 4)) = run;
         }
     };
     f32x4 ra[NA], rb[B16 ? 1 : NB];
     auto load_tile = [&](int kt) {
         const int64_t k0 = kbeg + (int64_t)kt * BK;
-        load_operand(ra, Ab, g.lda, i0, g.I, AROW, BM, k0, GATHER == 2 ? 2 : 0);
+        load_operand(ra, keep_a, Ab, g.lda, i0, g.I, AROW, BM, k0, GATHER == 2 ? 2 : 0);
         if constexpr (B16) load_b16(k0);
-        else load_operand(rb, Bb, g.ldb, j0, g.J, BROW, BN, k0, GATHER == 1 ? 1 : 0);
+        else load_operand(rb, keep_b, Bb, g.ldb, j0, g.J, BROW, BN, k0, GATHER == 1 ? 1 : 0);
     };
     auto store_tile = [&](int buf) {
-        store_operand(ra, As + buf * BM * BK, AROW, BM);
+        store_operand(ra, keep_a, As + buf * BM * BK, AROW, BM);
         if constexpr (B16) store_b16(Bs + buf * BN * BK);
-        else store_operand(rb, Bs + buf * BN * BK, BROW, BN);
+        else store_operand(rb, keep_b, Bs + buf * BN * BK, BROW, BN);
     };
 
     f32x16 acc[TM][TN];
@@ -197,6 +233,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bwd_mfma16_kernel(const BwdArgs g
         const int cur = kt & 1;
         const bool more = kt + 1 < nkt;
         if (more) load_tile(kt + 1);
+        __builtin_amdgcn_sched_barrier(0);                    // loads stay in flight across the MFMAs of this tile
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             x8 fa[TM], fb[TN];
@@ -213,6 +250,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bwd_mfma16_kernel(const BwdArgs g
                     acc[mt][nt] = SPLITK ? Lowp<T16>::mfma(fa[mt], fb[nt], acc[mt][nt])
                                          : Lowp<T16>::mfma(fb[nt], fa[mt], acc[mt][nt]);
         }
+        __builtin_amdgcn_sched_barrier(0);
         if (more) store_tile(cur ^ 1);
         __syncthreads();
     }
@@ -234,13 +272,17 @@ int launch_one(BwdArgs g, hipStream_t s) {
     const int64_t per = (g.Kc + splits - 1) / splits;
     g.k_per_split = (per + 63) / 64 * 64;
     const dim3 grid(tiles, (unsigned)splits, (unsigned)g.nbatch);
+    const bool aligned = (AROW ? (g.Kc & 3) == 0 : (g.I & 3) == 0) &&
+                         (BROW ? (g.Kc & 3) == 0 : (g.J & (B16 ? 7 : 3)) == 0);
     if constexpr (kCanSplit) {
         if (splits > 1) {
-            hipLaunchKernelGGL((gemm_bwd_mfma16_kernel<T16, BM, BN, AROW, BROW, EPI, GATHER, true, B16>), grid, dim3(256), 0, s, g);
+            if (aligned) hipLaunchKernelGGL((gemm_bwd_mfma16_kernel<T16, BM, BN, AROW, BROW, EPI, GATHER, true, B16, true>), grid, dim3(256), 0, s, g);
+            else hipLaunchKernelGGL((gemm_bwd_mfma16_kernel<T16, BM, BN, AROW, BROW, EPI, GATHER, true, B16, false>), grid, dim3(256), 0, s, g);
             return cfm_launch_status();
         }
     }
-    hipLaunchKernelGGL((gemm_bwd_mfma16_kernel<T16, BM, BN, AROW, BROW, EPI, GATHER, false, B16>), grid, dim3(256), 0, s, g);
+    if (aligned) hipLaunchKernelGGL((gemm_bwd_mfma16_kernel<T16, BM, BN, AROW, BROW, EPI, GATHER, false, B16, true>), grid, dim3(256), 0, s, g);
+    else hipLaunchKernelGGL((gemm_bwd_mfma16_kernel<T16, BM, BN, AROW, BROW, EPI, GATHER, false, B16, false>), grid, dim3(256), 0, s, g);
     return cfm_launch_status();
 }
 
@@ -253,7 +295,10 @@ int launch_layout(const BwdArgs& g, hipStream_t s) {
         // weight-gradient products (both operands contraction-major, split-K) with a narrow dY (I <= 512) want 128x64
         // (the 512 x 2048 FFN-out gradient: 113 vs 163 us at M = 15936), the wide-dY ones 64x64
         if (!AROW && !BROW && g.nbatch == 1 && g.I <= 512 && g.I >= 96 && g.J >= 512) tile = 1;
-        else tile = (t128 >= 400 && g.I >= 96 && g.J >= 96) ? 0 : 3;
+        else if (g.I < 96 || g.J < 96) tile = 3;
+        else if (t128 >= 400) tile = 0;
+        else if (t128 >= 200 && g.J >= 64 && (AROW || BROW)) tile = 1;        // e.g. dX 7968 x 512: 504 tiles of 128x64
+        else tile = 3;
     }
     if (tile == 0) return launch_one<T16, 128, 128, AROW, BROW, EPI, 0, B16>(g, s);
     if (tile == 1) return launch_one<T16, 128, 64, AROW, BROW, EPI, 0, B16>(g, s);
