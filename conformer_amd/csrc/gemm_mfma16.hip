@@ -67,59 +67,54 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma16_kernel(const GemmArgs g) {
 #pragma unroll
         for (int p = 0; p < NB; ++p) w_ptr[p] = w_row_ptr<EPI, BN>(g, n0, srow + 16 * p);
     }
+    // All loads are unconditional: a K-tile chunk beyond K (only possible in the last tile when K % 64 != 0) reads a clamped
+    // address and is zeroed by a select when it is staged into LDS (`kvalid*`), after the MFMAs of the current tile.
     f32x4 ra[A16 ? 1 : NA], rb[W16 ? 1 : NB];
     x8 rah[A16 ? NAH : 1], rbh[W16 ? NBH : 1];
+    bool kvalid = true, kvalid_h = true;
     auto load_tile = [&](int kt) {
-        const int k = kt * BK + sch * 4;
-        const int64_t aoff = a_k_offset<CONV>(g, kt * BK) + sch * 4;
-        const bool ok = k < g.K;
-        const int kh = kt * BK + hch * 8;                      // K % 8 == 0: a 16-byte chunk is all in or all out
+        const int k = kt * BK + sch * 4, kh = kt * BK + hch * 8;       // K % 4 == 0 (K % 8 == 0 for 16-bit operands)
+        kvalid = k < g.K; kvalid_h = kh < g.K;
+        const int kc = min(k, g.K - 4), khc = min(kh, g.K - 8);
         if (A16) {
-            const int64_t ahoff = a_k_offset<CONV>(g, kt * BK) + hch * 8;
+            const int64_t ahoff = a_k_offset<CONV>(g, khc - hch * 8) + hch * 8;
 #pragma unroll
-            for (int p = 0; p < NAH; ++p) {
-                if (kh < g.K) rah[p] = *reinterpret_cast<const x8*>(ah_ptr[p] + ahoff);
-                else
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) rah[p][e] = (T16)0.f;
-            }
+            for (int p = 0; p < NAH; ++p) rah[p] = *reinterpret_cast<const x8*>(ah_ptr[p] + ahoff);
         } else {
+            const int64_t aoff = a_k_offset<CONV>(g, kc - sch * 4) + sch * 4;
 #pragma unroll
-            for (int p = 0; p < NA; ++p)
-                ra[p] = ok ? *reinterpret_cast<const f32x4*>(a_ptr[p] + aoff) : f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int p = 0; p < NA; ++p) ra[p] = *reinterpret_cast<const f32x4*>(a_ptr[p] + aoff);
         }
         if (W16) {
 #pragma unroll
-            for (int p = 0; p < NBH; ++p) {
-                if (kh < g.K) rbh[p] = *reinterpret_cast<const x8*>(wh_ptr[p] + kh);
-                else
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) rbh[p][e] = (T16)0.f;
-            }
+            for (int p = 0; p < NBH; ++p) rbh[p] = *reinterpret_cast<const x8*>(wh_ptr[p] + khc);
         } else {
 #pragma unroll
-            for (int p = 0; p < NB; ++p)
-                rb[p] = ok ? *reinterpret_cast<const f32x4*>(w_ptr[p] + k) : f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int p = 0; p < NB; ++p) rb[p] = *reinterpret_cast<const f32x4*>(w_ptr[p] + kc);
         }
     };
     auto store_tile = [&](int buf) {
+        const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+        x8 z8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) z8[e] = (T16)0.f;
         if (A16) {
 #pragma unroll
             for (int p = 0; p < NAH; ++p)
-                *reinterpret_cast<x8*>(As + (buf * BM + hrow + 32 * p) * ROWB + hch * 8) = rah[p];
+                *reinterpret_cast<x8*>(As + (buf * BM + hrow + 32 * p) * ROWB + hch * 8) = kvalid_h ? rah[p] : z8;
         } else {
 #pragma unroll
             for (int p = 0; p < NA; ++p)
-                *reinterpret_cast<x4*>(As + (buf * BM + srow + 16 * p) * ROWB + sch * 4) = Lowp<T16>::cvt4(ra[p]);
+                *reinterpret_cast<x4*>(As + (buf * BM + srow + 16 * p) * ROWB + sch * 4) = Lowp<T16>::cvt4(kvalid ? ra[p] : z4);
         }
         if (W16) {
 #pragma unroll
             for (int p = 0; p < NBH; ++p)
-                *reinterpret_cast<x8*>(Bs + (buf * BN + hrow + 32 * p) * ROWB + hch * 8) = rbh[p];
+                *reinterpret_cast<x8*>(Bs + (buf * BN + hrow + 32 * p) * ROWB + hch * 8) = kvalid_h ? rbh[p] : z8;
         } else {
 #pragma unroll
             for (int p = 0; p < NB; ++p)
-                *reinterpret_cast<x4*>(Bs + (buf * BN + srow + 16 * p) * ROWB + sch * 4) = Lowp<T16>::cvt4(rb[p]);
+                *reinterpret_cast<x4*>(Bs + (buf * BN + srow + 16 * p) * ROWB + sch * 4) = Lowp<T16>::cvt4(kvalid ? rb[p] : z4);
         }
     };
 
@@ -141,6 +136,7 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma16_kernel(const GemmArgs g) {
         const int cur = kt & 1;
         const bool more = kt + 1 < nkt;
         if (more) load_tile(kt + 1);
+        __builtin_amdgcn_sched_barrier(0);                    // the loads stay in flight across this tile's MFMAs
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             x8 fa[TM], fb[TN];
@@ -156,6 +152,7 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma16_kernel(const GemmArgs g) {
                 for (int nt = 0; nt < TN; ++nt)
                     acc[mt][nt] = Lowp<T16>::mfma(fb[nt], fa[mt], acc[mt][nt]);
         }
+        __builtin_amdgcn_sched_barrier(0);
         if (more) store_tile(cur ^ 1);
         __syncthreads();
     }
