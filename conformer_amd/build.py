@@ -51,7 +51,7 @@ def build_library(force: bool = False, verbose: bool = True) -> str:
     os.makedirs(OBJ, exist_ok=True)
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
     srcs = sources()
-    with ThreadPoolExecutor(max_workers=min(6, len(srcs))) as ex:
+    with ThreadPoolExecutor(max_workers=min(os.cpu_count() or 4, len(srcs))) as ex:
         objs = list(ex.map(lambda s: _compile(s, force), srcs))
     if force or not os.path.exists(LIB) or any(os.path.getmtime(o) > os.path.getmtime(LIB) for o in objs):
         cmd = [HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-fno-gpu-rdc", "--no-hip-rt" if False else "",

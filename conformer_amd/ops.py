@@ -573,14 +573,16 @@ def relpos_attention_bwd(qkv, pos, u, v, lengths, n_heads, ctx, lse, dctx, drop_
     sBH_pf = (T * P4, B * T * P4)     # (b,h) offsets into (H,B,T,P4)
     nb = B * H
     lp = mfma16_prec()
-    # content[b,h] = Qu_bh . K_bh^T        (T x T4; padded columns read clamped K rows, masked later)
-    gemm_bwd(qu, False, qkv, False, T, T4, dh, out=content, lda=d, ldb=d3, ldc=T4, nbatch=nb, nb1=H,
+    # content[b,h] = Qu_bh . K_bh^T        (T x T into rows of T4 floats; the pad columns are never read: the softmax
+    # kernel overwrites them with 0.  J must be T, not T4: with J = T4 the last batch element would read up to three K
+    # rows past the end of qkv)
+    gemm_bwd(qu, False, qkv, False, T, T, dh, out=content, lda=d, ldb=d3, ldc=T4, nbatch=nb, nb1=H,
              sa=sBH_rows, sb=sBH_qkv, sc=sBH_sq, b_ptr=kp, prec=lp)
     # posfull[h,b] = Qv_bh . Pm_h^T        (T x P4)
-    gemm_bwd(qv, False, pos, False, T, P4, dh, out=posfull, lda=d, ldb=ldp, ldc=P4, nbatch=nb, nb1=H,
+    gemm_bwd(qv, False, pos, False, T, P, dh, out=posfull, lda=d, ldb=ldp, ldc=P4, nbatch=nb, nb1=H,
              sa=sBH_rows, sb=(0, dh), sc=sBH_pf, prec=lp)
     # dP[b,h] = dO_bh . V_bh^T
-    gemm_bwd(dctx, False, qkv, False, T, T4, dh, out=dP, lda=d, ldb=d3, ldc=T4, nbatch=nb, nb1=H,
+    gemm_bwd(dctx, False, qkv, False, T, T, dh, out=dP, lda=d, ldb=d3, ldc=T4, nbatch=nb, nb1=H,
              sa=sBH_rows, sb=sBH_qkv, sc=sBH_sq, b_ptr=vp, prec=lp)
     _lib.check(lib.cfm_attn_softmax_bwd_f32(content.data_ptr(), posfull.data_ptr(), dP.data_ptr(), lse.data_ptr(),
                                             Dr.data_ptr(), _p(lengths), scale, B, T, H, T4, P4, float(drop_p), int(seed),
