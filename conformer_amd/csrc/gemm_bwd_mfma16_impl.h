@@ -194,11 +194,99 @@ __global__ __launch_bounds__(256, 2) void gemm_bwd_mfma16_kernel(const BwdArgs g
         }
     };
     f32x4 ra[NA], rb[B16 ? 1 : NB];
+    // ---- FAST path (ALIGNED, no gather): every load has a running 64-bit pointer that advances by a constant per K-tile;
+    // the only per-tile work is one 32-bit "still inside the split?" compare per load and a select between the running and
+    // a precomputed always-valid pointer.  (The general path re-derives each address with 64-bit min / multiply / add:
+    // ~10 VALU instructions per load, which made the 64x64 variants instruction-bound at 4 MFMAs per tile.)
+    constexpr bool FAST = ALIGNED && GATHER == 0;
+    const int klen = (int)(kend - kbeg);
+    const float* pa_run[NA]; const float* pa_safe[NA]; int ka_row[NA]; unsigned ia_ok = 0;
+    const float* pb_run[B16 ? 1 : NB]; const float* pb_safe[B16 ? 1 : NB]; int kb_row[B16 ? 1 : NB]; unsigned ib_ok = 0;
+    const T16* ph_run[4]; const T16* ph_safe[4]; bool ih_ok = false;
+    int64_t step_a = 0, step_b = 0;
+    if constexpr (FAST) {
+        auto init = [&](const float* X, int64_t ld, int idx0, int IDX, bool row, int bt, auto& run, auto& safe, auto& krow,
+                        unsigned& iok, int64_t& step) {
+            constexpr int NV = sizeof(run) / sizeof(run[0]);
+            step = row ? BK : (int64_t)BK * ld;
+#pragma unroll
+            for (int p = 0; p < NV; ++p) {
+                int kr, idx; bool ok = true;
+                int64_t off_idx;
+                if (row) {
+                    idx = min(idx0 + (tid >> 4) + 16 * p, IDX - 1);
+                    kr = (tid & 15) * 4;
+                    off_idx = (int64_t)idx * ld;
+                    const int64_t kc = min(kbeg + kr, g.Kc - 4);
+                    run[p] = X + off_idx + kbeg + kr;
+                    safe[p] = X + off_idx + kc;
+                } else {
+                    const int cpr = bt >> 2;
+                    const int slot = tid + 256 * (p >> 2);
+                    const int kg = slot / cpr, ch = slot - kg * cpr;
+                    kr = kg * 4 + (p & 3);
+                    idx = idx0 + 4 * ch;
+                    ok = idx < IDX;
+                    off_idx = min(idx, IDX - 4);
+                    run[p] = X + (kbeg + kr) * ld + off_idx;
+                    safe[p] = X + min(kbeg + kr, kend - 1) * ld + off_idx;
+                }
+                krow[p] = kr;
+                if (ok) iok |= 1u << p;
+            }
+        };
+        init(Ab, g.lda, i0, g.I, AROW, BM, pa_run, pa_safe, ka_row, ia_ok, step_a);
+        if constexpr (B16) {
+            step_b = (int64_t)BK * g.ldb;
+            const int idx = j0 + 8 * hch;
+            ih_ok = hkg < 16 && idx < g.J;
+            const int64_t off_idx = min(idx, g.J - 8);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int kr = min(hkg, 15) * 4 + j;
+                ph_run[j] = Bh + (kbeg + kr) * g.ldb + off_idx;
+                ph_safe[j] = Bh + min(kbeg + kr, kend - 1) * g.ldb + off_idx;
+            }
+        } else {
+            init(Bb, g.ldb, j0, g.J, BROW, BN, pb_run, pb_safe, kb_row, ib_ok, step_b);
+        }
+    }
     auto load_tile = [&](int kt) {
-        const int64_t k0 = kbeg + (int64_t)kt * BK;
-        load_operand(ra, keep_a, Ab, g.lda, i0, g.I, AROW, BM, k0, GATHER == 2 ? 2 : 0);
-        if constexpr (B16) load_b16(k0);
-        else load_operand(rb, keep_b, Bb, g.ldb, j0, g.J, BROW, BN, k0, GATHER == 1 ? 1 : 0);
+        if constexpr (FAST) {
+            const int kofs = kt * BK;
+            keep_a = ia_ok;
+#pragma unroll
+            for (int p = 0; p < NA; ++p) {
+                const bool in = ka_row[p] + kofs < klen;
+                ra[p] = *reinterpret_cast<const f32x4*>(in ? pa_run[p] : pa_safe[p]);
+                if (!in) keep_a &= ~(1u << p);
+                pa_run[p] += step_a;
+            }
+            if constexpr (B16) {
+                keep_b = ih_ok ? 15u : 0u;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const bool in = min(hkg, 15) * 4 + j + kofs < klen;
+                    rbh[j] = *reinterpret_cast<const x8*>(in ? ph_run[j] : ph_safe[j]);
+                    if (!in) keep_b &= ~(1u << j);
+                    ph_run[j] += step_b;
+                }
+            } else {
+                keep_b = ib_ok;
+#pragma unroll
+                for (int p = 0; p < NB; ++p) {
+                    const bool in = kb_row[p] + kofs < klen;
+                    rb[p] = *reinterpret_cast<const f32x4*>(in ? pb_run[p] : pb_safe[p]);
+                    if (!in) keep_b &= ~(1u << p);
+                    pb_run[p] += step_b;
+                }
+            }
+        } else {
+            const int64_t k0 = kbeg + (int64_t)kt * BK;
+            load_operand(ra, keep_a, Ab, g.lda, i0, g.I, AROW, BM, k0, GATHER == 2 ? 2 : 0);
+            if constexpr (B16) load_b16(k0);
+            else load_operand(rb, keep_b, Bb, g.ldb, j0, g.J, BROW, BN, k0, GATHER == 1 ? 1 : 0);
+        }
     };
     auto store_tile = [&](int buf) {
         store_operand(ra, keep_a, As + buf * BM * BK, AROW, BM);
@@ -225,21 +313,25 @@ __global__ __launch_bounds__(256, 2) void gemm_bwd_mfma16_kernel(const BwdArgs g
         const bool more = kt + 1 < nkt;
         if (more) load_tile(kt + 1);
         __builtin_amdgcn_sched_barrier(0);                    // loads stay in flight across the MFMAs of this tile
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            x8 fa[TM], fb[TN];
+        x8 fa[2][TM], fb[2][TN];                              // fragments of step s+1 are read while step s multiplies
+        auto read_frags = [&](int s) {
 #pragma unroll
             for (int t = 0; t < TM; ++t)
-                fa[t] = *reinterpret_cast<const x8*>(As + cur * BM * BK + lds_off(a_idx + 32 * t, 16 * s + 8 * hf));
+                fa[s & 1][t] = *reinterpret_cast<const x8*>(As + cur * BM * BK + lds_off(a_idx + 32 * t, 16 * s + 8 * hf));
 #pragma unroll
             for (int t = 0; t < TN; ++t)
-                fb[t] = *reinterpret_cast<const x8*>(Bs + cur * BN * BK + lds_off(b_idx + 32 * t, 16 * s + 8 * hf));
+                fb[s & 1][t] = *reinterpret_cast<const x8*>(Bs + cur * BN * BK + lds_off(b_idx + 32 * t, 16 * s + 8 * hf));
+        };
+        read_frags(0);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            if (s < 3) read_frags(s + 1);
 #pragma unroll
             for (int mt = 0; mt < TM; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < TN; ++nt)
-                    acc[mt][nt] = SPLITK ? Lowp<T16>::mfma(fa[mt], fb[nt], acc[mt][nt])
-                                         : Lowp<T16>::mfma(fb[nt], fa[mt], acc[mt][nt]);
+                    acc[mt][nt] = SPLITK ? Lowp<T16>::mfma(fa[s & 1][mt], fb[s & 1][nt], acc[mt][nt])
+                                         : Lowp<T16>::mfma(fb[s & 1][nt], fa[s & 1][mt], acc[mt][nt]);
         }
         __builtin_amdgcn_sched_barrier(0);
         if (more) store_tile(cur ^ 1);
