@@ -17,9 +17,16 @@ __global__ __launch_bounds__(256, 2) void gemm_bwd_mfma16_kernel(const BwdArgs g
     using x4 = typename Lowp<T16>::x4;
     constexpr int TM = BM / 64, TN = BN / 64, BK = 64;
     constexpr int NA = BM / 16, NB = BN / 16;                 // float4 loads per thread per tile
-    __shared__ __attribute__((aligned(16))) T16 lds[2 * (BM + BN) * BK];
-    T16* As = lds;                    // [2][BM][64]
-    T16* Bs = lds + 2 * BM * BK;      // [2][BN][64]
+    // LDS image per operand and stage.  Index-major (ROW) operands: [index][64 k], 128-byte rows, XOR-swizzled 16-byte
+    // blocks, fragments by ds_read_b128.  Contraction-major (COL) operands: stored AS LOADED, [64 k][index] with rows of
+    // (BT + 32) elements (the 64-byte pad puts four consecutive k rows on disjoint bank ranges), and the MFMA fragment --
+    // 8 consecutive k of one index -- is fetched with two ds_read_b64_tr_b16 (gfx950's transposing LDS read): no register
+    // transposes and full-width (8 / 16-byte) LDS writes.
+    constexpr int RSA = BM + 32, RSB = BN + 32;               // COL row strides in elements
+    constexpr int AF = AROW ? BM * BK : BK * RSA, BF = BROW ? BN * BK : BK * RSB;
+    __shared__ __attribute__((aligned(16))) T16 lds[2 * (AF + BF)];
+    T16* As = lds;                    // [2][AF]
+    T16* Bs = lds + 2 * AF;           // [2][BF]
 
     const unsigned nwg = g.tiles_i * g.tiles_j;
     const unsigned tile = xcd_remap(blockIdx.x, nwg);
@@ -148,10 +155,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bwd_mfma16_kernel(const BwdArgs g
                 const int slot = tid + 256 * q;
                 const int kg = slot / cpr, ch = slot - kg * cpr;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {                          // idx 4ch+e gets k-run kg*4 .. kg*4+3
-                    const f32x4 run = {regs[4 * q][e], regs[4 * q + 1][e], regs[4 * q + 2][e], regs[4 * q + 3][e]};
-                    *reinterpret_cast<x4*>(S + lds_off(4 * ch + e, kg * 4)) = Lowp<T16>::cvt4(run);
-                }
+                for (int j = 0; j < 4; ++j)                            // k row kg*4+j, indices 4ch .. 4ch+3: as loaded
+                    *reinterpret_cast<x4*>(S + (kg * 4 + j) * (bt + 32) + 4 * ch) = Lowp<T16>::cvt4(regs[4 * q + j]);
             }
         }
     };
@@ -184,14 +189,12 @@ __global__ __launch_bounds__(256, 2) void gemm_bwd_mfma16_kernel(const BwdArgs g
     };
     auto store_b16 = [&](T16* S) {
         if (hkg >= 16) return;
-        const T16 z16 = (T16)0.f;
+        x8 z8;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            x4 run;
-            run[0] = (keep_b & 1u) ? rbh[0][e] : z16; run[1] = (keep_b & 2u) ? rbh[1][e] : z16;
-            run[2] = (keep_b & 4u) ? rbh[2][e] : z16; run[3] = (keep_b & 8u) ? rbh[3][e] : z16;
-            *reinterpret_cast<x4*>(S + lds_off(8 * hch + e, hkg * 4)) = run;
-        }
+        for (int e = 0; e < 8; ++e) z8[e] = (T16)0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            *reinterpret_cast<x8*>(S + (hkg * 4 + j) * RSB + 8 * hch) = ((keep_b >> j) & 1u) ? rbh[j] : z8;
     };
     f32x4 ra[NA], rb[B16 ? 1 : NB];
     // ---- FAST path (ALIGNED, no gather): every load has a running 64-bit pointer that advances by a constant per K-tile;
@@ -289,9 +292,25 @@ __global__ __launch_bounds__(256, 2) void gemm_bwd_mfma16_kernel(const BwdArgs g
         }
     };
     auto store_tile = [&](int buf) {
-        store_operand(ra, keep_a, As + buf * BM * BK, AROW, BM);
-        if constexpr (B16) store_b16(Bs + buf * BN * BK);
-        else store_operand(rb, keep_b, Bs + buf * BN * BK, BROW, BN);
+        store_operand(ra, keep_a, As + buf * AF, AROW, BM);
+        if constexpr (B16) store_b16(Bs + buf * BF);
+        else store_operand(rb, keep_b, Bs + buf * BF, BROW, BN);
+    };
+
+    // Transposing fragment read of a [k][index] image: the 16-lane group (lane >> 4) covers indices idx0 + 16*(group & 1) ..
+    // +15 and k rows 16 s + 8 hf + {0..3} (first read) / {4..7} (second); lane 4q+p of the group supplies the address of
+    // row q, indices 4p .. 4p+3, and receives its own index (lane & 31) at the four rows.  EXEC is all ones here.
+    typedef short s16x4 __attribute__((ext_vector_type(4)));
+    auto tr_frag = [&](const T16* S, int rs, int idx0, int s) -> x8 {
+        const int q = (lane >> 2) & 3, p = lane & 3, grp = (lane >> 4) & 1;
+        const T16* a0 = S + (16 * s + 8 * hf + q) * rs + idx0 + 16 * grp + 4 * p;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) s16x4*)(const_cast<T16*>(a0)));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) s16x4*)(const_cast<T16*>(a0 + 4 * rs)));
+        union { struct { s16x4 l, h; } p2; x8 v; } u;
+        u.p2.l = lo; u.p2.h = hi;
+        return u.v;
     };
 
     f32x16 acc[TM][TN];
@@ -317,10 +336,12 @@ __global__ __launch_bounds__(256, 2) void gemm_bwd_mfma16_kernel(const BwdArgs g
         auto read_frags = [&](int s) {
 #pragma unroll
             for (int t = 0; t < TM; ++t)
-                fa[s & 1][t] = *reinterpret_cast<const x8*>(As + cur * BM * BK + lds_off(a_idx + 32 * t, 16 * s + 8 * hf));
+                fa[s & 1][t] = AROW ? *reinterpret_cast<const x8*>(As + cur * AF + lds_off(a_idx + 32 * t, 16 * s + 8 * hf))
+                                    : tr_frag(As + cur * AF, RSA, wr * (BM / 2) + 32 * t, s);
 #pragma unroll
             for (int t = 0; t < TN; ++t)
-                fb[s & 1][t] = *reinterpret_cast<const x8*>(Bs + cur * BN * BK + lds_off(b_idx + 32 * t, 16 * s + 8 * hf));
+                fb[s & 1][t] = BROW ? *reinterpret_cast<const x8*>(Bs + cur * BF + lds_off(b_idx + 32 * t, 16 * s + 8 * hf))
+                                    : tr_frag(Bs + cur * BF, RSB, wc * (BN / 2) + 32 * t, s);
         };
         read_frags(0);
 #pragma unroll
