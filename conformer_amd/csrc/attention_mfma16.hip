@@ -7,9 +7,10 @@
 //   * v_mfma_f32_32x32x16_{bf16,f16}: 4 steps per 64-dim product instead of 32 -> 16 MFMAs per key tile instead of 128,
 //     so the kernel is bound by the staging / skew / softmax instruction stream, not by the matrix pipe;
 //   * K and the ring are staged as 16-bit rows of 144 B (conflict-free 16-byte fragment reads: 8 dims per lane per step);
-//   * V is staged TRANSPOSED ([dim][key], 16-bit): the P.V product contracts over keys, and a lane's accumulator
-//     registers hold keys {16s + 8(e>>2) + 4hf + (e&3)}, e = 0..7, for step s -- the V^T fragment is two 8-byte reads
-//     in exactly that key order, so P goes from the softmax registers to the MFMA without any shuffle;
+//   * the P.V product contracts over keys, and a lane's accumulator registers hold keys {16s + 8(e>>2) + 4hf + (e&3)},
+//     e = 0..7, for step s.  V is staged as loaded ([key][dim], 16-bit) and its V^T fragment is fetched with two
+//     ds_read_b64_tr_b16 (gfx950's transposing LDS read) over key rows 16s+4hf+{0..3} and +8 -- exactly that key order,
+//     so P goes from the softmax registers to the MFMA without any shuffle and V is never transposed by hand;
 //   * (Q+u), (Q+v) live in 16 VGPRs each (64 in the fp32 kernel): 48 KB LDS + ~130 VGPRs -> 3 workgroups per CU.
 #include "cfm_common.h"
 #include <math.h>
@@ -17,7 +18,7 @@
 namespace {
 
 constexpr int KROWH = 72;                // LDS row (16-bit elements) of the K tile and the P ring: 64 + 8 pad = 144 B
-constexpr int VROWH = 40;                // LDS row of V^T: 32 keys + 8 pad = 80 B
+constexpr int VROWH = 96;                // LDS row of the V tile [key][dim]: 64 dims + 32 pad = 192 B (tr-read conflict-free)
 constexpr int RINGH = 160;
 
 struct Attn16Args {
@@ -32,11 +33,11 @@ template <typename T16>
 __global__ __launch_bounds__(256, 2) void relpos_attn_fwd_mfma16_kernel(const Attn16Args a) {
     using x8 = typename Lowp<T16>::x8;
     using x4 = typename Lowp<T16>::x4;
-    __shared__ __attribute__((aligned(16))) T16 smem16[32 * KROWH + 64 * VROWH + RINGH * KROWH];
+    __shared__ __attribute__((aligned(16))) T16 smem16[32 * KROWH + 32 * VROWH + RINGH * KROWH];
     __shared__ __attribute__((aligned(16))) float gsm[4 * 32 * 32];
     T16* Ks = smem16;                            // [32 keys][KROWH]
-    T16* Vt = Ks + 32 * KROWH;                   // [64 dims][VROWH]   (V transposed)
-    T16* Pr = Vt + 64 * VROWH;                   // [RINGH][KROWH]
+    T16* Vt = Ks + 32 * KROWH;                   // [32 keys][VROWH]: stored as loaded, read transposed (ds_read_b64_tr_b16)
+    T16* Pr = Vt + 32 * VROWH;                   // [RINGH][KROWH]
     float* gs = gsm + (threadIdx.x >> 6) * 1024; // per-wave skew tile [32][32]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -87,9 +88,7 @@ __global__ __launch_bounds__(256, 2) void relpos_attn_fwd_mfma16_kernel(const At
         for (int p = 0; p < 2; ++p) {
             const int r = srow + 16 * p;
             *reinterpret_cast<x4*>(Ks + r * KROWH + sch * 4) = Lowp<T16>::cvt4(pk[p]);
-            const x4 vv = Lowp<T16>::cvt4(pv[p]);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) Vt[(sch * 4 + e) * VROWH + r] = vv[e];          // transpose while staging
+            *reinterpret_cast<x4*>(Vt + r * VROWH + sch * 4) = Lowp<T16>::cvt4(pv[p]);
             const int slot = (jnew + r + ring_bias) % RINGH;
             *reinterpret_cast<x4*>(Pr + slot * KROWH + sch * 4) = Lowp<T16>::cvt4(pp[p]);
         }
@@ -228,12 +227,16 @@ __global__ __launch_bounds__(256, 2) void relpos_attn_fwd_mfma16_kernel(const At
                 for (int e = 0; e < 8; ++e) pb[e] = (T16)p[8 * s + e];
 #pragma unroll
                 for (int n = 0; n < 2; ++n) {
-                    const T16* vrow = Vt + (32 * n + li) * VROWH + 16 * s + 4 * hf;
-                    const x4 lo = *reinterpret_cast<const x4*>(vrow), hi = *reinterpret_cast<const x4*>(vrow + 8);
-                    x8 va;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { va[e] = lo[e]; va[4 + e] = hi[e]; }
-                    o[n] = Lowp<T16>::mfma(va, pb, o[n]);
+                    // V^T fragment by the transposing LDS read: 16-lane group -> dims 32n + 16*(group&1) .. +15, key rows
+                    // 16s + 4hf + {0..3} and + 8: lane 4q+p supplies row q, dims 4p..4p+3; each lane gets its own dim
+                    typedef short s16x4 __attribute__((ext_vector_type(4)));
+                    const int tq = (lane >> 2) & 3, tp = lane & 3, grp = (lane >> 4) & 1;
+                    const T16* a0 = Vt + (16 * s + 4 * hf + tq) * VROWH + 32 * n + 16 * grp + 4 * tp;
+                    union { struct { s16x4 l, h; } p2; x8 v; } u;
+                    u.p2.l = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(const_cast<T16*>(a0)));
+                    u.p2.h = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) s16x4*)(const_cast<T16*>(a0 + 8 * VROWH)));
+                    o[n] = Lowp<T16>::mfma(u.v, pb, o[n]);
                 }
             }
         }
