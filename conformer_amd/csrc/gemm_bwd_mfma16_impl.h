@@ -201,44 +201,50 @@ __global__ __launch_bounds__(256, 2) void gemm_bwd_mfma16_kernel(const BwdArgs g
     // the only per-tile work is one 32-bit "still inside the split?" compare per load and a select between the running and
     // a precomputed always-valid pointer.  (The general path re-derives each address with 64-bit min / multiply / add:
     // ~10 VALU instructions per load, which made the 64x64 variants instruction-bound at 4 MFMAs per tile.)
-    constexpr bool FAST = ALIGNED && GATHER == 0;
+    // Per-operand fast paths (ALIGNED).  Plain operands: running pointers.  Stem gathers: the index arithmetic that does not
+    // change from tile to tile is hoisted -- GATHER 1 (B = im2col(h1)): the (tap, ci) part is a per-thread constant and the
+    // output position (b, t2, f2) of a thread's first k row is advanced by 64 rows per tile with carries instead of being
+    // re-derived with two 64-bit divisions per load; GATHER 2 (A = dz2 rows per tap): the row pointer is recomputed only when
+    // the contraction crosses into the next tap (every C/64 tiles) and advanced by 64 otherwise.
+    constexpr bool FAST_A = ALIGNED && GATHER != 2, FAST_B = ALIGNED && GATHER != 1;
+    constexpr bool FAST_G1 = ALIGNED && GATHER == 1, FAST_G2 = ALIGNED && GATHER == 2;
     const int klen = (int)(kend - kbeg);
     const float* pa_run[NA]; const float* pa_safe[NA]; int ka_row[NA]; unsigned ia_ok = 0;
     const float* pb_run[B16 ? 1 : NB]; const float* pb_safe[B16 ? 1 : NB]; int kb_row[B16 ? 1 : NB]; unsigned ib_ok = 0;
     const T16* ph_run[4]; const T16* ph_safe[4]; bool ih_ok = false;
     int64_t step_a = 0, step_b = 0;
-    if constexpr (FAST) {
-        auto init = [&](const float* X, int64_t ld, int idx0, int IDX, bool row, int bt, auto& run, auto& safe, auto& krow,
-                        unsigned& iok, int64_t& step) {
-            constexpr int NV = sizeof(run) / sizeof(run[0]);
-            step = row ? BK : (int64_t)BK * ld;
+    auto init = [&](const float* X, int64_t ld, int idx0, int IDX, bool row, int bt, auto& run, auto& safe, auto& krow,
+                    unsigned& iok, int64_t& step) {
+        constexpr int NV = sizeof(run) / sizeof(run[0]);
+        step = row ? BK : (int64_t)BK * ld;
 #pragma unroll
-            for (int p = 0; p < NV; ++p) {
-                int kr, idx; bool ok = true;
-                int64_t off_idx;
-                if (row) {
-                    idx = min(idx0 + (tid >> 4) + 16 * p, IDX - 1);
-                    kr = (tid & 15) * 4;
-                    off_idx = (int64_t)idx * ld;
-                    const int64_t kc = min(kbeg + kr, g.Kc - 4);
-                    run[p] = X + off_idx + kbeg + kr;
-                    safe[p] = X + off_idx + kc;
-                } else {
-                    const int cpr = bt >> 2;
-                    const int slot = tid + 256 * (p >> 2);
-                    const int kg = slot / cpr, ch = slot - kg * cpr;
-                    kr = kg * 4 + (p & 3);
-                    idx = idx0 + 4 * ch;
-                    ok = idx < IDX;
-                    off_idx = min(idx, IDX - 4);
-                    run[p] = X + (kbeg + kr) * ld + off_idx;
-                    safe[p] = X + min(kbeg + kr, kend - 1) * ld + off_idx;
-                }
-                krow[p] = kr;
-                if (ok) iok |= 1u << p;
+        for (int p = 0; p < NV; ++p) {
+            int kr, idx; bool ok = true;
+            int64_t off_idx;
+            if (row) {
+                idx = min(idx0 + (tid >> 4) + 16 * p, IDX - 1);
+                kr = (tid & 15) * 4;
+                off_idx = (int64_t)idx * ld;
+                const int64_t kc = min(kbeg + kr, g.Kc - 4);
+                run[p] = X + off_idx + kbeg + kr;
+                safe[p] = X + off_idx + kc;
+            } else {
+                const int cpr = bt >> 2;
+                const int slot = tid + 256 * (p >> 2);
+                const int kg = slot / cpr, ch = slot - kg * cpr;
+                kr = kg * 4 + (p & 3);
+                idx = idx0 + 4 * ch;
+                ok = idx < IDX;
+                off_idx = min(idx, IDX - 4);
+                run[p] = X + (kbeg + kr) * ld + off_idx;
+                safe[p] = X + min(kbeg + kr, kend - 1) * ld + off_idx;
             }
-        };
-        init(Ab, g.lda, i0, g.I, AROW, BM, pa_run, pa_safe, ka_row, ia_ok, step_a);
+            krow[p] = kr;
+            if (ok) iok |= 1u << p;
+        }
+    };
+    if constexpr (FAST_A) init(Ab, g.lda, i0, g.I, AROW, BM, pa_run, pa_safe, ka_row, ia_ok, step_a);
+    if constexpr (FAST_B) {
         if constexpr (B16) {
             step_b = (int64_t)BK * g.ldb;
             const int idx = j0 + 8 * hch;
@@ -254,9 +260,47 @@ __global__ __launch_bounds__(256, 2) void gemm_bwd_mfma16_kernel(const BwdArgs g
             init(Bb, g.ldb, j0, g.J, BROW, BN, pb_run, pb_safe, kb_row, ib_ok, step_b);
         }
     }
+    // GATHER 1 state: per register group q (4 consecutive k rows), the output position of its first row
+    constexpr int NQ = NB / 4;
+    int g1_f2[NQ], g1_t2[NQ]; int64_t g1_b[NQ]; int g1_kr[NQ]; int64_t g1_tap[NQ]; unsigned g1_ok = 0;
+    const int q64 = g.cF2 > 0 ? BK / g.cF2 : 0, r64 = g.cF2 > 0 ? BK - q64 * g.cF2 : 0;       // 64 rows = q64 full f2 rows + r64
+    if constexpr (FAST_G1) {
+        const int cpr = BN >> 2;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int slot = tid + 256 * q;
+            const int kg = slot / cpr, ch = slot - kg * cpr;
+            const int idx = j0 + 4 * ch, idc = min(idx, g.J - 4);
+            const int tap = idc / g.cC, ci = idc - tap * g.cC;
+            const int kf = tap / 3, ktp = tap - 3 * kf;
+            g1_tap[q] = ((int64_t)ktp * g.cF1 + kf) * g.cC + ci;
+            g1_kr[q] = kg * 4;
+            const int64_t m0 = kbeg + kg * 4;
+            g1_f2[q] = (int)(m0 % g.cF2);
+            const int64_t bt2 = m0 / g.cF2;
+            g1_t2[q] = (int)(bt2 % g.cT2);
+            g1_b[q] = bt2 / g.cT2;
+            if (idx < g.J) g1_ok |= 1u << q;
+        }
+    }
+    // GATHER 2 state: row pointer per staged class row for the current tap
+    const float* g2_ptr[NA]; unsigned g2_ok = 0;
+    auto g2_retarget = [&](int64_t k0) {
+        const int tap = (int)(k0 / g.cC);
+        const int co = (int)(k0 - (int64_t)tap * g.cC) + (tid & 15) * 4;
+        g2_ok = 0;
+#pragma unroll
+        for (int p = 0; p < NA; ++p) {
+            const int t2 = g2_a[p] + g.tap_dt[tap], f2 = g2_c[p] + g.tap_df[tap];
+            if (t2 >= 0 && t2 < g.cT2 && f2 >= 0 && f2 < g.cF2) g2_ok |= 1u << p;
+            const int t2c = min(max(t2, 0), g.cT2 - 1), f2c = min(max(f2, 0), g.cF2 - 1);
+            g2_ptr[p] = Ab + (((int64_t)g2_b[p] * g.cT2 + t2c) * g.cF2 + f2c) * g.cC + co;
+        }
+    };
     auto load_tile = [&](int kt) {
-        if constexpr (FAST) {
-            const int kofs = kt * BK;
+        const int kofs = kt * BK;
+        const int64_t k0 = kbeg + (int64_t)kofs;
+        if constexpr (FAST_A) {
             keep_a = ia_ok;
 #pragma unroll
             for (int p = 0; p < NA; ++p) {
@@ -265,30 +309,59 @@ __global__ __launch_bounds__(256, 2) void gemm_bwd_mfma16_kernel(const BwdArgs g
                 if (!in) keep_a &= ~(1u << p);
                 pa_run[p] += step_a;
             }
-            if constexpr (B16) {
-                keep_b = ih_ok ? 15u : 0u;
+        } else if constexpr (FAST_G2) {
+            if (k0 % g.cC == 0) g2_retarget(k0);                 // uniform: a new tap every C/64 tiles
+            keep_a = g2_ok;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const bool in = min(hkg, 15) * 4 + j + kofs < klen;
-                    rbh[j] = *reinterpret_cast<const x8*>(in ? ph_run[j] : ph_safe[j]);
-                    if (!in) keep_b &= ~(1u << j);
-                    ph_run[j] += step_b;
-                }
-            } else {
-                keep_b = ib_ok;
-#pragma unroll
-                for (int p = 0; p < NB; ++p) {
-                    const bool in = kb_row[p] + kofs < klen;
-                    rb[p] = *reinterpret_cast<const f32x4*>(in ? pb_run[p] : pb_safe[p]);
-                    if (!in) keep_b &= ~(1u << p);
-                    pb_run[p] += step_b;
-                }
+            for (int p = 0; p < NA; ++p) {
+                ra[p] = *reinterpret_cast<const f32x4*>(g2_ptr[p]);
+                g2_ptr[p] += BK;
             }
         } else {
-            const int64_t k0 = kbeg + (int64_t)kt * BK;
             load_operand(ra, keep_a, Ab, g.lda, i0, g.I, AROW, BM, k0, GATHER == 2 ? 2 : 0);
-            if constexpr (B16) load_b16(k0);
-            else load_operand(rb, keep_b, Bb, g.ldb, j0, g.J, BROW, BN, k0, GATHER == 1 ? 1 : 0);
+        }
+        if constexpr (FAST_B && B16) {
+            keep_b = ih_ok ? 15u : 0u;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool in = min(hkg, 15) * 4 + j + kofs < klen;
+                rbh[j] = *reinterpret_cast<const x8*>(in ? ph_run[j] : ph_safe[j]);
+                if (!in) keep_b &= ~(1u << j);
+                ph_run[j] += step_b;
+            }
+        } else if constexpr (FAST_B) {
+            keep_b = ib_ok;
+#pragma unroll
+            for (int p = 0; p < NB; ++p) {
+                const bool in = kb_row[p] + kofs < klen;
+                rb[p] = *reinterpret_cast<const f32x4*>(in ? pb_run[p] : pb_safe[p]);
+                if (!in) keep_b &= ~(1u << p);
+                pb_run[p] += step_b;
+            }
+        } else if constexpr (FAST_G1) {
+            keep_b = 0;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                int f2 = g1_f2[q], t2 = g1_t2[q];
+                int64_t bb = g1_b[q];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const bool in = g1_kr[q] + j + kofs < klen;
+                    const float* src = Bb + (((bb * g.cT1 + 2 * t2) * g.cF1 + 2 * f2) * (int64_t)g.cC) + g1_tap[q];
+                    rb[4 * q + j] = *reinterpret_cast<const f32x4*>(in ? src : Bb);
+                    if (in && ((g1_ok >> q) & 1u)) keep_b |= 1u << (4 * q + j);
+                    if (++f2 == g.cF2) { f2 = 0; if (++t2 == g.cT2) { t2 = 0; ++bb; } }      // next output position
+                }
+                // advance the group's first row by 64 output positions
+                int nf = g1_f2[q] + r64, nt = g1_t2[q] + q64;
+                if (nf >= g.cF2) { nf -= g.cF2; ++nt; }
+                while (nt >= g.cT2) { nt -= g.cT2; ++g1_b[q]; }
+                g1_f2[q] = nf; g1_t2[q] = nt;
+            }
+        } else if constexpr (B16) {
+            load_b16(k0);
+        } else {
+            load_operand(rb, keep_b, Bb, g.ldb, j0, g.J, BROW, BN, k0, GATHER == 1 ? 1 : 0);
         }
     };
     auto store_tile = [&](int buf) {
