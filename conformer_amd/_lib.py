@@ -33,7 +33,7 @@ SIGNATURES = {
     "cfm_subsample_conv2_relu_mfma16_f32": (c_int, [_I, _P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P]),
     "cfm_subsample_conv1_relu_out16_f32": (c_int, [_I, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "cfm_gemm_bwd_batched_mfma16_f32": (c_int, [_I, _P, _I, _L, _P, _I, _I, _L, _P, _L, _F, _P, _L, _I, _I, _L, _I, _I, _I, _I,
-                                                _L, _L, _L, _L, _L, _L, _F, _U, _P]),
+                                                _L, _L, _L, _L, _L, _L, _F, _U, _I, _P]),
     "cfm_subsample_conv2_bwd_weight_mfma16_f32": (c_int, [_I, _P, _P, _P, _I, _I, _I, _I, _P]),
     "cfm_subsample_conv2_bwd_input_mfma16_f32": (c_int, [_I, _P, _P, _P, _I, _I, _I, _I, _P]),
     "cfm_reflect_pad_f32": (c_int, [_P, _P, _I, _L, _I, _L, _P]),

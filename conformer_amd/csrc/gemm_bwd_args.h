@@ -13,6 +13,7 @@ struct BwdArgs {
     float drop_p; unsigned long long drop_seed;   // DSWISH: the forward dropped swish(Z): re-apply its mask to the incoming gradient
     int accumulate;                      // C += ... (non-atomic read-modify-write; not combined with splits)
     int b16;                             // 16-bit kernels: operand B is already stored in the 16-bit type (ldb/sb* in elements)
+    int pad4;                            // 16-bit kernels: ragged Kc / I / J are physically padded to a multiple of 4 with zeros
     int nbatch, nb1;                     // batched: blockIdx.z = b0*nb1 + b1; operand offset = b0*s?0 + b1*s?1
     int64_t sa0, sa1, sb0, sb1, sc0, sc1;
     // stem-convolution gathers (GATHER != 0): geometry of the 3x3 / stride-2 conv over the channel-last h1

@@ -27,7 +27,7 @@ extern "C" int cfm_gemm_bwd_batched_mfma16_f32(int prec, const float* A, int a_c
                                                int64_t ldc, int I, int J, int64_t Kc, int allow_split, int accumulate,
                                                int nbatch, int nb1, int64_t sa0, int64_t sa1, int64_t sb0, int64_t sb1,
                                                int64_t sc0, int64_t sc1, float drop_p, uint64_t drop_seed,
-                                               cfm_stream_t stream) {
+                                               int operands_zero_padded4, cfm_stream_t stream) {
     CFM_REQUIRE(A && B && C, CFM_ERR_NULL);
     CFM_REQUIRE(I > 0 && J > 0 && Kc > 0 && nbatch > 0 && nb1 > 0 && nbatch % nb1 == 0 && nbatch <= 65535, CFM_ERR_BAD_SHAPE);
     CFM_REQUIRE((ldc & 3) == 0 && (lda & 3) == 0 && (ldb & 3) == 0, CFM_ERR_BAD_SHAPE);
@@ -38,6 +38,7 @@ extern "C" int cfm_gemm_bwd_batched_mfma16_f32(int prec, const float* A, int a_c
     CFM_REQUIRE(!Z_or_null || (!a_col && b_col && nbatch == 1), CFM_ERR_UNSUPPORTED);
     BwdArgs g{};
     g.b16 = b_is_16bit != 0;
+    g.pad4 = operands_zero_padded4 != 0;
     g.A = A; g.B = static_cast<const float*>(B); g.Z = Z_or_null; g.C = C; g.I = I; g.J = J; g.Kc = Kc;
     g.lda = lda; g.ldb = ldb; g.ldz = ldz; g.ldc = ldc; g.alpha = alpha;
     g.splits = (allow_split && !accumulate) ? 0 : 1;

@@ -225,7 +225,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bwd_mfma16_kernel(const BwdArgs g
                 idx = min(idx0 + (tid >> 4) + 16 * p, IDX - 1);
                 kr = (tid & 15) * 4;
                 off_idx = (int64_t)idx * ld;
-                const int64_t kc = min(kbeg + kr, g.Kc - 4);
+                const int64_t kc = min(kbeg + kr, (g.Kc - 1) & ~(int64_t)3);      // (ragged Kc under pad4: the padded chunk)
                 run[p] = X + off_idx + kbeg + kr;
                 safe[p] = X + off_idx + kc;
             } else {
@@ -235,7 +235,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bwd_mfma16_kernel(const BwdArgs g
                 kr = kg * 4 + (p & 3);
                 idx = idx0 + 4 * ch;
                 ok = idx < IDX;
-                off_idx = min(idx, IDX - 4);
+                off_idx = min(idx, (IDX - 1) & ~3);                               // (ragged IDX under pad4: the padded chunk)
                 run[p] = X + (kbeg + kr) * ld + off_idx;
                 safe[p] = X + min(kbeg + kr, kend - 1) * ld + off_idx;
             }
@@ -449,8 +449,10 @@ int launch_one(BwdArgs g, hipStream_t s) {
     const int64_t per = (g.Kc + splits - 1) / splits;
     g.k_per_split = (per + 63) / 64 * 64;
     const dim3 grid(tiles, (unsigned)splits, (unsigned)g.nbatch);
-    const bool aligned = (AROW ? (g.Kc & 3) == 0 : (g.I & 3) == 0) &&
-                         (BROW ? (g.Kc & 3) == 0 : (g.J & (B16 ? 7 : 3)) == 0);
+    // pad4: the caller guarantees that ragged extents are physically padded to a multiple of 4 with ZEROS (the attention
+    // backward's (T x T4) / (T x P4) tensors), so their partial 16-byte chunks may be loaded whole
+    const bool aligned = ((AROW ? (g.Kc & 3) == 0 : (g.I & 3) == 0) || g.pad4) &&
+                         ((BROW ? (g.Kc & 3) == 0 : (g.J & (B16 ? 7 : 3)) == 0) || (g.pad4 && !B16));
     if constexpr (kCanSplit) {
         if (splits > 1) {
             if (aligned) hipLaunchKernelGGL((gemm_bwd_mfma16_kernel<T16, BM, BN, AROW, BROW, EPI, GATHER, true, B16, true>), grid, dim3(256), 0, s, g);

@@ -437,11 +437,12 @@ def colsum(x2d, alpha: float = 1.0, rows=None, cols=None, ld=None, out=None):
 def gemm_bwd(A, a_col: bool, B, b_col: bool, I: int, J: int, Kc: int, *, alpha: float = 1.0, Z=None, out=None,
              lda=None, ldb=None, ldc=None, ldz=None, allow_split: bool = False, accumulate: bool = False,
              nbatch: int = 1, nb1: int = 1, sa=(0, 0), sb=(0, 0), sc=(0, 0), a_ptr=None, b_ptr=None, c_ptr=None,
-             drop_p: float = 0.0, drop_seed: int = 0, prec: int = 0, b16: bool = False):
+             drop_p: float = 0.0, drop_seed: int = 0, prec: int = 0, b16: bool = False, pad4: bool = False):
     """C (I,J) (+)= alpha * sum_k A(i,k) B(j,k) [* swish'(Z)]; *_col selects the contraction-major layout.
     Pointers default to the tensors' data_ptr(); explicit *_ptr / ld* let callers address sub-blocks (head slices).
     prec: PREC_F32 (fp32 MFMA) | PREC_BF16 | PREC_FP16 (operands rounded while staged, fp32 accumulate).
-    b16: B is a tensor already stored in the 16-bit type of `prec` (contraction-major only; ldb in elements)."""
+    b16: B is a tensor already stored in the 16-bit type of `prec` (contraction-major only; ldb in elements).
+    pad4 (16-bit kernels): ragged Kc / I / J are physically padded to a multiple of 4 with zeros (fast load path)."""
     lda = A.stride(-2) if lda is None else lda
     ldb = B.stride(-2) if ldb is None else ldb
     if out is None:
@@ -450,14 +451,14 @@ def gemm_bwd(A, a_col: bool, B, b_col: bool, I: int, J: int, Kc: int, *, alpha: 
     ldz = 0 if Z is None else (Z.stride(-2) if ldz is None else ldz)
     head = (A.data_ptr() if a_ptr is None else a_ptr, int(a_col), lda, B.data_ptr() if b_ptr is None else b_ptr, int(b_col))
     tail = (ldb, _p(Z), ldz, alpha, out.data_ptr() if c_ptr is None else c_ptr, ldc, I, J, Kc, int(allow_split),
-            int(accumulate), nbatch, nb1, sa[0], sa[1], sb[0], sb[1], sc[0], sc[1], float(drop_p), int(drop_seed),
-            _stream())
+            int(accumulate), nbatch, nb1, sa[0], sa[1], sb[0], sb[1], sc[0], sc[1], float(drop_p), int(drop_seed))
     if prec:
-        _lib.check(_lib.load().cfm_gemm_bwd_batched_mfma16_f32(prec, *head, int(b16), *tail), "cfm_gemm_bwd_batched_mfma16_f32")
+        _lib.check(_lib.load().cfm_gemm_bwd_batched_mfma16_f32(prec, *head, int(b16), *tail, int(pad4), _stream()),
+                   "cfm_gemm_bwd_batched_mfma16_f32")
     else:
         if b16:
             raise _lib.ConformerHipError("a 16-bit B operand needs a 16-bit precision mode")
-        _lib.check(_lib.load().cfm_gemm_bwd_batched_f32(*head, *tail), "cfm_gemm_bwd_batched_f32")
+        _lib.check(_lib.load().cfm_gemm_bwd_batched_f32(*head, *tail, _stream()), "cfm_gemm_bwd_batched_f32")
     return out
 
 
@@ -593,24 +594,24 @@ def relpos_attention_bwd(qkv, pos, u, v, lengths, n_heads, ctx, lse, dctx, drop_
     dq_p = dqkv.data_ptr(); dk_p = dq_p + f * d; dv_p = dq_p + 2 * f * d
     # dV_bh = P_bh^T . dO_bh               (A = P contraction-major over queries; B = dO contraction-major)
     gemm_bwd(Pm, True, dctx, True, T, dh, T, out=dqkv, lda=T4, ldb=d, ldc=d3, nbatch=nb, nb1=H,
-             sa=sBH_sq, sb=sBH_rows, sc=sBH_qkv, c_ptr=dv_p, prec=lp)
+             sa=sBH_sq, sb=sBH_rows, sc=sBH_qkv, c_ptr=dv_p, prec=lp, pad4=True)
     # dK_bh = dS_bh^T . Qu_bh
     gemm_bwd(dS, True, qu, True, T, dh, T, out=dqkv, lda=T4, ldb=d, ldc=d3, nbatch=nb, nb1=H,
-             sa=sBH_sq, sb=sBH_rows, sc=sBH_qkv, c_ptr=dk_p, prec=lp)
+             sa=sBH_sq, sb=sBH_rows, sc=sBH_qkv, c_ptr=dk_p, prec=lp, pad4=True)
     # dQu_bh = dS_bh . K_bh                (contraction over keys: dS index-major, K contraction-major)
     gemm_bwd(dS, False, qkv, True, T, dh, T, out=dqkv, lda=T4, ldb=d3, ldc=d3, nbatch=nb, nb1=H,
-             sa=sBH_sq, sb=sBH_qkv, sc=sBH_qkv, b_ptr=kp, c_ptr=dq_p, prec=lp)
+             sa=sBH_sq, sb=sBH_qkv, sc=sBH_qkv, b_ptr=kp, c_ptr=dq_p, prec=lp, pad4=True)
     du, dvb, dpos = _zeros_split(dev, dt, (H, dh), (H, dh), (P, d))
     colsum(dqkv, rows=N, cols=d, ld=d3, out=du)
     # dQv_bh = dposfull_hb . Pm_h          (contraction over the 2T-1 relative positions)
     dqv = torch.empty(N, d, device=dev, dtype=dt)
     gemm_bwd(dpf, False, pos, True, T, dh, P, out=dqv, lda=P4, ldb=ldp, ldc=d, nbatch=nb, nb1=H,
-             sa=sBH_pf, sb=(0, dh), sc=sBH_rows, prec=lp)
+             sa=sBH_pf, sb=(0, dh), sc=sBH_rows, prec=lp, pad4=True)
     colsum(dqv, out=dvb)
     _lib.check(lib.cfm_add_strided_f32(dq_p, d3, dqv.data_ptr(), d, N, d, _stream()), "cfm_add_strided_f32")
     # dPm_h = sum_{b,i} dposfull_h[(b,i), :]^T . Qv_h[(b,i), :]     (contraction over B*T rows, split + atomics)
     gemm_bwd(dpf, True, qv, True, P, dh, N, out=dpos, lda=P4, ldb=d, ldc=d, allow_split=True, nbatch=H, nb1=H,
-             sa=(0, B * T * P4), sb=(0, dh), sc=(0, dh), prec=lp)
+             sa=(0, B * T * P4), sb=(0, dh), sc=(0, dh), prec=lp, pad4=True)
     return dqkv, dpos, du, dvb
 
 

@@ -149,7 +149,10 @@ int cfm_gemm_bwd_batched_mfma16_f32(int prec, const float* A, int a_col, int64_t
                                     int b_is_16bit, int64_t ldb, const float* Z_or_null, int64_t ldz, float alpha, float* C,
                                     int64_t ldc, int I, int J, int64_t Kc, int allow_split, int accumulate,
                                     int nbatch, int nb1, int64_t sa0, int64_t sa1, int64_t sb0, int64_t sb1,
-                                    int64_t sc0, int64_t sc1, float drop_p, uint64_t drop_seed, cfm_stream_t stream);
+                                    int64_t sc0, int64_t sc1, float drop_p, uint64_t drop_seed,
+                                    int operands_zero_padded4, cfm_stream_t stream);
+/*      operands_zero_padded4: ragged Kc (index-major operands) / I, J (contraction-major operands) are physically padded
+ *      to a multiple of 4 elements with zeros, so partial 16-byte chunks may be loaded whole (the fast load path). */
 int cfm_subsample_conv2_bwd_weight_mfma16_f32(int prec, const float* dz2, const float* h1, float* dw2p, int B, int F1,
                                               int T1, int C, cfm_stream_t stream);
 int cfm_subsample_conv2_bwd_input_mfma16_f32(int prec, const float* dz2, const float* w2c, float* dh1, int B, int F1,
