@@ -261,3 +261,19 @@ class SwishBatchNormFn(Function):
         h, weight, mean, var = ctx.saved_tensors
         dh, dga, dbe = ops.swish_bn_bwd(h, dz.contiguous(), mean, var, weight, ctx.eps, ctx.train_bn)
         return dh, dga, dbe, None, None, None, None, None
+
+
+class CtcLossFn(Function):
+    """ConformerCriterion.ctc_loss (evaluation.py:12-16): mean-reduced zero_infinity CTC of log_softmax(logits), logits
+    (B,T,V) batch-first fp32.  Forward: log-sum-exp + alpha lattice; backward: beta lattice + the logits gradient
+    (softmax - occupancy), csrc/ctc.hip.  The log-softmax / transpose tensors of the reference are never formed."""
+
+    @staticmethod
+    def forward(ctx, logits, targets, input_lengths, target_lengths, blank):
+        loss, state = ops.ctc_loss_forward(logits, targets, input_lengths, target_lengths, blank)
+        ctx.state = state
+        return loss
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        return ops.ctc_loss_backward(ctx.state, grad_out.float().contiguous()), None, None, None, None

@@ -745,3 +745,62 @@ def swish_bn_bwd(h, dz, bn_mean, bn_var, bn_weight, eps: float = 1e-5, train_sta
                                                 bn_weight.data_ptr(), eps, int(train_stats), dh.data_ptr(), dga.data_ptr(),
                                                 dbe.data_ptr(), h.numel() // C, C, _stream()), "cfm_swish_bn_bwd_f32")
     return dh, dga, dbe
+
+
+# ---- N1 loss: CTC over the logits (log-softmax folded in), evaluation.py:12-16 ------------------------------------------------
+CTC_MAX_TARGET = 1023            # CFM_CTC_MAX_TARGET
+
+
+def _ctc_geometry(logits, targets, input_lengths, target_lengths):
+    logits = _req(logits, "logits")
+    if logits.dim() != 3:
+        raise _lib.ConformerHipError(f"ctc_loss: logits must be (B,T,V), got {tuple(logits.shape)}")
+    B = logits.shape[0]
+    targets = _req(targets.to(logits.device), "targets", torch.int64)
+    in_len = _req(torch.as_tensor(input_lengths).to(logits.device), "input_lengths", torch.int64)
+    tg_len = _req(torch.as_tensor(target_lengths).to(logits.device), "target_lengths", torch.int64)
+    if in_len.numel() != B or tg_len.numel() != B:
+        raise _lib.ConformerHipError("ctc_loss: input_lengths / target_lengths must hold one entry per utterance")
+    if targets.dim() == 2:
+        if targets.shape[0] != B:
+            raise _lib.ConformerHipError("ctc_loss: 2-D targets must be (B, max_target_length)")
+        off, stride, lmax = None, targets.shape[1], targets.shape[1]
+    elif targets.dim() == 1:                              # concatenated targets: one host read for the lattice width
+        off = (torch.cumsum(tg_len, 0) - tg_len).contiguous()
+        stride, lmax = 0, int(tg_len.max())
+    else:
+        raise _lib.ConformerHipError("ctc_loss: targets must be 1-D (concatenated) or 2-D (padded)")
+    lmax = max(lmax, 1)
+    if lmax > CTC_MAX_TARGET:
+        raise NotImplementedError(f"ctc_loss: targets longer than {CTC_MAX_TARGET} labels are not built")
+    return logits, targets, off, stride, in_len, tg_len, lmax
+
+
+def ctc_loss_forward(logits, targets, input_lengths, target_lengths, blank: int = 0):
+    """mean-reduced, zero_infinity CTC loss of log_softmax(logits) -- logits (B,T,V) fp32 batch-first.  Returns
+    (loss (scalar tensor), ctx) where ctx carries the lattice workspace for ctc_loss_backward."""
+    logits, targets, off, stride, in_len, tg_len, lmax = _ctc_geometry(logits, targets, input_lengths, target_lengths)
+    B, T, V = logits.shape
+    lib = _lib.load()
+    ws = torch.empty(int(lib.cfm_ctc_workspace_floats(B, T, lmax)), device=logits.device, dtype=torch.float32)
+    loss = torch.empty((), device=logits.device, dtype=torch.float32)
+    _lib.check(lib.cfm_ctc_loss_fwd_f32(logits.data_ptr(), targets.data_ptr(), _p(off), stride, targets.numel(),
+                                        in_len.data_ptr(), tg_len.data_ptr(), B, T, V, lmax, int(blank), ws.data_ptr(),
+                                        loss.data_ptr(), _stream()), "cfm_ctc_loss_fwd_f32")
+    return loss, (logits, targets, off, stride, in_len, tg_len, lmax, int(blank), ws)
+
+
+def ctc_loss_backward(ctx, grad_out):
+    logits, targets, off, stride, in_len, tg_len, lmax, blank, ws = ctx
+    B, T, V = logits.shape
+    g = _req(grad_out.reshape(1), "grad_out")
+    dlogits = torch.empty_like(logits)
+    _lib.check(_lib.load().cfm_ctc_loss_bwd_f32(logits.data_ptr(), targets.data_ptr(), _p(off), stride, targets.numel(),
+                                                in_len.data_ptr(), tg_len.data_ptr(), B, T, V, lmax, blank, ws.data_ptr(),
+                                                g.data_ptr(), dlogits.data_ptr(), _stream()), "cfm_ctc_loss_bwd_f32")
+    return dlogits
+
+
+def ctc_nll(ctx) -> torch.Tensor:
+    """Per-utterance negative log-likelihood (B,) left in the workspace by ctc_loss_forward (inf = no valid alignment)."""
+    return ctx[-1][-ctx[0].shape[0]:]

@@ -319,6 +319,24 @@ int cfm_swish_bn_bwd_f32(const float* h, const float* dz, const float* bn_mean, 
                          const float* bn_weight, float eps, int train_stats, float* dh, float* dgamma, float* dbeta,
                          int64_t rows, int C, cfm_stream_t stream);
 
+/* N1, loss half: ConformerCriterion.ctc_loss (evaluation.py:12-16) = nn.CTCLoss(blank, reduction='mean',
+ *      zero_infinity=True) over log_softmax(logits), the log-softmax folded in.  logits (B,T,V) fp32 (batch-first, as
+ *      the model returns them: the transpose of evaluation.py:16 is index arithmetic); targets int64, label i of
+ *      utterance b at targets[off_b + i], off_b = tgt_off_or_null ? tgt_off[b] : b*tgt_stride (2-D padded or 1-D
+ *      concatenated targets), tgt_numel = elements in `targets`; in_len / tgt_len int64 (B) on the device (clamped to
+ *      T / Lmax); Lmax <= CFM_CTC_MAX_TARGET bounds every tgt_len.  workspace: cfm_ctc_workspace_floats(B,T,Lmax)
+ *      floats, written by fwd and consumed by bwd (same arguments).  loss: 1 float.  bwd: dlogits (B,T,V) =
+ *      grad_out[0] * d loss / d logits (frames >= in_len and utterances with infinite loss get zeros). */
+#define CFM_CTC_MAX_TARGET 1023
+int64_t cfm_ctc_workspace_floats(int B, int T, int Lmax);
+int cfm_ctc_loss_fwd_f32(const float* logits, const int64_t* targets, const int64_t* tgt_off_or_null,
+                         int64_t tgt_stride, int64_t tgt_numel, const int64_t* in_len, const int64_t* tgt_len,
+                         int B, int T, int V, int Lmax, int blank, float* workspace, float* loss, cfm_stream_t stream);
+int cfm_ctc_loss_bwd_f32(const float* logits, const int64_t* targets, const int64_t* tgt_off_or_null,
+                         int64_t tgt_stride, int64_t tgt_numel, const int64_t* in_len, const int64_t* tgt_len,
+                         int B, int T, int V, int Lmax, int blank, float* workspace, const float* grad_out,
+                         float* dlogits, cfm_stream_t stream);
+
 /* diagnostics only: cfm_relpos_attention_fwd_f32 + s_memrealtime stamps of one wave (trace: 16*ceil(T/32) uint64) */
 int cfm_debug_attention_trace_f32(const float* q, const float* k, const float* v, int64_t ld, const float* pos,
                                   int64_t ldp, const float* u, const float* vbias, const int64_t* lengths_or_null,

@@ -250,6 +250,76 @@ def ctc_loss(logits: torch.Tensor, targets: torch.Tensor, in_len: torch.Tensor, 
     return F.ctc_loss(lp, targets, in_len, tgt_len, blank=blank, zero_infinity=True)
 
 
+def ctc_lattice(logits: torch.Tensor, targets: torch.Tensor, in_len, tgt_len, blank: int = 0):
+    """The same loss written out (Graves et al. 2006 forward-backward over the blank-extended label sequence, which is
+    what nn.CTCLoss of evaluation.py:10 computes), float64: returns (loss, nll (B,), dloss/dlogits (B,T,V)) with
+    reduction='mean' (mean over utterances of nll / max(target_length, 1)) and zero_infinity=True.  Pinned against
+    F.ctc_loss and its autograd in tests/test_oracle_golden.py."""
+    import numpy as np
+    x = logits.detach().double().cpu().numpy()
+    B, T, V = x.shape
+    tg = targets.detach().cpu().numpy().astype(np.int64)
+    il = [int(v) for v in torch.as_tensor(in_len).tolist()]
+    tl = [int(v) for v in torch.as_tensor(tgt_len).tolist()]
+    offs = np.cumsum([0] + tl[:-1]) if tg.ndim == 1 else None
+    mx = x.max(-1, keepdims=True)
+    lp = x - (mx + np.log(np.exp(x - mx).sum(-1, keepdims=True)))
+    nll = np.zeros(B)
+    grad = np.zeros_like(x)
+
+    def lse(*a):
+        m = np.maximum.reduce(a)
+        ms = np.where(np.isfinite(m), m, 0.0)
+        with np.errstate(divide="ignore"):
+            return np.where(np.isfinite(m), ms + np.log(sum(np.exp(v - ms) for v in a)), -np.inf)
+
+    for b in range(B):
+        Tb, L = il[b], tl[b]
+        lab = tg[b, :L] if tg.ndim == 2 else tg[offs[b]:offs[b] + L]
+        ext = np.full(2 * L + 1, blank, dtype=np.int64)
+        ext[1::2] = lab
+        S = ext.size
+        if Tb == 0:
+            nll[b] = 0.0 if L == 0 else np.inf
+            continue
+        hop = np.zeros(S, dtype=bool)                  # state s reachable from s-2
+        hop[2:] = (ext[2:] != blank) & (ext[2:] != ext[:-2])
+        em = lp[b, :Tb][:, ext]                        # (Tb, S)
+        al = np.full((Tb, S), -np.inf)
+        al[0, 0] = em[0, 0]
+        if S > 1:
+            al[0, 1] = em[0, 1]
+        ninf1, ninf2 = np.array([-np.inf]), np.array([-np.inf, -np.inf])
+        for t in range(1, Tb):
+            p = al[t - 1]
+            s1 = np.concatenate([ninf1, p[:-1]])
+            s2 = np.where(hop, np.concatenate([ninf2, p[:-2]])[:S], -np.inf)
+            al[t] = lse(p, s1, s2) + em[t]
+        be = np.full((Tb, S), -np.inf)
+        be[Tb - 1, S - 1] = em[Tb - 1, S - 1]
+        if S > 1:
+            be[Tb - 1, S - 2] = em[Tb - 1, S - 2]
+        hop_f = np.zeros(S, dtype=bool)                # state s may go to s+2
+        hop_f[:-2] = hop[2:]
+        for t in range(Tb - 2, -1, -1):
+            n = be[t + 1]
+            s1 = np.concatenate([n[1:], ninf1])
+            s2 = np.where(hop_f, np.concatenate([n[2:], ninf2])[:S], -np.inf)
+            be[t] = lse(n, s1, s2) + em[t]
+        ll = lse(al[Tb - 1, S - 1:S], al[Tb - 1, S - 2:S - 1] if S > 1 else ninf1)[0]
+        nll[b] = -ll
+        if not np.isfinite(ll):
+            continue
+        occ = np.exp(al + be - ll - em)                # posterior state occupancy (Tb, S)
+        g = np.exp(lp[b, :Tb])                         # softmax
+        for s in range(S):
+            g[:, ext[s]] -= occ[:, s]
+        grad[b, :Tb] = g / (B * max(L, 1))
+    fin = np.isfinite(nll)
+    loss = float(np.sum(np.where(fin, nll, 0.0) / np.maximum(np.array(tl), 1)) / B)
+    return loss, torch.from_numpy(nll), torch.from_numpy(grad)
+
+
 def greedy_indices(logits: torch.Tensor) -> torch.Tensor:
     """Per-frame argmax of processor.py:302-303 (the 'CTC alignment indices')."""
     return logits.argmax(-1)

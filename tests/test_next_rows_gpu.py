@@ -252,3 +252,91 @@ def test_training_trajectory_fused_adam_equals_torch_adam(dev, amp):
     assert runs["torch"][4] < runs["torch"][0]                             # it trains
     for a, b in zip(runs["torch"], runs["fused"]):
         assert abs(a - b) < tol * abs(a), (runs["torch"], runs["fused"])
+
+
+# ---- N1 loss: CTC lattice kernels vs the written-out float64 lattice (itself pinned against F.ctc_loss on the CPU) ----------
+def _ctc_inputs(B, T, V, L, in_len, tgt_len, seed, scale=2.0):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, T, V, generator=g) * scale
+    tg = torch.randint(1, V, (B, L), generator=g)
+    tg[0, :min(4, L)] = torch.tensor([2, 2, 2, 3])[:min(4, L)]          # repeated labels in every case
+    return x, tg, torch.tensor(in_len), torch.tensor(tgt_len)
+
+
+CTC_GPU_CASES = {
+    "cfg1": (2, 49, 370, 12, [49, 40], [12, 9]),
+    "ragged_empty_target": (3, 20, 11, 6, [20, 7, 20], [6, 6, 0]),
+    "infeasible": (2, 8, 7, 4, [8, 3], [4, 4]),
+    "one_frame": (2, 1, 9, 1, [1, 1], [1, 0]),
+    "zero_frames": (2, 6, 9, 2, [0, 6], [2, 2]),
+    "two_pairs_per_lane": (2, 260, 40, 100, [260, 150], [100, 64]),
+    "eight_pairs_per_lane": (2, 700, 30, 300, [700, 650], [300, 257]),
+    "sixteen_pairs_per_lane": (1, 1400, 30, 600, [1400], [600]),
+}
+
+
+@pytest.mark.parametrize("name", list(CTC_GPU_CASES))
+def test_ctc_loss_matches_lattice_oracle(dev, name):
+    from conformer_amd.evaluation import ConformerCriterion
+    B, T, V, L, il, tl = CTC_GPU_CASES[name]
+    x, tg, ilt, tlt = _ctc_inputs(B, T, V, L, il, tl, seed=3)
+    loss_o, nll_o, grad_o = O.ctc_lattice(x, tg, ilt, tlt)
+    xd = x.to(dev).requires_grad_()
+    crit = ConformerCriterion(blank_id=0)
+    loss = crit.ctc_loss(xd, tg.float().to(dev), ilt.to(dev), tlt.to(dev))     # float targets, as evaluation.py:14
+    (loss * 3.0).backward()
+    err = rel_l2(xd.grad, 3.0 * grad_o) if grad_o.abs().sum() > 0 else float(xd.grad.abs().max())
+    print(f"ctc[{name}]: loss {float(loss):.6f} vs {loss_o:.6f}, grad rel-L2 {err:.2e}")
+    assert abs(float(loss) - loss_o) <= 1e-5 * max(1.0, abs(loss_o))
+    assert err < 1e-4                # re-centred fp32 lattice: independent of the utterance length (1e-3 is the bar)
+    assert torch.isfinite(xd.grad).all()
+    # frames beyond an utterance's length and utterances without a valid alignment get exactly zero gradient
+    for b in range(B):
+        assert not xd.grad[b, il[b]:].any()
+        if not torch.isfinite(nll_o[b]):
+            assert not xd.grad[b].any()
+    # 1-D concatenated targets give the same numbers
+    cat = torch.cat([tg[b, :tl[b]] for b in range(B)])
+    if cat.numel():
+        x2 = x.to(dev).requires_grad_()
+        loss2 = crit.ctc_loss(x2, cat.to(dev), ilt.to(dev), tlt.to(dev))
+        loss2.backward()
+        assert float(loss2) == float(loss)
+        assert torch.equal(x2.grad * 3.0, xd.grad) or rel_l2(x2.grad * 3.0, xd.grad) < 1e-6
+
+
+def test_ctc_loss_training_geometry_matches_torch(dev):
+    """cfg-3 geometry (B=64, T'=249, V=370, 40 labels): against the lattice oracle AND torch's own CTC on the same device."""
+    from conformer_amd.evaluation import ConformerCriterion
+    B, T, V, L = 64, 249, 370, 40
+    il = sorted([249 - 3 * (i % 40) for i in range(B)], reverse=True)
+    tl = [40 - (i % 7) for i in range(B)]
+    x, tg, ilt, tlt = _ctc_inputs(B, T, V, L, il, tl, seed=5, scale=1.0)
+    loss_o, _, grad_o = O.ctc_lattice(x, tg, ilt, tlt)
+    xd = x.to(dev).requires_grad_()
+    loss = ConformerCriterion(0).ctc_loss(xd, tg.to(dev), ilt.to(dev), tlt.to(dev))
+    loss.backward()
+    assert abs(float(loss) - loss_o) <= 1e-5 * abs(loss_o)
+    assert rel_l2(xd.grad, grad_o) < 1e-4
+    xt = x.to(dev).requires_grad_()
+    lt = torch.nn.functional.ctc_loss(xt.log_softmax(-1).transpose(0, 1), tg.to(dev), ilt.to(dev), tlt.to(dev), blank=0,
+                                      zero_infinity=True)
+    lt.backward()
+    assert abs(float(loss) - float(lt)) <= 1e-5 * abs(float(lt))
+    assert rel_l2(xd.grad, xt.grad) < 1e-3      # torch's un-centred fp32 lattice is the looser side (2e-4 from the oracle)
+
+
+def test_ctc_loss_rejects_cpu_and_long_targets(dev):
+    from conformer_amd.evaluation import ConformerCriterion
+    crit = ConformerCriterion(0)
+    with pytest.raises(RuntimeError):
+        crit.ctc_loss(torch.randn(1, 4, 5), torch.ones(1, 2), torch.tensor([4]), torch.tensor([2]))
+    with pytest.raises(NotImplementedError):
+        crit.ctc_loss(torch.randn(1, 4, 5, device=dev), torch.ones(1, 1024, device=dev), torch.tensor([4]), torch.tensor([2]))
+
+
+def test_error_rates_follow_torchmetrics_definition():
+    from conformer_amd.evaluation import ConformerMetric
+    m = ConformerMetric()
+    assert abs(float(m.wer_score(["a b c", "d e"], ["a x c", "d e f"])) - 2 / 6) < 1e-7      # 1 sub + 1 del over 6 words
+    assert abs(float(m.cer_score("kitten", "sitting")) - 3 / 7) < 1e-7

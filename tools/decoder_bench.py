@@ -61,6 +61,36 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         res[name] = {"wall_ms": (time.perf_counter() - t0) / 5 * 1e3, "device_ms": e0.elapsed_time(e1) / 5}
+    # CTC loss on the logits (evaluation.py:12-16): lattice kernels vs torch's log_softmax + ctc_loss on the same device
+    from conformer_amd.evaluation import ConformerCriterion
+    crit = ConformerCriterion(0)
+    logits = torch.randn(B, 249, 370, device=dev)
+    tg = torch.randint(1, 370, (B, 40), device=dev)
+    tl = torch.full((B,), 40, dtype=torch.int64, device=dev)
+    def ctc_hip():
+        lg = logits.detach().requires_grad_(True)
+        crit.ctc_loss(lg, tg, L, tl).backward()
+        return lg.grad
+    def ctc_torch():
+        lg = logits.detach().requires_grad_(True)
+        torch.nn.functional.ctc_loss(lg.log_softmax(-1).transpose(0, 1), tg, L, tl, blank=0, zero_infinity=True).backward()
+        return lg.grad
+    for name, fn in (("ctc_hip_fwd_bwd", ctc_hip), ("ctc_torch_fwd_bwd", ctc_torch)):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        e0.record()
+        for _ in range(10):
+            g = fn()
+        e1.record()
+        torch.cuda.synchronize()
+        res[name] = {"wall_ms": (time.perf_counter() - t0) / 10 * 1e3, "device_ms": e0.elapsed_time(e1) / 10}
+        res[name + "_g"] = g
+    res["ctc_grad_rel_l2_vs_torch"] = float((res["ctc_hip_fwd_bwd_g"] - res["ctc_torch_fwd_bwd_g"]).norm() /
+                                            res.pop("ctc_torch_fwd_bwd_g").norm())
+    res.pop("ctc_hip_fwd_bwd_g")
     print(json.dumps({"what": f"decoder forward B={B} T'=249 512->640->370, eval", **res, "max_abs_diff": err}))
 
 

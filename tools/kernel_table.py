@@ -83,6 +83,11 @@ def main():
     adam = FusedAdam(params, lr=1e-5)
     logits = R(B, T, 370)
     from conformer_amd.decode import greedy_ctc_decode
+    ctc_tg = torch.randint(1, 370, (B, 40), device=dev)
+    ctc_il = torch.full((B,), T, dtype=torch.int64, device=dev)
+    ctc_tl = torch.full((B,), 40, dtype=torch.int64, device=dev)
+    ctc_state = ops.ctc_loss_forward(logits, ctc_tg, ctc_il, ctc_tl, 0)[1]
+    ctc_g = torch.ones((), device=dev)
 
     def specaug():
         _lib.check(lib.cfm_specaugment_apply_f32(mel.data_ptr(), B, 80, 1000, bands.data_ptr(), 3, 0.0, ops._stream()), "specaug")
@@ -107,6 +112,9 @@ def main():
         ("SpecAugment apply (3 bands)", specaug, 0, 0),
         ("fused Adam (16 x 1M params)", lambda: adam.step(), 16 * 2048 * 512 * 7 * f, 0),
         ("greedy CTC decode (B,T',370)", lambda: greedy_ctc_decode(logits, 0, 1), B * T * 370 * f, 0),
+        ("CTC loss fwd: lse + alpha lattice (40 labels)", lambda: ops.ctc_loss_forward(logits, ctc_tg, ctc_il, ctc_tl, 0),
+         B * T * 370 * f, 0),
+        ("CTC loss bwd: beta lattice + logits grad", lambda: ops.ctc_loss_backward(ctc_state, ctc_g), 2 * B * T * 370 * f, 0),
     ]
     # layernorm bwd dx: x, dy, dres read + dx written
     rows[2] = (rows[2][0], rows[2][1], 4 * N * d * f, 0)

@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--frames", type=int, default=1000)
     ap.add_argument("--optim", choices=["torch", "fused"], default="fused")
+    ap.add_argument("--ctc", choices=["hip", "torch"], default="hip", help="CTC loss: gfx950 lattice kernels or torch.nn.CTCLoss")
     ap.add_argument("--dtype", choices=["f32", "bf16", "f16"], default="f32",
                     help="bf16/f16: model under torch.autocast (f16 with GradScaler), as train.py:217,232-243")
     args = ap.parse_args()
@@ -49,7 +50,9 @@ def main():
     lengths = torch.full((args.batch,), args.frames, dtype=torch.int64, device=dev)
     targets = torch.randint(1, 370, (args.batch, 40), generator=g).to(dev)
     tlen = torch.full((args.batch,), 40, dtype=torch.int64, device=dev)
-    crit = torch.nn.CTCLoss(blank=0, zero_infinity=True)
+    from conformer_amd.evaluation import ConformerCriterion
+    crit = ConformerCriterion(blank_id=0)
+    torch_ctc = torch.nn.CTCLoss(blank=0, zero_infinity=True)
     last = {}
 
     amp_dtype = {"f32": None, "bf16": torch.bfloat16, "f16": torch.float16}[args.dtype]
@@ -58,7 +61,10 @@ def main():
     def step():
         with torch.autocast("cuda", dtype=amp_dtype, enabled=amp_dtype is not None):
             logits, out_len = ddp(x, lengths)
-        loss = crit(logits.float().log_softmax(-1).transpose(0, 1), targets, out_len, tlen)
+        if args.ctc == "hip":
+            loss = crit.ctc_loss(logits, targets, out_len, tlen)
+        else:
+            loss = torch_ctc(logits.float().log_softmax(-1).transpose(0, 1), targets, out_len, tlen)
         opt.zero_grad(set_to_none=True)
         scaler.scale(loss).backward()
         scaler.unscale_(opt)
@@ -77,7 +83,7 @@ def main():
     if env.is_main:
         ms = dt / args.steps * 1e3
         print(json.dumps({"what": "Conformer-L training step fwd+CTC+bwd+Adam, dropout 0, BN train", "dtype": args.dtype,
-                          "optimizer": args.optim, "n_gpus": env.world, "per_gpu_batch": args.batch, "mel_frames": args.frames,
+                          "optimizer": args.optim, "ctc": args.ctc, "n_gpus": env.world, "per_gpu_batch": args.batch, "mel_frames": args.frames,
                           "ms_per_step": ms, "host_issue_ms_per_step": host_ms, "frames_per_sec": env.world * args.batch * args.frames * args.steps / dt,
                           "loss": float(last["loss"]), "max_mem_gib": torch.cuda.max_memory_allocated() / 2 ** 30}),
               flush=True)
