@@ -7,6 +7,7 @@ the reference's own code path reach on this MI355X" -- the number the gfx950 pat
 sources travelling to the GPU box.  Random weights, synthetic input, eval, no_grad.
 
     python tools/stock_torch_encoder.py [--dtype f32|bf16] [--batch 32] [--frames 1000] [--steps 5]
+    python tools/stock_torch_encoder.py --train --dtype bf16 --batch 64     # + nn.LSTM decoder, CTC, backward, Adam (cfg-3)
 """
 import argparse
 import json
@@ -72,16 +73,16 @@ def self_attention(x, pos, pad_mask, p, heads, ubias, vbias):
     return F.linear(ctx, p["wo"], p["bo"])
 
 
-def conv_module(x, p, ksize):
+def conv_module(x, p, ksize, train=False):
     h = F.layer_norm(x, x.shape[-1:], p["lnw"], p["lnb"]).transpose(1, 2)
     h = F.glu(F.conv1d(h, p["pw1"], p["pb1"]), dim=1)
     h = F.conv1d(h, p["dw"], p["db"], padding=(ksize - 1) // 2, groups=h.shape[1])
-    h = F.batch_norm(h, p["bnm"], p["bnv"], p["bnw"], p["bnb"], training=False)
+    h = F.batch_norm(h, p["bnm"], p["bnv"], p["bnw"], p["bnb"], training=train)
     h = h * torch.sigmoid(h)
     return F.conv1d(h, p["pw2"], p["pb2"]).transpose(1, 2)
 
 
-def encoder(x, lengths, W, heads, ksize, ubias, vbias):
+def encoder(x, lengths, W, heads, ksize, ubias, vbias, train=False):
     h = F.relu(F.conv2d(x.unsqueeze(1), W["c1w"], W["c1b"], stride=2))
     h = F.relu(F.conv2d(h, W["c2w"], W["c2b"], stride=2))
     b, c, f, t = h.shape
@@ -97,14 +98,70 @@ def encoder(x, lengths, W, heads, ksize, ubias, vbias):
     for lay in W["layers"]:
         h = h + 0.5 * feed_forward(h, lay["f1"])
         h = h + self_attention(h, pos, pad_mask, lay["att"], heads, ubias, vbias)
-        h = h + conv_module(h, lay["conv"], ksize)
+        h = h + conv_module(h, lay["conv"], ksize, train)
         h = h + 0.5 * feed_forward(h, lay["f2"])
         h = F.layer_norm(h, (d,), lay["lnw"], lay["lnb"])
     return h, out_len
 
 
+def leaves(obj):
+    if isinstance(obj, torch.Tensor):
+        yield obj
+    elif isinstance(obj, dict):
+        for v in obj.values():
+            yield from leaves(v)
+    elif isinstance(obj, list):
+        for v in obj:
+            yield from leaves(v)
+
+
+def train_bench(args, dev, W, ubias, vbias, x, lengths, heads, ksize):
+    """Full step as train.py:225-243 runs it: forward under autocast, CTC on fp32 log-softmax, backward, Adam."""
+    d, hidden, vocab = 512, 640, 370
+    lstm = torch.nn.LSTM(d, hidden, 1, batch_first=True).to(dev)
+    bn = torch.nn.BatchNorm1d(hidden).to(dev)
+    out = torch.nn.Linear(hidden, vocab).to(dev)
+    buffers = {id(t) for lay in W["layers"] for t in (lay["conv"]["bnm"], lay["conv"]["bnv"])}
+    params = [t.requires_grad_() for t in leaves(W) if id(t) not in buffers] + [ubias.requires_grad_(), vbias.requires_grad_()]
+    params += list(lstm.parameters()) + list(bn.parameters()) + list(out.parameters())
+    opt = torch.optim.Adam(params, lr=2e-5)
+    targets = torch.randint(1, vocab, (args.batch, 40), device=dev)
+    tlen = torch.full((args.batch,), 40, dtype=torch.int64, device=dev)
+    ctc = torch.nn.CTCLoss(blank=0, zero_infinity=True)
+    amp = torch.bfloat16 if args.dtype == "bf16" else None
+
+    def step():
+        with torch.autocast("cuda", dtype=amp, enabled=amp is not None):
+            h, out_len = encoder(x, lengths, W, heads, ksize, ubias, vbias, train=True)
+            pk = torch.nn.utils.rnn.pack_padded_sequence(h, out_len.cpu(), batch_first=True, enforce_sorted=True)
+            y, _ = torch.nn.utils.rnn.pad_packed_sequence(lstm(pk)[0], batch_first=True)
+            y = y * torch.sigmoid(y)
+            y = bn(y.transpose(1, 2)).transpose(1, 2)
+            logits = out(y)
+        loss = ctc(logits.float().log_softmax(-1).transpose(0, 1), targets, out_len, tlen)
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+        return loss
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / args.steps * 1e3
+    print(json.dumps({"what": "training step (fwd + CTC + bwd + Adam) with stock PyTorch-ROCm operators (yard-stick)",
+                      "dtype": args.dtype, "batch": args.batch, "mel_frames": args.frames, "ms_per_step": ms,
+                      "frames_per_sec": args.batch * args.frames / (ms / 1e3), "loss": float(loss),
+                      "params": sum(p.numel() for p in params), "torch": torch.__version__,
+                      "max_mem_gib": torch.cuda.max_memory_allocated() / 2 ** 30}))
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--train", action="store_true")
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32")
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--frames", type=int, default=1000)
@@ -119,6 +176,9 @@ def main():
     vbias = (torch.randn(heads, d // heads, generator=g) * 0.1).to(dev)
     x = torch.randn(args.batch, 80, args.frames, generator=g).to(dev)
     lengths = torch.full((args.batch,), args.frames, dtype=torch.int64, device=dev)
+
+    if args.train:
+        return train_bench(args, dev, W, ubias, vbias, x, lengths, heads, ksize)
 
     def step():
         with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16, enabled=args.dtype == "bf16"):
