@@ -173,9 +173,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch the ~260 kernels eagerly instead of one hipGraph replay")
-    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
-                    help="f32 = the headline configuration (BASELINE cfg-2); bf16 = torch.autocast(bfloat16): dense GEMMs on "
-                         "the bf16 matrix pipe with fp32 accumulate and fp32 tensors (secondary result, never the default)")
+    ap.add_argument("--dtype", choices=["f32", "bf16", "f32x6", "f32x3"], default="f32",
+                    help="f32 = the headline configuration (BASELINE cfg-2, native fp32 MFMA); bf16 = torch.autocast(bfloat16): "
+                         "dense GEMMs on the bf16 matrix pipe with fp32 accumulate and fp32 tensors; f32x6 / f32x3 = fp32 GEMMs "
+                         "computed from exact bf16 expansions of the fp32 operands (ops.set_fp32_matmul: six / three bf16 "
+                         "MFMAs per K-step, fp32-class / 2^-15 error).  All but f32 are secondary results, never the default")
     args = ap.parse_args()
 
     from conformer_amd import parallel
@@ -192,9 +194,11 @@ def main():
     if args.gpus != world and rank == 0:
         log(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; reporting n_gpus={world}")
 
-    from conformer_amd import _lib
+    from conformer_amd import _lib, ops
     _lib.check(_lib.load().cfm_device_check(), "cfm_device_check")
     from model.modules.encoder import Encoder
+    if args.dtype in ("f32x6", "f32x3"):
+        ops.set_fp32_matmul("bf16x6" if args.dtype == "f32x6" else "bf16x3")
 
     torch.manual_seed(0)
     enc = Encoder(CFG["n_mel"], CFG["n_blocks"], CFG["d"], CFG["n_heads"], CFG["ksize"], 0.0).to(dev).eval()
@@ -209,7 +213,7 @@ def main():
     log(f"[bench] rank {rank}/{world}: model on {dev}, warm-up {args.warmup} steps")
     last = {}
     runner, graphed = enc, False
-    if not args.no_graph and args.dtype == "f32":
+    if not args.no_graph and args.dtype != "bf16":
         try:
             from conformer_amd.graph import GraphedEncoder
             runner, graphed = GraphedEncoder(enc, x, lengths), True
@@ -236,7 +240,10 @@ def main():
         "metric": "encoder audio-frames/sec (B=32,T=1000,d=512,L=16)",
         "value": frames / dt, "unit": "audio-frames/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32" if args.dtype == "f32" else "bf16 MFMA operands, f32 accumulate/storage (autocast)", "data": "synthetic", "launch": "hipGraph replay" if graphed else "eager",
+        "dtype": {"f32": "f32", "bf16": "bf16 MFMA operands, f32 accumulate/storage (autocast)",
+                  "f32x6": "f32 operands split exactly into 3 bf16 terms, 6 bf16 MFMAs per K-step, f32 accumulate/storage",
+                  "f32x3": "f32 operands split into 2 bf16 terms, 3 bf16 MFMAs per K-step, f32 accumulate/storage"}[args.dtype],
+        "data": "synthetic", "launch": "hipGraph replay" if graphed else "eager",
         "config": {"workload": "cfg2 Conformer-L Encoder.forward: B=32/GPU, T=1000 mel frames (T'=249), d=512, 16 blocks, "
                                "8 heads, k=31, fp32, eval, random-init weights, batch-sharded replicas",
                    "per_gpu_batch": CFG["B"], "mel_frames": CFG["T"]},

@@ -98,6 +98,62 @@ def weight16(w: torch.Tensor, prec: int) -> Optional[torch.Tensor]:
     return out
 
 
+# ---- opt-in fp32 matmul mode: exact bf16 operand splitting on the 16x faster bf16 matrix pipe (csrc/gemm_split.hip) -----------
+_FP32_MATMUL = {"native": 0, "bf16x6": 3, "bf16x3": 2}       # value = bf16 planes per operand
+_fp32_planes = _FP32_MATMUL[__import__("os").environ.get("CONFORMER_AMD_FP32_MATMUL", "native")]
+
+
+def set_fp32_matmul(mode: str) -> str:
+    """How the forward computes its fp32 GEMMs outside autocast (the plain / GLU / residual linear layers and the stem's
+    conv2; GEMMs with fused dropout or saved pre-activations and every backward GEMM stay "native"):
+      "native"  v_mfma_f32_32x32x2_f32 (default);
+      "bf16x6"  every fp32 operand split exactly into three bf16 terms, six bf16 MFMAs per K-step: fp32 inputs, fp32
+                accumulation, fp32 outputs, per-product error <= 2^-23 (fp32 class), 0.375x the matrix-pipe time;
+      "bf16x3"  two terms, three MFMAs: error <= 2^-15 (60x inside the 1e-3 parity bar).
+    Returns the previous mode.  Also settable with CONFORMER_AMD_FP32_MATMUL."""
+    global _fp32_planes
+    if mode not in _FP32_MATMUL:
+        raise ValueError(f"fp32 matmul mode must be one of {sorted(_FP32_MATMUL)}, got {mode!r}")
+    prev = fp32_matmul()
+    _fp32_planes = _FP32_MATMUL[mode]
+    return prev
+
+
+def fp32_matmul() -> str:
+    return {v: k for k, v in _FP32_MATMUL.items()}[_fp32_planes]
+
+
+_WSPLIT_CACHE = {}     # data_ptr -> (weakref(base), version, planes, shape, [planes][N][K] bf16)
+def weight_split(w: torch.Tensor, planes: int) -> Optional[torch.Tensor]:
+    """Exact bf16 expansion of a weight matrix, cached like weight16.  None when the split path does not apply."""
+    if w.shape[-1] % 8 or w.numel() % 4:
+        return None
+    key = w.data_ptr()
+    base = w._base if w._base is not None else w
+    hit = _WSPLIT_CACHE.get(key)
+    if hit is not None and hit[0]() is base and hit[1] == w._version and hit[2] == planes and hit[3] == w.shape:
+        return hit[4]
+    out = torch.empty((planes,) + tuple(w.shape), device=w.device, dtype=torch.bfloat16)
+    _lib.check(_lib.load().cfm_split_bf16_f32(planes, w.data_ptr(), out.data_ptr(), w.numel(), _stream()), "cfm_split_bf16_f32")
+    if len(_WSPLIT_CACHE) > 4096:
+        for k in [k for k, v in _WSPLIT_CACHE.items() if v[0]() is None]:
+            del _WSPLIT_CACHE[k]
+    _WSPLIT_CACHE[key] = (weakref.ref(base), w._version, planes, w.shape, out)
+    return out
+
+
+def _split_gemm(epi: int, a, w2, b, c, m, n, k, res=None, alpha: float = 1.0):
+    """Returns c, or None when the split path does not apply to this call (the caller then runs the native kernel)."""
+    if not _fp32_planes or a.dtype != torch.float32 or c.dtype != torch.float32:
+        return None
+    ws = weight_split(w2, _fp32_planes)
+    if ws is None:
+        return None
+    _lib.check(_lib.load().cfm_gemm_split_bf16_f32(_fp32_planes, epi, a.data_ptr(), ws.data_ptr(), b.data_ptr(), _p(res), alpha,
+                                                   c.data_ptr(), m, n, k, k, n, n, _stream()), "cfm_gemm_split_bf16_f32")
+    return c
+
+
 def out16_ok(k: int) -> int:
     """Precision in which a producer may write a tensor that only feeds GEMM operands with contraction length k (0: keep fp32)."""
     prec = mfma16_prec()
@@ -161,6 +217,8 @@ def linear(a, w, b, act: str = "none", for_gemm: bool = False) -> torch.Tensor:
     c = torch.empty(*a.shape[:-1], n, device=a.device, dtype=_DT16[p16] if p16 else torch.float32)
     if prec:
         return _mfma16_gemm(prec, {"none": 0, "swish": 1, "relu": 2}[act], a, w2, b, c, m, n, k)
+    if _split_gemm({"none": 0, "swish": 1, "relu": 2}[act], a, w2, b, c, m, n, k) is not None:
+        return c
     fn = {"none": "cfm_gemm_bias_f32", "swish": "cfm_gemm_bias_swish_f32", "relu": "cfm_gemm_bias_relu_f32"}[act]
     st = getattr(_lib.load(), fn)(a.data_ptr(), w2.data_ptr(), b.data_ptr(), c.data_ptr(), m, n, k, k, n, _stream())
     _lib.check(st, fn)
@@ -175,6 +233,8 @@ def linear_glu(a, w, b) -> torch.Tensor:
     prec = mfma16_prec()
     if prec:
         return _mfma16_gemm(prec, 3, a, w2, b, c, m, n, k)
+    if _split_gemm(3, a, w2, b, c, m, n, k) is not None:
+        return c
     st = _lib.load().cfm_gemm_bias_glu_f32(a.data_ptr(), w2.data_ptr(), b.data_ptr(), c.data_ptr(), m, n, k, k, n,
                                            _stream())
     _lib.check(st, "cfm_gemm_bias_glu_f32")
@@ -189,6 +249,8 @@ def linear_residual(a, w, b, res: torch.Tensor, alpha: float = 1.0) -> torch.Ten
     prec = mfma16_prec()
     if prec:
         return _mfma16_gemm(prec, 4, a, w2, b, c, m, n, k, res, alpha)
+    if _split_gemm(4, a, w2, b, c, m, n, k, res, alpha) is not None:
+        return c
     st = _lib.load().cfm_gemm_bias_residual_f32(a.data_ptr(), w2.data_ptr(), b.data_ptr(), res.data_ptr(), alpha,
                                                 c.data_ptr(), m, n, k, k, n, n, _stream())
     _lib.check(st, "cfm_gemm_bias_residual_f32")
@@ -294,6 +356,11 @@ def _conv2_relu(lib, h1, w2p, b2, h2, B, F1, T1, C):
                                                            (w2p if w16 is None else w16).data_ptr(), int(w16 is not None),
                                                            b2.data_ptr(), h2.data_ptr(), int(h2.dtype != torch.float32), B, F1,
                                                            T1, C, _stream()), "cfm_subsample_conv2_relu_mfma16_f32")
+    elif _fp32_planes and C % 64 == 0:
+        ws = weight_split(w2p, _fp32_planes)
+        _lib.check(lib.cfm_subsample_conv2_relu_split_bf16_f32(_fp32_planes, h1.data_ptr(), ws.data_ptr(), b2.data_ptr(),
+                                                               h2.data_ptr(), B, F1, T1, C, _stream()),
+                   "cfm_subsample_conv2_relu_split_bf16_f32")
     else:
         _lib.check(lib.cfm_subsample_conv2_relu_f32(h1.data_ptr(), w2p.data_ptr(), b2.data_ptr(), h2.data_ptr(), B, F1, T1,
                                                     C, _stream()), "cfm_subsample_conv2_relu_f32")

@@ -319,6 +319,19 @@ int cfm_swish_bn_bwd_f32(const float* h, const float* dz, const float* bn_mean, 
                          const float* bn_weight, float eps, int train_stats, float* dh, float* dgamma, float* dbeta,
                          int64_t rows, int C, cfm_stream_t stream);
 
+/* ---- opt-in: fp32 GEMMs on the bf16 matrix pipe by exact operand splitting (csrc/gemm_split.hip).  Same contract as the
+ *      fp32 entries above (fp32 A, bias, R, C; fp32 accumulation): every fp32 operand is expanded into `planes` bf16 terms
+ *      (x = x0 + x1 + x2 exactly for planes = 3) and the products of total order < planes are accumulated -- planes = 3:
+ *      six bf16 MFMAs per K-step, per-product relative error <= 2^-23 (fp32 class); planes = 2: three, <= 2^-15.
+ *      W_split = [planes][N][K] bf16 made by cfm_split_bf16_f32 from the (N,K) fp32 weight (epi 3: N = 2*n_out rows).
+ *      K % 8 == 0.  epi as cfm_gemm_mfma16_f32. */
+int cfm_split_bf16_f32(int planes, const float* src, void* dst, int64_t n, cfm_stream_t stream);
+int cfm_gemm_split_bf16_f32(int planes, int epi, const float* A, const void* W_split, const float* bias,
+                            const float* R_or_null, float alpha, float* C, int64_t M, int N, int K, int64_t lda,
+                            int64_t ldr, int64_t ldc, cfm_stream_t stream);
+int cfm_subsample_conv2_relu_split_bf16_f32(int planes, const float* h1, const void* w2p_split, const float* b2, float* h2,
+                                            int B, int F1, int T1, int C, cfm_stream_t stream);
+
 /* N1, loss half: ConformerCriterion.ctc_loss (evaluation.py:12-16) = nn.CTCLoss(blank, reduction='mean',
  *      zero_infinity=True) over log_softmax(logits), the log-softmax folded in.  logits (B,T,V) fp32 (batch-first, as
  *      the model returns them: the transpose of evaluation.py:16 is index arithmetic); targets int64, label i of
