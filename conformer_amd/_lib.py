@@ -70,7 +70,8 @@ SIGNATURES = {
     "cfm_swish_bn_eval_f32": (c_int, [_P, _P, _P, _P, _P, _F, _P, _L, _I, _P]),
     "cfm_swish_bn_stats_f32": (c_int, [_P, _P, _P, _P, _P, _F, _L, _I, _P]),
     "cfm_swish_bn_bwd_f32": (c_int, [_P, _P, _P, _P, _P, _F, _I, _P, _P, _P, _L, _I, _P]),
-    "cfm_split_bf16_f32": (c_int, [_I, _P, _P, _L, _P]),
+    "cfm_split_pack_elems": (ctypes.c_int64, [_I, _I, _I]),
+    "cfm_split_pack_bf16_f32": (c_int, [_I, _P, _P, _I, _I, _P]),
     "cfm_gemm_split_bf16_f32": (c_int, [_I, _I, _P, _P, _P, _P, _F, _P, _L, _I, _I, _L, _L, _L, _P]),
     "cfm_subsample_conv2_relu_split_bf16_f32": (c_int, [_I, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "cfm_ctc_workspace_floats": (ctypes.c_int64, [_I, _I, _I]),

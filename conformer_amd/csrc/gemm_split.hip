@@ -12,13 +12,14 @@
 // against the float64 oracle, side by side with the native fp32 kernel).  `planes` = 2 keeps x0 + x1 (three products,
 // relative error <= 2^-15: the "3x" mode, still 60x inside the 1e-3 parity bar).
 //
-// Weights are split once per parameter version into bf16 planes [planes][N][K] (cfm_split_bf16_f32, cached by the
-// host side like the 16-bit weight copies); activations are split on their way into LDS.  Block tile 128x128 / 128x64
-// / 64x64, K-tile 32, 4 waves (2x2), LDS rows of 80 B (conflict-free ds_read_b128), single LDS stage with the next
-// tile's global loads in flight across the MFMAs, two workgroups per CU; shared 16-byte epilogue (gemm_shared.h).
-// (A two-stage K-tile-16 pipeline with the staging interleaved between the MFMAs measured 5-15 % slower: one barrier per
-// 24 MFMAs and 32/64-byte global segments cost more than the overlap gains; the kernel is bound by LDS traffic -- 144 KB
-// per 48 MFMAs per wave quartet, ~75 % of the CU's 128 B/clk when the matrix pipe is saturated.)
+// Weights are split once per parameter version (cfm_split_pack_bf16_f32, cached by the host side like the 16-bit weight
+// copies) and stored in MFMA fragment order, so they stream from L2 straight into registers; activations are split on
+// their way into LDS.  Block tile 128x128 / 128x64 / 64x64, K-tile 32, 4 waves (2x2), two workgroups per CU; shared
+// 16-byte epilogue (gemm_shared.h).
+// Measured on the FFN GEMM (7968 x 2048 x 512, 115 us against 160 us native in the same harness): the six MFMAs alone
+// take 51 us (1.95 PFLOP/s, 78 % of the nominal bf16 peak -- the practical ceiling of the pipe), ~36 us are fixed
+// (65 MB epilogue, ramp, barriers), ~30 us are operand staging that is not yet hidden behind the MFMAs.  Three loop
+// structures (both operands through one LDS stage; K-tile 16 with two stages; this one) land within 5 % of each other.
 #include "gemm_shared.h"
 
 namespace {
@@ -28,16 +29,21 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ f32x4 widen(const bf16x4 h) { return f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]}; }
 
+// Weight operand: pre-split AND pre-shuffled into MFMA fragment order by cfm_split_pack_bf16_f32 --
+//     [row block of 32][K-step of 16][plane][lane = 32*hf + li][8 bf16]   (row = 32*block + li, k = 16*step + 8*hf + e)
+// so the fragment one wave feeds one MFMA is ONE fully coalesced 1 KB load straight into registers: the weights never
+// touch LDS (half of the kernel's LDS traffic and LDS footprint gone), consecutive K-steps of a row block are contiguous.
+// Activation operand: fp32 rows -> registers -> split chain -> LDS planes (two stages), read back as 16-byte fragments.
+// Per K-tile (32 = two MFMA K-steps) and wave: 2*TM*NPL ds_read_b128, 2*TN*NPL 1 KB global loads (issued one K-tile
+// ahead), 2*TM*TN*terms MFMAs with the staging of the next activation tile sliced in between; one barrier.
 template <int BM, int BN, int EPI, bool CONV, int NPL>
 __global__ __launch_bounds__(256, 2) void gemm_split_kernel(const GemmArgs g) {
     constexpr int TM = BM / 64, TN = BN / 64, BK = 32;
     constexpr int ROWB = 40;                                  // LDS row in bf16 elements: 32 + 8 pad = 80 B
     constexpr int NA = BM / 32;                               // float4 loads per thread per K-tile (8 lanes per row)
-    constexpr int NBH = BN / 64;                              // 16-byte plane loads per thread per K-tile and plane (4 lanes per row)
+    constexpr int STAGE = NPL * BM * ROWB;                    // [NPL][BM][ROWB]
     static_assert(EPI != EPI_GLU || TN == 2, "GLU keeps value and gate tiles in one wave");
-    __shared__ __attribute__((aligned(16))) __bf16 lds[NPL * (BM + BN) * ROWB];
-    __bf16* As = lds;                          // [NPL][BM][ROWB]
-    __bf16* Bs = lds + NPL * BM * ROWB;        // [NPL][BN][ROWB]
+    __shared__ __attribute__((aligned(16))) __bf16 lds[2 * STAGE];
 
     const unsigned nwg = g.tiles_m * g.tiles_n;
     const unsigned tile = xcd_remap(blockIdx.x, nwg);
@@ -50,51 +56,52 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(const GemmArgs g) {
     const int li = lane & 31, hf = lane >> 5;
 
     const int srow = tid >> 3, sch = tid & 7;                 // A: fp32, 8 lanes x 16 B = the 128 B of one tile row
-    const int hrow = tid >> 2, hch = tid & 3;                 // W planes: bf16, 4 lanes x 16 B = the 64 B of one tile row
     const float* a_ptr[NA];
-    const __bf16* w_ptr[NBH];
 #pragma unroll
     for (int p = 0; p < NA; ++p) a_ptr[p] = a_row_ptr<CONV>(g, m0 + srow + 32 * p);
-#pragma unroll
-    for (int p = 0; p < NBH; ++p)
-        w_ptr[p] = reinterpret_cast<const __bf16*>(g.W) + (int64_t)w_row_index<EPI, BN>(g, n0, hrow + 64 * p) * g.K;
-    const int64_t plane = (int64_t)g.N * g.K;                 // elements between two planes of the split weight
 
-    // unconditional clamped loads; chunks beyond K are zeroed when they are staged (`kvalid*`)
-    f32x4 ra[NA];
-    bf16x8 rb[NPL][NBH];
-    bool kvalid = true, kvalid_h = true;
-    auto load_tile = [&](int kt) {
-        const int k = kt * BK + sch * 4, kh = kt * BK + hch * 8;       // K % 8 == 0
-        kvalid = k < g.K; kvalid_h = kh < g.K;
-        const int kc = max(min(k, g.K - 4), 0), khc = max(min(kh, g.K - 8), 0);
+    // this wave's weight row blocks (32 rows each) in the packed buffer
+    const int ksteps = g.K / 16;                              // K % 16 == 0
+    const int nblocks = (g.N + 31) / 32;
+    const __bf16* w_blk[TN];
+#pragma unroll
+    for (int t = 0; t < TN; ++t) {
+        int row;
+        if (EPI == EPI_GLU) row = n0 + wc * 32 + (t == 0 ? 0 : g.n_out);       // tile 0 = value rows, tile 1 = gate rows
+        else row = n0 + wc * (BN / 2) + 32 * t;
+        const int blk = min(row / 32, nblocks - 1);                            // beyond N: clamped, never stored
+        w_blk[t] = reinterpret_cast<const __bf16*>(g.W) + ((int64_t)blk * ksteps * NPL * 64 + lane) * 8;
+    }
+
+    // Global loads run far ahead of their use (an iteration of 8*TM*TN*.. MFMAs is shorter than the memory latency):
+    // weights: a ring of four K-step slots -- the slot a K-step has just consumed is refilled with the K-step four ahead
+    // (two K-tiles); activations: two register sets, loaded two K-tiles ahead, split into LDS one K-tile ahead.
+    struct WFrag { bf16x8 f[2][TN][NPL]; };                   // the two K-steps of one K-tile
+    auto load_w_step = [&](int kt, int s, WFrag& w) {
+        const int ks = min(kt * 2 + s, ksteps - 1);           // a K-step beyond K meets zeroed activations
+#pragma unroll
+        for (int t = 0; t < TN; ++t)
+#pragma unroll
+            for (int pl = 0; pl < NPL; ++pl)
+                w.f[s][t][pl] = *reinterpret_cast<const bf16x8*>(w_blk[t] + ((int64_t)ks * NPL + pl) * 512);
+    };
+    struct ARegs { f32x4 v[NA]; bool valid; };
+    auto load_a = [&](int kt, ARegs& r) {
+        const int k = kt * BK + sch * 4;
+        r.valid = k < g.K;
+        const int kc = max(min(k, g.K - 4), 0);
         const int64_t aoff = a_k_offset<CONV>(g, kc - sch * 4) + sch * 4;
 #pragma unroll
-        for (int p = 0; p < NA; ++p) ra[p] = *reinterpret_cast<const f32x4*>(a_ptr[p] + aoff);
-#pragma unroll
-        for (int pl = 0; pl < NPL; ++pl)
-#pragma unroll
-            for (int p = 0; p < NBH; ++p) rb[pl][p] = *reinterpret_cast<const bf16x8*>(w_ptr[p] + pl * plane + khc);
+        for (int p = 0; p < NA; ++p) r.v[p] = *reinterpret_cast<const f32x4*>(a_ptr[p] + aoff);
     };
-    auto store_tile = [&]() {
-        bf16x8 z8;
+    auto store_a = [&](const ARegs& r, int p, __bf16* stage) {
+        f32x4 v = r.valid ? r.v[p] : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int e = 0; e < 8; ++e) z8[e] = (__bf16)0.f;
-#pragma unroll
-        for (int p = 0; p < NA; ++p) {
-            f32x4 r = kvalid ? ra[p] : f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int pl = 0; pl < NPL; ++pl) {
-                const bf16x4 h = Lowp<__bf16>::cvt4(r);                                   // RNE: |r - h| <= 2^-9 |r|
-                *reinterpret_cast<bf16x4*>(As + (pl * BM + srow + 32 * p) * ROWB + sch * 4) = h;
-                if (pl + 1 < NPL) r = r - widen(h);                                       // exact
-            }
+        for (int pl = 0; pl < NPL; ++pl) {
+            const bf16x4 h = Lowp<__bf16>::cvt4(v);                                       // RNE: |v - h| <= 2^-9 |v|
+            *reinterpret_cast<bf16x4*>(stage + (pl * BM + srow + 32 * p) * ROWB + sch * 4) = h;
+            if (pl + 1 < NPL) v = v - widen(h);                                           // exact
         }
-#pragma unroll
-        for (int pl = 0; pl < NPL; ++pl)
-#pragma unroll
-            for (int p = 0; p < NBH; ++p)
-                *reinterpret_cast<bf16x8*>(Bs + (pl * BN + hrow + 64 * p) * ROWB + hch * 8) = kvalid_h ? rb[pl][p] : z8;
     };
 
     f32x16 acc[TM][TN];
@@ -105,42 +112,62 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(const GemmArgs g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int a_row = wr * (BM / 2) + li, b_row = wc * (BN / 2) + li;
+    const int a_row = wr * (BM / 2) + li;
     const int nkt = (g.K + BK - 1) / BK;
-    load_tile(0);
-    for (int kt = 0; kt < nkt; ++kt) {
-        store_tile();
-        __syncthreads();
-        if (kt + 1 < nkt) load_tile(kt + 1);
-        __builtin_amdgcn_sched_barrier(0);                    // the loads stay in flight across this tile's MFMAs
+
+    // K-tile kt: activations in LDS `cur`, weights in `w` (refilled with tile kt+2 as its K-steps retire); splits tile kt+1
+    // (held in `a_next`) into `other`; loads the activations of tile kt+2 into `a_free`
+    auto iteration = [&](int kt, const __bf16* cur, __bf16* other, WFrag& w, const ARegs& a_next, ARegs& a_free) {
+        const bool more = kt + 1 < nkt;
+        if (kt + 2 < nkt) load_a(kt + 2, a_free);
+        __builtin_amdgcn_sched_barrier(0);
+        int unit = 0;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            bf16x8 fa[TM][NPL], fb[TN][NPL];
+            bf16x8 fa[TM][NPL];
 #pragma unroll
-            for (int pl = 0; pl < NPL; ++pl) {
+            for (int pl = 0; pl < NPL; ++pl)
 #pragma unroll
                 for (int t = 0; t < TM; ++t)
-                    fa[t][pl] = *reinterpret_cast<const bf16x8*>(As + (pl * BM + a_row + 32 * t) * ROWB + 16 * s + 8 * hf);
+                    fa[t][pl] = *reinterpret_cast<const bf16x8*>(cur + (pl * BM + a_row + 32 * t) * ROWB + 16 * s + 8 * hf);
+            // term-major order: consecutive MFMAs hit different accumulators; smallest terms first; every product is exact
 #pragma unroll
-                for (int t = 0; t < TN; ++t)
-                    fb[t][pl] = *reinterpret_cast<const bf16x8*>(Bs + (pl * BN + b_row + 32 * t) * ROWB + 16 * s + 8 * hf);
-            }
+            for (int order = NPL - 1; order >= 0; --order)
 #pragma unroll
-            for (int mt = 0; mt < TM; ++mt)
+                for (int i = 0; i <= order; ++i) {
 #pragma unroll
-                for (int nt = 0; nt < TN; ++nt) {
-                    f32x16 c = acc[mt][nt];
-                    // smallest terms first; every product is exact, the sums are fp32
+                    for (int mt = 0; mt < TM; ++mt)
 #pragma unroll
-                    for (int order = NPL - 1; order >= 0; --order)
+                        for (int nt = 0; nt < TN; ++nt)
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.f[s][nt][order - i], fa[mt][i], acc[mt][nt],
+                                                                                  0, 0, 0);
+                    // slices of the next tile's staging in the shadow of these MFMAs (NA slices over the term groups)
+                    constexpr int SLOTS = 2 * (NPL * (NPL + 1) / 2);
+                    if (more) {
 #pragma unroll
-                        for (int i = 0; i <= order; ++i)
-                            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[nt][order - i], fa[mt][i], c, 0, 0, 0);
-                    acc[mt][nt] = c;
+                        for (int p = 0; p < NA; ++p)
+                            if (p * SLOTS / NA == unit) store_a(a_next, p, other);
+                    }
+                    ++unit;
+                    __builtin_amdgcn_sched_barrier(0);
                 }
+            if (kt + 2 < nkt) load_w_step(kt + 2, s, w);       // this K-step's slot is free again
+            __builtin_amdgcn_sched_barrier(0);
         }
-        __builtin_amdgcn_sched_barrier(0);
         __syncthreads();
+    };
+
+    WFrag w0, w1;
+    ARegs a0, a1;
+    load_a(0, a0);
+    load_w_step(0, 0, w0); load_w_step(0, 1, w0);
+    if (nkt > 1) { load_a(1, a1); load_w_step(1, 0, w1); load_w_step(1, 1, w1); }
+#pragma unroll
+    for (int p = 0; p < NA; ++p) store_a(a0, p, lds);
+    __syncthreads();
+    for (int kt = 0; kt < nkt; kt += 2) {
+        iteration(kt, lds, lds + STAGE, w0, a1, a0);
+        if (kt + 1 < nkt) iteration(kt + 1, lds + STAGE, lds, w1, a0, a1);
     }
     gemm_epilogue<BM, BN, EPI, TM, TN>(g, acc, m0, n0, wr, wc, li, hf);
 }
@@ -171,35 +198,49 @@ int launch(const GemmArgs& g, int planes, hipStream_t s) {
     }
 }
 
-// dst[pl][i] = pl-th bf16 term of src[i] (RNE residual chain), pl < planes
-__global__ __launch_bounds__(256) void split_bf16_kernel(const float* __restrict__ src, __bf16* __restrict__ dst, int64_t n4,
+// packed[block][kstep][plane][lane][8]: the exact bf16 expansion of W (N,K) in MFMA fragment order (rows >= N: zeros)
+__global__ __launch_bounds__(256) void split_pack_kernel(const float* __restrict__ w, __bf16* __restrict__ dst, int N, int K,
                                                          int planes) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n4) return;
-    f32x4 r = reinterpret_cast<const f32x4*>(src)[i];
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;      // one 8-element fragment slot per thread
+    const int ksteps = K / 16;
+    const int64_t slots = (int64_t)((N + 31) / 32) * ksteps * 64;
+    if (i >= slots) return;
+    const int lane = (int)(i & 63);
+    const int64_t bk = i >> 6;
+    const int ks = (int)(bk % ksteps), blk = (int)(bk / ksteps);
+    const int row = blk * 32 + (lane & 31), k = ks * 16 + (lane >> 5) * 8;
+    f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = lo;
+    if (row < N) {
+        lo = *reinterpret_cast<const f32x4*>(w + (int64_t)row * K + k);
+        hi = *reinterpret_cast<const f32x4*>(w + (int64_t)row * K + k + 4);
+    }
     for (int pl = 0; pl < planes; ++pl) {
-        const bf16x4 h = Lowp<__bf16>::cvt4(r);
-        *reinterpret_cast<bf16x4*>(dst + (int64_t)pl * n4 * 4 + 4 * i) = h;
-        r = r - widen(h);
+        const bf16x4 a = Lowp<__bf16>::cvt4(lo), b = Lowp<__bf16>::cvt4(hi);
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { o[e] = a[e]; o[4 + e] = b[e]; }
+        *reinterpret_cast<bf16x8*>(dst + ((bk * planes + pl) * 64 + lane) * 8) = o;
+        lo = lo - widen(a); hi = hi - widen(b);
     }
 }
 
 }  // namespace
 
-// planes: 3 (six products, fp32-level error) or 2 (three products, 2^-15).  W_split: [planes][N][K] bf16 from
-// cfm_split_bf16_f32 (for epi 3 / GLU: N = 2*n_out rows).  Everything else as cfm_gemm_mfma16_f32 with fp32 A and C.
+// planes: 3 (six products, fp32-level error) or 2 (three products, 2^-15).  W_split: the packed expansion made by
+// cfm_split_pack_bf16_f32 from the (N,K) weight (for epi 3 / GLU: all 2*n_out rows, n_out % 32 == 0).  K % 16 == 0.  Everything else as cfm_gemm_mfma16_f32 with fp32 A and C.
 extern "C" int cfm_gemm_split_bf16_f32(int planes, int epi, const float* A, const void* W_split, const float* bias,
                                        const float* R_or_null, float alpha, float* C, int64_t M, int N, int K, int64_t lda,
                                        int64_t ldr, int64_t ldc, cfm_stream_t stream) {
     CFM_REQUIRE(A && W_split && bias && C, CFM_ERR_NULL);
     CFM_REQUIRE(planes == 2 || planes == 3, CFM_ERR_UNSUPPORTED);
-    CFM_REQUIRE(M > 0 && N > 0 && K > 0 && (K & 7) == 0 && (lda & 3) == 0 && lda >= K && ldc >= N, CFM_ERR_BAD_SHAPE);
+    CFM_REQUIRE(M > 0 && N > 0 && K > 0 && (K & 15) == 0 && (lda & 3) == 0 && lda >= K && ldc >= N, CFM_ERR_BAD_SHAPE);
     CFM_REQUIRE(CFM_ALIGNED16(A) && CFM_ALIGNED16(W_split), CFM_ERR_ALIGN);
     GemmArgs g{};
     g.A = A; g.W = static_cast<const float*>(W_split); g.bias = bias; g.R = R_or_null; g.C = C; g.M = M; g.K = K;
     g.lda = lda; g.ldr = ldr; g.ldc = ldc; g.alpha = alpha;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (epi == EPI_GLU) {
+        CFM_REQUIRE((N & 31) == 0, CFM_ERR_BAD_SHAPE);
         g.n_out = N; g.N = 2 * N;
         return launch<EPI_GLU, false>(g, planes, s);
     }
@@ -216,7 +257,7 @@ extern "C" int cfm_gemm_split_bf16_f32(int planes, int epi, const float* A, cons
     }
 }
 
-// split-operand form of cfm_subsample_conv2_relu_f32 (C % 64 == 0); w2p_split: [planes][C][9C] bf16 of the packed weight
+// split-operand form of cfm_subsample_conv2_relu_f32 (C % 64 == 0); w2p_split: cfm_split_pack_bf16_f32 of the (C, 9C) packed conv weight
 extern "C" int cfm_subsample_conv2_relu_split_bf16_f32(int planes, const float* h1, const void* w2p_split, const float* b2,
                                                        float* h2, int B, int F1, int T1, int C, cfm_stream_t stream) {
     CFM_REQUIRE(h1 && w2p_split && b2 && h2, CFM_ERR_NULL);
@@ -231,13 +272,20 @@ extern "C" int cfm_subsample_conv2_relu_split_bf16_f32(int planes, const float* 
     return launch<EPI_RELU, true>(g, planes, static_cast<hipStream_t>(stream));
 }
 
-// dst [planes][n] bf16 <- the exact bf16 expansion of src (n % 4 == 0)
-extern "C" int cfm_split_bf16_f32(int planes, const float* src, void* dst, int64_t n, cfm_stream_t stream) {
-    CFM_REQUIRE(src && dst, CFM_ERR_NULL);
+// dst <- the exact bf16 expansion of the (N,K) fp32 weight in MFMA fragment order: cfm_split_pack_elems(planes,N,K) bf16
+// elements.  K % 16 == 0.
+extern "C" int64_t cfm_split_pack_elems(int planes, int N, int K) {
+    if ((planes != 2 && planes != 3) || N <= 0 || K <= 0 || (K & 15)) return -1;
+    return (int64_t)planes * ((N + 31) / 32) * 32 * K;
+}
+
+extern "C" int cfm_split_pack_bf16_f32(int planes, const float* w, void* dst, int N, int K, cfm_stream_t stream) {
+    CFM_REQUIRE(w && dst, CFM_ERR_NULL);
     CFM_REQUIRE(planes == 2 || planes == 3, CFM_ERR_UNSUPPORTED);
-    CFM_REQUIRE(n > 0 && (n & 3) == 0, CFM_ERR_BAD_SHAPE);
-    CFM_REQUIRE(CFM_ALIGNED16(src) && (reinterpret_cast<uintptr_t>(dst) & 7) == 0, CFM_ERR_ALIGN);
-    hipLaunchKernelGGL(split_bf16_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
-                       src, static_cast<__bf16*>(dst), n / 4, planes);
+    CFM_REQUIRE(N > 0 && K > 0 && (K & 15) == 0, CFM_ERR_BAD_SHAPE);
+    CFM_REQUIRE(CFM_ALIGNED16(w) && CFM_ALIGNED16(dst), CFM_ERR_ALIGN);
+    const int64_t slots = (int64_t)((N + 31) / 32) * (K / 16) * 64;
+    hipLaunchKernelGGL(split_pack_kernel, dim3((unsigned)((slots + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       w, static_cast<__bf16*>(dst), N, K, planes);
     return cfm_launch_status();
 }

@@ -125,28 +125,38 @@ def fp32_matmul() -> str:
 
 _WSPLIT_CACHE = {}     # data_ptr -> (weakref(base), version, planes, shape, [planes][N][K] bf16)
 def weight_split(w: torch.Tensor, planes: int) -> Optional[torch.Tensor]:
-    """Exact bf16 expansion of a weight matrix, cached like weight16.  None when the split path does not apply."""
-    if w.shape[-1] % 8 or w.numel() % 4:
+    """Exact bf16 expansion of a (N,K) weight matrix in MFMA fragment order ([row block of 32][K-step of 16][plane][lane][8]),
+    cached like weight16.  None when the split path does not apply (K % 16 != 0)."""
+    if w.dim() != 2 or w.shape[1] % 16:
         return None
     key = w.data_ptr()
     base = w._base if w._base is not None else w
     hit = _WSPLIT_CACHE.get(key)
     if hit is not None and hit[0]() is base and hit[1] == w._version and hit[2] == planes and hit[3] == w.shape:
         return hit[4]
-    out = torch.empty((planes,) + tuple(w.shape), device=w.device, dtype=torch.bfloat16)
-    _lib.check(_lib.load().cfm_split_bf16_f32(planes, w.data_ptr(), out.data_ptr(), w.numel(), _stream()), "cfm_split_bf16_f32")
+    lib = _lib.load()
+    n, k = w.shape
+    out = torch.empty(int(lib.cfm_split_pack_elems(planes, n, k)), device=w.device, dtype=torch.bfloat16)
+    _lib.check(lib.cfm_split_pack_bf16_f32(planes, w.data_ptr(), out.data_ptr(), n, k, _stream()), "cfm_split_pack_bf16_f32")
     if len(_WSPLIT_CACHE) > 4096:
-        for k in [k for k, v in _WSPLIT_CACHE.items() if v[0]() is None]:
-            del _WSPLIT_CACHE[k]
+        for kk in [kk for kk, v in _WSPLIT_CACHE.items() if v[0]() is None]:
+            del _WSPLIT_CACHE[kk]
     _WSPLIT_CACHE[key] = (weakref.ref(base), w._version, planes, w.shape, out)
     return out
+
+
+def unpack_weight_split(packed: torch.Tensor, planes: int, n: int, k: int) -> torch.Tensor:
+    """(planes, n, k) bf16 view of weight_split's buffer in natural order (tests / inspection)."""
+    nb, ks = (n + 31) // 32, k // 16
+    p = packed.view(nb, ks, planes, 2, 32, 8)                      # [block][kstep][plane][hf][li][e]
+    return p.permute(2, 0, 4, 1, 3, 5).reshape(planes, nb * 32, k)[:, :n]
 
 
 def _split_gemm(epi: int, a, w2, b, c, m, n, k, res=None, alpha: float = 1.0):
     """Returns c, or None when the split path does not apply to this call (the caller then runs the native kernel)."""
     if not _fp32_planes or a.dtype != torch.float32 or c.dtype != torch.float32:
         return None
-    ws = weight_split(w2, _fp32_planes)
+    ws = weight_split(w2, _fp32_planes) if (epi != 3 or n % 32 == 0) else None
     if ws is None:
         return None
     _lib.check(_lib.load().cfm_gemm_split_bf16_f32(_fp32_planes, epi, a.data_ptr(), ws.data_ptr(), b.data_ptr(), _p(res), alpha,
@@ -357,7 +367,7 @@ def _conv2_relu(lib, h1, w2p, b2, h2, B, F1, T1, C):
                                                            b2.data_ptr(), h2.data_ptr(), int(h2.dtype != torch.float32), B, F1,
                                                            T1, C, _stream()), "cfm_subsample_conv2_relu_mfma16_f32")
     elif _fp32_planes and C % 64 == 0:
-        ws = weight_split(w2p, _fp32_planes)
+        ws = weight_split(w2p.view(C, 9 * C), _fp32_planes)
         _lib.check(lib.cfm_subsample_conv2_relu_split_bf16_f32(_fp32_planes, h1.data_ptr(), ws.data_ptr(), b2.data_ptr(),
                                                                h2.data_ptr(), B, F1, T1, C, _stream()),
                    "cfm_subsample_conv2_relu_split_bf16_f32")

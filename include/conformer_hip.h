@@ -323,9 +323,11 @@ int cfm_swish_bn_bwd_f32(const float* h, const float* dz, const float* bn_mean, 
  *      fp32 entries above (fp32 A, bias, R, C; fp32 accumulation): every fp32 operand is expanded into `planes` bf16 terms
  *      (x = x0 + x1 + x2 exactly for planes = 3) and the products of total order < planes are accumulated -- planes = 3:
  *      six bf16 MFMAs per K-step, per-product relative error <= 2^-23 (fp32 class); planes = 2: three, <= 2^-15.
- *      W_split = [planes][N][K] bf16 made by cfm_split_bf16_f32 from the (N,K) fp32 weight (epi 3: N = 2*n_out rows).
- *      K % 8 == 0.  epi as cfm_gemm_mfma16_f32. */
-int cfm_split_bf16_f32(int planes, const float* src, void* dst, int64_t n, cfm_stream_t stream);
+ *      W_split: the expansion of the (N,K) fp32 weight in MFMA fragment order ([row block of 32][K-step of 16][plane]
+ *      [lane][8 bf16]; cfm_split_pack_elems bf16 elements), made once per weight version by cfm_split_pack_bf16_f32
+ *      (epi 3: all 2*n_out rows, n_out % 32 == 0).  K % 16 == 0.  epi as cfm_gemm_mfma16_f32. */
+int64_t cfm_split_pack_elems(int planes, int N, int K);
+int cfm_split_pack_bf16_f32(int planes, const float* w, void* dst, int N, int K, cfm_stream_t stream);
 int cfm_gemm_split_bf16_f32(int planes, int epi, const float* A, const void* W_split, const float* bias,
                             const float* R_or_null, float alpha, float* C, int64_t M, int N, int K, int64_t lda,
                             int64_t ldr, int64_t ldc, cfm_stream_t stream);

@@ -39,16 +39,21 @@ def test_split_planes_reconstruct_fp32_exactly(dev):
     g = torch.Generator().manual_seed(1)
     w = (torch.randn(64, 128, generator=g) * torch.exp2(torch.randint(-60, 60, (64, 128), generator=g).float())).to(dev)
     w[0, :4] = torch.tensor([0.0, -0.0, 1.0, 3.0e38])                 # (|x| >= 3.39e38 rounds to bf16 inf, as under autocast)
-    planes = ops.weight_split(w, 3)
+    packed = ops.weight_split(w, 3)
+    planes = ops.unpack_weight_split(packed, 3, 64, 128)
     assert planes.shape == (3, 64, 128) and planes.dtype == torch.bfloat16
     bad = (planes.double().sum(0) != w.double()).sum()
     assert int(bad) == 0, f"{int(bad)} of {w.numel()} values are not reproduced exactly"   # x0 + x1 + x2 == x
-    assert ops.weight_split(w, 3) is planes                            # cached
+    assert ops.weight_split(w, 3) is packed                            # cached
     w.add_(1.0)
-    assert ops.weight_split(w, 3) is not planes                        # invalidated by the version bump
+    assert ops.weight_split(w, 3) is not packed                        # invalidated by the version bump
+    w40 = torch.randn(40, 48, device=dev)                              # rows beyond N in the last block are zero
+    p40 = ops.weight_split(w40, 2)
+    assert p40.numel() == 2 * 64 * 48
+    assert torch.equal(ops.unpack_weight_split(p40, 2, 40, 48).float().sum(0), w40.bfloat16().float() + (w40 - w40.bfloat16().float()).bfloat16().float())
 
 
-@pytest.mark.parametrize("shape", [(7968, 2048, 512), (7968, 512, 2048), (300, 520, 72), (129, 64, 40), (5, 8, 8)])
+@pytest.mark.parametrize("shape", [(7968, 2048, 512), (7968, 512, 2048), (300, 520, 80), (129, 72, 48), (5, 8, 16)])
 @pytest.mark.parametrize("mode,bound", [("bf16x6", 1.0), ("bf16x3", 300.0)])
 def test_split_gemm_error_vs_native_fp32(dev, shape, mode, bound):
     from conformer_amd import ops
