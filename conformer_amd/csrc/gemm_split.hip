@@ -16,7 +16,7 @@
 // copies) and stored in MFMA fragment order, so they stream from L2 straight into registers; activations are split on
 // their way into LDS.  Block tile 128x128 / 128x64 / 64x64, K-tile 32, 4 waves (2x2), two workgroups per CU; shared
 // 16-byte epilogue (gemm_shared.h).
-// Measured on the FFN GEMM (7968 x 2048 x 512, 115 us against 160 us native in the same harness): the six MFMAs alone
+// Measured on the FFN GEMM (7968 x 2048 x 512, 112 us against 160 us native in the same harness): the six MFMAs alone
 // take 51 us (1.95 PFLOP/s, 78 % of the nominal bf16 peak -- the practical ceiling of the pipe), ~36 us are fixed
 // (65 MB epilogue, ramp, barriers), ~30 us are operand staging that is not yet hidden behind the MFMAs.  Three loop
 // structures (both operands through one LDS stage; K-tile 16 with two stages; this one) land within 5 % of each other.
@@ -113,13 +113,15 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(const GemmArgs g) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int a_row = wr * (BM / 2) + li;
-    const int nkt = (g.K + BK - 1) / BK;
+    // Every load and LDS store below is UNCONDITIONAL (addresses clamped, activations beyond K zeroed by a select): a load
+    // inside a conditional block makes the compiler's s_waitcnt bookkeeping fall back to vmcnt(0) at the join, which
+    // drains the whole prefetch ring every K-tile.  The K-tile count is rounded up to even (an extra tile multiplies zeros).
+    const int nkt = (((g.K + BK - 1) / BK) + 1) & ~1;
 
     // K-tile kt: activations in LDS `cur`, weights in `w` (refilled with tile kt+2 as its K-steps retire); splits tile kt+1
     // (held in `a_next`) into `other`; loads the activations of tile kt+2 into `a_free`
     auto iteration = [&](int kt, const __bf16* cur, __bf16* other, WFrag& w, const ARegs& a_next, ARegs& a_free) {
-        const bool more = kt + 1 < nkt;
-        if (kt + 2 < nkt) load_a(kt + 2, a_free);
+        load_a(kt + 2, a_free);
         __builtin_amdgcn_sched_barrier(0);
         int unit = 0;
 #pragma unroll
@@ -143,15 +145,13 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(const GemmArgs g) {
                                                                                   0, 0, 0);
                     // slices of the next tile's staging in the shadow of these MFMAs (NA slices over the term groups)
                     constexpr int SLOTS = 2 * (NPL * (NPL + 1) / 2);
-                    if (more) {
 #pragma unroll
-                        for (int p = 0; p < NA; ++p)
-                            if (p * SLOTS / NA == unit) store_a(a_next, p, other);
-                    }
+                    for (int p = 0; p < NA; ++p)
+                        if (p * SLOTS / NA == unit) store_a(a_next, p, other);
                     ++unit;
                     __builtin_amdgcn_sched_barrier(0);
                 }
-            if (kt + 2 < nkt) load_w_step(kt + 2, s, w);       // this K-step's slot is free again
+            load_w_step(kt + 2, s, w);                         // this K-step's slot is free again
             __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();
@@ -161,13 +161,13 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(const GemmArgs g) {
     ARegs a0, a1;
     load_a(0, a0);
     load_w_step(0, 0, w0); load_w_step(0, 1, w0);
-    if (nkt > 1) { load_a(1, a1); load_w_step(1, 0, w1); load_w_step(1, 1, w1); }
+    load_a(1, a1); load_w_step(1, 0, w1); load_w_step(1, 1, w1);
 #pragma unroll
     for (int p = 0; p < NA; ++p) store_a(a0, p, lds);
     __syncthreads();
     for (int kt = 0; kt < nkt; kt += 2) {
         iteration(kt, lds, lds + STAGE, w0, a1, a0);
-        if (kt + 1 < nkt) iteration(kt + 1, lds + STAGE, lds, w1, a0, a1);
+        iteration(kt + 1, lds + STAGE, lds, w1, a0, a1);
     }
     gemm_epilogue<BM, BN, EPI, TM, TN>(g, acc, m0, n0, wr, wc, li, hf);
 }
