@@ -173,6 +173,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch the ~260 kernels eagerly instead of one hipGraph replay")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the extra (never headline) timings of the opt-in modes appended under \"secondary\"")
     ap.add_argument("--dtype", choices=["f32", "bf16", "f32x6", "f32x3"], default="f32",
                     help="f32 = the headline configuration (BASELINE cfg-2, native fp32 MFMA); bf16 = torch.autocast(bfloat16): "
                          "dense GEMMs on the bf16 matrix pipe with fp32 accumulate and fp32 tensors; f32x6 / f32x3 = fp32 GEMMs "
@@ -268,6 +270,31 @@ def main():
                                 if k not in ("flops", "pmc_name", "alg_bytes")}
                                for r in rows],
         }
+    if rank == 0 and world == 1 and args.dtype == "f32" and not args.no_secondary:
+        # The same forward in the opt-in modes, for the record only: `value` above is the native-fp32-MFMA path.
+        sec = {}
+        for name, mode, autocast in (("f32x6", "bf16x6", False), ("f32x3", "bf16x3", False), ("bf16_autocast", "native", True)):
+            try:
+                ops.set_fp32_matmul(mode)
+                run2 = enc
+                if not autocast and not args.no_graph:
+                    from conformer_amd.graph import GraphedEncoder
+                    run2 = GraphedEncoder(enc, x, lengths)
+                amp2 = (lambda: torch.autocast("cuda", dtype=torch.bfloat16)) if autocast else contextlib.nullcontext
+                res = {}
+
+                def step2():
+                    with torch.no_grad(), amp2():
+                        res["y"], _ = run2(x, lengths)
+
+                dt2 = parallel.timed_steps(step2, args.steps, args.warmup, torch.cuda.synchronize, dev)
+                sec[name] = {"ms_per_step": dt2 / args.steps * 1e3, "value": CFG["B"] * CFG["T"] * args.steps / dt2,
+                             "rel_l2_vs_headline_output": float((res["y"].float() - y).norm() / y.norm())}
+            finally:
+                ops.set_fp32_matmul("native")
+        out["secondary"] = {"note": "opt-in modes, same workload, never the headline: f32x6 / f32x3 = fp32 GEMMs from exact "
+                                    "bf16 operand expansions (6 / 3 bf16 MFMAs per K-step, fp32 accumulate, fp32 tensors); "
+                                    "bf16_autocast = torch.autocast(bfloat16)", **sec}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(enc, sample_b=32)
     if rank == 0:

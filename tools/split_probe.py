@@ -26,6 +26,14 @@ def main():
         r = torch.randn(m, n, device=dev)
         row = {"site": name, "M": m, "N": n, "K": k}
         for mode in modes:
+            if mode == "autocast":
+                ops.set_fp32_matmul("native")
+                fns = {"swish": lambda: ops.linear(a, w, b, "swish"), "none": lambda: ops.linear(a, w, b),
+                       "resid": lambda: ops.linear_residual(a, w, b, r, 0.5), "glu": lambda: ops.linear_glu(a, w, b)}
+                with torch.autocast("cuda", dtype=torch.bfloat16):
+                    us = time_us(fns[epi], 20)
+                row[mode] = {"us": round(us, 1), "tflops_equiv": round(2.0 * m * w.shape[0] * k / us / 1e6, 1)}
+                continue
             ops.set_fp32_matmul(mode)
             fn = {"swish": lambda: ops.linear(a, w, b, "swish"), "none": lambda: ops.linear(a, w, b),
                   "resid": lambda: ops.linear_residual(a, w, b, r, 0.5), "glu": lambda: ops.linear_glu(a, w, b)}[epi]
