@@ -76,6 +76,12 @@ def bf16_mfma_active() -> bool:
     return mfma16_prec() == PREC_BF16
 
 
+def _ver(t: torch.Tensor) -> int:
+    """`_version` of a weight, 0 for inference tensors (packs built under torch.inference_mode() carry no version counter;
+    they are never modified in place -- PackCache rebuilds them as new tensors when a source parameter changes)."""
+    return 0 if t.is_inference() else t._version
+
+
 _W16_CACHE = {}        # data_ptr -> (weakref(base tensor), version, prec, shape, 16-bit tensor): per-optimizer-step weight casts
 def weight16(w: torch.Tensor, prec: int) -> Optional[torch.Tensor]:
     """The weight matrix rounded to the 16-bit matrix-pipe type, cached until the parameter changes in place (optimizer
@@ -87,14 +93,14 @@ def weight16(w: torch.Tensor, prec: int) -> Optional[torch.Tensor]:
     hit = _W16_CACHE.get(key)
     # (a freed temporary -- e.g. last step's fused QKV matrix -- can hand its address to a new tensor: the weak reference
     # to the owner tells the two apart; `_version` catches in-place updates of a live parameter)
-    if hit is not None and hit[0]() is base and hit[1] == w._version and hit[2] == prec and hit[3] == w.shape:
+    if hit is not None and hit[0]() is base and hit[1] == _ver(w) and hit[2] == prec and hit[3] == w.shape:
         return hit[4]
     out = torch.empty(w.shape, device=w.device, dtype=_DT16[prec])
     _lib.check(_lib.load().cfm_cast16_f32(prec, w.data_ptr(), out.data_ptr(), w.numel(), _stream()), "cfm_cast16_f32")
     if len(_W16_CACHE) > 4096:
         for k in [k for k, v in _W16_CACHE.items() if v[0]() is None]:
             del _W16_CACHE[k]
-    _W16_CACHE[key] = (weakref.ref(base), w._version, prec, w.shape, out)
+    _W16_CACHE[key] = (weakref.ref(base), _ver(w), prec, w.shape, out)
     return out
 
 
@@ -132,7 +138,7 @@ def weight_split(w: torch.Tensor, planes: int) -> Optional[torch.Tensor]:
     key = w.data_ptr()
     base = w._base if w._base is not None else w
     hit = _WSPLIT_CACHE.get(key)
-    if hit is not None and hit[0]() is base and hit[1] == w._version and hit[2] == planes and hit[3] == w.shape:
+    if hit is not None and hit[0]() is base and hit[1] == _ver(w) and hit[2] == planes and hit[3] == w.shape:
         return hit[4]
     lib = _lib.load()
     n, k = w.shape
@@ -141,7 +147,7 @@ def weight_split(w: torch.Tensor, planes: int) -> Optional[torch.Tensor]:
     if len(_WSPLIT_CACHE) > 4096:
         for kk in [kk for kk, v in _WSPLIT_CACHE.items() if v[0]() is None]:
             del _WSPLIT_CACHE[kk]
-    _WSPLIT_CACHE[key] = (weakref.ref(base), w._version, planes, w.shape, out)
+    _WSPLIT_CACHE[key] = (weakref.ref(base), _ver(w), planes, w.shape, out)
     return out
 
 

@@ -136,3 +136,26 @@ def test_cfg2_encoder_split_vs_native(dev):
             err = rel_l2(y, ref)
             print(f"cfg-2 encoder {mode} vs native: rel-L2 {err:.2e}")
             assert err < tol
+
+
+@pytest.mark.parametrize("mode", ["bf16x6", "autocast"])
+def test_weight_caches_under_inference_mode(dev, mode):
+    """Packs built inside torch.inference_mode() are inference tensors (no version counter): the 16-bit / split weight caches
+    must accept them (fused QKV matrix, packed conv / linear weights)."""
+    from conformer_amd import ops
+    from model.modules.encoder import Encoder
+    torch.manual_seed(0)
+    enc = Encoder(80, 2, 64, 4, 31, 0.0).to(dev).eval()
+    x = torch.randn(2, 80, 120, device=dev)
+    L = torch.tensor([120, 77], device=dev)
+    with torch.no_grad():
+        ref, _ = enc(x, L)
+    enc2 = Encoder(80, 2, 64, 4, 31, 0.0).to(dev).eval()
+    enc2.load_state_dict(enc.state_dict())
+    if mode != "autocast":
+        ops.set_fp32_matmul(mode)
+    with torch.inference_mode(), torch.autocast("cuda", dtype=torch.bfloat16, enabled=mode == "autocast"):
+        y1, _ = enc2(x, L)                              # first call builds every pack inside inference mode
+        y2, _ = enc2(x, L)
+    assert torch.equal(y1, y2)
+    assert rel_l2(y1, ref) < (2e-2 if mode == "autocast" else 2e-6)
