@@ -340,3 +340,51 @@ def test_error_rates_follow_torchmetrics_definition():
     m = ConformerMetric()
     assert abs(float(m.wer_score(["a b c", "d e"], ["a x c", "d e f"])) - 2 / 6) < 1e-7      # 1 sub + 1 del over 6 words
     assert abs(float(m.cer_score("kitten", "sitting")) - 3 / 7) < 1e-7
+
+
+@pytest.mark.parametrize("amp", [None, torch.float16, torch.bfloat16])
+def test_reference_training_loop_with_all_drop_ins(dev, amp):
+    """The loop of train.py:225-245 assembled from this repo's drop-ins only: Conformer, ConformerCriterion (lattice kernels),
+    FusedAdam, GradScaler under fp16 (`--fp16 1`).  First-step loss and gradients equal the torch.nn.CTCLoss route on a
+    twin model; the loss goes down."""
+    from conformer_amd.evaluation import ConformerCriterion
+    from conformer_amd.optim import FusedAdam
+    from model.conformer import Conformer
+    torch.manual_seed(0)
+    m = Conformer(23, 80, 2, 32, 4, 31, 24, 1, 0.0).to(dev).train()
+    twin = Conformer(23, 80, 2, 32, 4, 31, 24, 1, 0.0).to(dev).train()
+    twin.load_state_dict(m.state_dict())
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(4, 80, 131, generator=g).to(dev)
+    L = torch.tensor([131, 120, 99, 64], device=dev)                    # sorted descending, as dataset.py:97 guarantees
+    tg = torch.randint(1, 23, (4, 6), generator=g).to(dev)
+    tl = torch.tensor([6, 5, 6, 3], device=dev)
+    crit = ConformerCriterion(blank_id=0)
+    opt = FusedAdam(m.parameters(), lr=2e-3)
+    scaler = torch.amp.GradScaler("cuda", enabled=amp == torch.float16)
+
+    def forward(model):
+        with torch.autocast("cuda", dtype=amp, enabled=amp is not None):
+            return model(x, L)
+
+    # twin: torch's CTC on the same logits
+    lt, ol = forward(twin)
+    ref = torch.nn.functional.ctc_loss(lt.float().log_softmax(-1).transpose(0, 1), tg, ol, tl, blank=0, zero_infinity=True)
+    ref.backward()
+    losses = []
+    for it in range(6):
+        logits, ol = forward(m)
+        loss = crit.ctc_loss(logits, tg, ol, tl)
+        assert not torch.isnan(loss)                                     # train.py:236
+        opt.zero_grad(set_to_none=True)
+        scaler.scale(loss).backward()
+        if it == 0:
+            scaler.unscale_(opt)
+            assert abs(float(loss) - float(ref)) < 1e-5 * abs(float(ref))
+            gm = torch.cat([p.grad.flatten() for p in m.parameters() if p.grad is not None])
+            gt = torch.cat([p.grad.flatten() for p in twin.parameters() if p.grad is not None])
+            assert rel_l2(gm, gt) < (2e-4 if amp is None else 5e-2)      # 16-bit: atomics order + lattice precision
+        scaler.step(opt)
+        scaler.update()
+        losses.append(float(loss))
+    assert losses[-1] < losses[0]
