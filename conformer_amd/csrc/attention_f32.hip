@@ -32,6 +32,7 @@ struct AttnArgs {
     const float* pos; int64_t ldp; const float* u; const float* vb;
     const int64_t* lengths; float* ctx; int64_t ldo; float* lse;
     int B, T, H, dh; float inv_sqrt_dh;
+    int q_begin, q_end;                             // query rows computed by this launch: [q_begin, q_end) (streaming: the new rows)
     float drop_p; unsigned long long drop_seed;     // training: dropout on the softmax weights (attention.py:67)
     unsigned long long* trace;                      // diagnostics (cfm_debug_attention_trace_f32): phase stamps of one wave
 };
@@ -48,9 +49,9 @@ __global__ __launch_bounds__(256, 2) void relpos_attn_fwd_kernel(const AttnArgs 
     const int li = lane & 31, hf = lane >> 5;
     const int bh = blockIdx.y, b = bh / a.H, h = bh % a.H;
     const int T = a.T, dh = a.dh;
-    const int q0 = blockIdx.x * 128;
+    const int q0 = a.q_begin + blockIdx.x * 128;
     const int i0 = q0 + wave * 32;
-    const bool active = i0 < T;                                    // wave-uniform; idle waves still stage + barrier
+    const bool active = i0 < a.q_end;                                    // wave-uniform; idle waves still stage + barrier
 
     int klen = T;
     bool uniform = false;
@@ -270,7 +271,7 @@ __global__ __launch_bounds__(256, 2) void relpos_attn_fwd_kernel(const AttnArgs 
 #undef ATT_STAMP
 
     // ---- normalise and store: lane = query row, registers = head dims (4 consecutive dims per r>>2 group)
-    if (active && i0 + li < T) {
+    if (active && i0 + li < a.q_end) {
         const float inv = 1.0f / lrow;
         float* orow = a.ctx + ((int64_t)b * T + i0 + li) * a.ldo + h * dh;
 #pragma unroll
@@ -292,7 +293,7 @@ __global__ __launch_bounds__(256, 2) void relpos_attn_fwd_kernel(const AttnArgs 
 static int attention_launch(const float* q, const float* k, const float* v, int64_t ld, const float* pos, int64_t ldp,
                             const float* u, const float* vbias, const int64_t* lengths_or_null, float* ctx, int64_t ldo,
                             float* lse_or_null, int B, int T, int H, int dh, float drop_p, uint64_t drop_seed,
-                            cfm_stream_t stream, void* trace = nullptr);
+                            cfm_stream_t stream, void* trace = nullptr, int q_begin = 0, int q_count = -1);
 
 // diagnostics only (tools/attn_probe.py trace): as cfm_relpos_attention_fwd_f32, plus s_memrealtime (100 MHz) stamps of
 // wave 0 of workgroup (0,0) at 9 phase boundaries of every key tile: trace[16*tile + phase], 16*ceil(T/32) uint64.
@@ -312,6 +313,17 @@ extern "C" int cfm_relpos_attention_fwd_f32(const float* q, const float* k, cons
                             stream);
 }
 
+// Streaming / incremental form: only the query rows [q_begin, q_begin + q_count) are computed (ctx rows outside are left
+// untouched); K / V / the positional table are those of the whole (B,T,.) buffers and `lengths` bounds the visible keys --
+// rows of a growing K/V cache attend to everything cached so far (conformer_amd/streaming.py, BASELINE cfg-5).
+extern "C" int cfm_relpos_attention_rows_f32(const float* q, const float* k, const float* v, int64_t ld,
+                                             const float* pos, int64_t ldp, const float* u, const float* vbias,
+                                             const int64_t* lengths_or_null, float* ctx, int64_t ldo, int B, int T, int H,
+                                             int dh, int q_begin, int q_count, cfm_stream_t stream) {
+    return attention_launch(q, k, v, ld, pos, ldp, u, vbias, lengths_or_null, ctx, ldo, nullptr, B, T, H, dh, 0.f, 0, stream,
+                            nullptr, q_begin, q_count);
+}
+
 // training variant: dropout with probability drop_p on the softmax weights (mask index ((b*H+h)*T + i)*T + k)
 extern "C" int cfm_relpos_attention_train_f32(const float* q, const float* k, const float* v, int64_t ld,
                                               const float* pos, int64_t ldp, const float* u, const float* vbias,
@@ -326,7 +338,7 @@ extern "C" int cfm_relpos_attention_train_f32(const float* q, const float* k, co
 static int attention_launch(const float* q, const float* k, const float* v, int64_t ld, const float* pos, int64_t ldp,
                             const float* u, const float* vbias, const int64_t* lengths_or_null, float* ctx, int64_t ldo,
                             float* lse_or_null, int B, int T, int H, int dh, float drop_p, uint64_t drop_seed,
-                            cfm_stream_t stream, void* trace) {
+                            cfm_stream_t stream, void* trace, int q_begin, int q_count) {
     CFM_REQUIRE(q && k && v && pos && u && vbias && ctx, CFM_ERR_NULL);
     CFM_REQUIRE(B > 0 && T > 0 && H > 0 && dh > 0 && (dh & 3) == 0, CFM_ERR_BAD_SHAPE);
     CFM_REQUIRE((ld & 3) == 0 && (ldp & 3) == 0 && (ldo & 3) == 0, CFM_ERR_BAD_SHAPE);
@@ -334,9 +346,11 @@ static int attention_launch(const float* q, const float* k, const float* v, int6
     CFM_REQUIRE(CFM_ALIGNED16(q) && CFM_ALIGNED16(k) && CFM_ALIGNED16(v) && CFM_ALIGNED16(pos) && CFM_ALIGNED16(u) &&
                 CFM_ALIGNED16(vbias) && CFM_ALIGNED16(ctx), CFM_ERR_ALIGN);
     CFM_REQUIRE((int64_t)B * H <= 65535 && T < (1 << 28), CFM_ERR_UNSUPPORTED);
+    if (q_count < 0) q_count = T - q_begin;
+    CFM_REQUIRE(q_begin >= 0 && q_count > 0 && q_begin + q_count <= T, CFM_ERR_BAD_SHAPE);
     AttnArgs a{q, k, v, ld, pos, ldp, u, vbias, lengths_or_null, ctx, ldo, lse_or_null, B, T, H, dh, 1.0f / sqrtf((float)dh),
-               drop_p, drop_seed, static_cast<unsigned long long*>(trace)};
-    const dim3 grid((unsigned)((T + 127) / 128), (unsigned)(B * H)), block(256);
+               q_begin, q_begin + q_count, drop_p, drop_seed, static_cast<unsigned long long*>(trace)};
+    const dim3 grid((unsigned)((q_count + 127) / 128), (unsigned)(B * H)), block(256);
     hipStream_t s = static_cast<hipStream_t>(stream);
 #define ATT_LAUNCH(NC, ND) hipLaunchKernelGGL((relpos_attn_fwd_kernel<NC, ND>), grid, block, 0, s, a)
     if (dh <= 8) ATT_LAUNCH(1, 1);

@@ -311,6 +311,27 @@ def relpos_attention(qkv: torch.Tensor, pos: torch.Tensor, u: torch.Tensor, v: t
     return ctx
 
 
+def relpos_attention_rows(qkv: torch.Tensor, pos: torch.Tensor, u: torch.Tensor, v: torch.Tensor, lengths: torch.Tensor,
+                          n_heads: int, q_begin: int, q_count: int, ctx: torch.Tensor) -> torch.Tensor:
+    """Incremental attention over a K/V cache: qkv (B,Tmax,3d) holds the projections of every frame seen so far (rows
+    beyond `lengths` are ignored), pos the projected (2Tmax-1,d) table; only query rows [q_begin, q_begin+q_count) are
+    computed, into the same rows of `ctx` (B,Tmax,d).  fp32 only (inference)."""
+    qkv = _req(qkv, "qkv"); u = _req(u, "content_bias"); v = _req(v, "position_bias"); ctx = _req(ctx, "ctx")
+    B, T, d3 = qkv.shape
+    d = d3 // 3
+    if not (pos.is_cuda and pos.dtype == torch.float32 and pos.dim() == 2 and pos.stride(1) == 1 and pos.shape == (2 * T - 1, d)):
+        raise _lib.ConformerHipError(f"pos: expected a ({2 * T - 1},{d}) fp32 HIP tensor with unit column stride")
+    if ctx.shape != (B, T, d) or not qkv.is_contiguous() or not ctx.is_contiguous():
+        raise _lib.ConformerHipError("relpos_attention_rows: qkv (B,T,3d) and ctx (B,T,d) must be contiguous cache buffers")
+    lengths = _req(lengths, "lengths", torch.int64)
+    base = qkv.data_ptr()
+    st = _lib.load().cfm_relpos_attention_rows_f32(base, base + 4 * d, base + 8 * d, d3, pos.data_ptr(), pos.stride(0),
+                                                   u.data_ptr(), v.data_ptr(), lengths.data_ptr(), ctx.data_ptr(), d, B, T,
+                                                   n_heads, d // n_heads, int(q_begin), int(q_count), _stream())
+    _lib.check(st, "cfm_relpos_attention_rows_f32")
+    return ctx
+
+
 def dwconv_bn_swish(g, w, b, bn_w, bn_b, bn_mean, bn_var, eps: float = 1e-5) -> torch.Tensor:
     g = _req(g, "g"); w = _req(w, "dw weight"); b = _req(b, "dw bias")
     B, T, C = g.shape

@@ -352,6 +352,14 @@ int cfm_ctc_loss_bwd_f32(const float* logits, const int64_t* targets, const int6
                          int B, int T, int V, int Lmax, int blank, float* workspace, const float* grad_out,
                          float* dlogits, cfm_stream_t stream);
 
+/* incremental / streaming attention (no reference counterpart: the reference has no streaming code; BASELINE cfg-5): as
+ *      cfm_relpos_attention_fwd_f32 but only the query rows [q_begin, q_begin+q_count) are computed; q/k/v/ctx are the
+ *      whole (B,T,.) buffers (a K/V cache that grows in place), lengths = keys visible so far. */
+int cfm_relpos_attention_rows_f32(const float* q, const float* k, const float* v, int64_t ld, const float* pos,
+                                  int64_t ldp, const float* u, const float* vbias, const int64_t* lengths_or_null,
+                                  float* ctx, int64_t ldo, int B, int T, int H, int dh, int q_begin, int q_count,
+                                  cfm_stream_t stream);
+
 /* diagnostics only: cfm_relpos_attention_fwd_f32 + s_memrealtime stamps of one wave (trace: 16*ceil(T/32) uint64) */
 int cfm_debug_attention_trace_f32(const float* q, const float* k, const float* v, int64_t ld, const float* pos,
                                   int64_t ldp, const float* u, const float* vbias, const int64_t* lengths_or_null,

@@ -82,7 +82,8 @@ def relpos_table(t: int, div_term: torch.Tensor) -> torch.Tensor:
 
 
 def relpos_attention_core(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, pp: torch.Tensor,
-                          u: torch.Tensor, vb: torch.Tensor, lengths: Optional[torch.Tensor]) -> torch.Tensor:
+                          u: torch.Tensor, vb: torch.Tensor, lengths: Optional[torch.Tensor],
+                          visible_end: Optional[torch.Tensor] = None) -> torch.Tensor:
     """scaled_dot_product_relative_attention + _relative_shift, attention.py:47-72,94-102.
 
     q,k,v: (B,T,H,dh) projected; pp: (2T-1,H,dh) projected positions (row j <-> r=T-1-j);
@@ -100,13 +101,16 @@ def relpos_attention_core(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, pp:
     if lengths is not None:
         pad = torch.arange(T)[None, :] >= lengths[:, None]                # True at padded keys
         s = s.masked_fill(pad[:, None, None, :], torch.finfo(s.dtype).min)
+    if visible_end is not None:                                           # chunked evaluation: row i sees keys < visible_end[i]
+        hidden = torch.arange(T)[None, :] >= visible_end[:, None]         # (T,T)
+        s = s.masked_fill(hidden[None, None], torch.finfo(s.dtype).min)
     a = torch.softmax(s, dim=-1)
     ctx = torch.einsum("bhik,bkhc->bihc", a, v)
     return ctx.reshape(B, T, H * dh)
 
 
 def mhsa_module(x: torch.Tensor, pe: torch.Tensor, lengths: Optional[torch.Tensor], p: Params, pre: str,
-                n_heads: int) -> torch.Tensor:
+                n_heads: int, visible_end: Optional[torch.Tensor] = None) -> torch.Tensor:
     """MultiHeadSelfAttentionModule.forward, attention.py:14-18, 74-92 (dropout p=0).
 
     ``pe`` is the un-repeated (2T-1, d) table.
@@ -119,13 +123,14 @@ def mhsa_module(x: torch.Tensor, pe: torch.Tensor, lengths: Optional[torch.Tenso
     k = (xn @ p[a + "key_proj.weight"].t() + p[a + "key_proj.bias"]).view(B, T, n_heads, dh)
     v = (xn @ p[a + "value_proj.weight"].t() + p[a + "value_proj.bias"]).view(B, T, n_heads, dh)
     pp = (pe @ p[a + "pos_proj.weight"].t() + p[a + "pos_proj.bias"]).view(2 * T - 1, n_heads, dh)
-    ctx = relpos_attention_core(q, k, v, pp, p[a + "content_bias"], p[a + "position_bias"], lengths)
+    ctx = relpos_attention_core(q, k, v, pp, p[a + "content_bias"], p[a + "position_bias"], lengths, visible_end)
     return ctx @ p[a + "out_proj.weight"].t() + p[a + "out_proj.bias"]
 
 
 # --------------------------------------------------------------------------- conv module
 def conv_module(x: torch.Tensor, p: Params, pre: str, training: bool = False,
-                bn_state: Optional[Dict[str, torch.Tensor]] = None) -> torch.Tensor:
+                bn_state: Optional[Dict[str, torch.Tensor]] = None,
+                visible_end: Optional[torch.Tensor] = None) -> torch.Tensor:
     """ConvolutionModule.forward, convolution.py:21-32 (dropout p=0).
 
     Channel-last restatement: the pointwise convs are row GEMMs on (B,T,C).
@@ -143,7 +148,11 @@ def conv_module(x: torch.Tensor, p: Params, pre: str, training: bool = False,
     gp = F.pad(g, (0, 0, half, half))                                     # zero pad in time, per utterance
     c = p[pre + "deepwise_conv.bias"].expand(B, T, C).clone()
     for jtap in range(K):
-        c = c + gp[:, jtap:jtap + T, :] * wdw[:, jtap]
+        tap = gp[:, jtap:jtap + T, :] * wdw[:, jtap]
+        if visible_end is not None:                                       # chunked: frames >= visible_end[i] count as padding
+            seen = (torch.arange(T) + jtap - half) < visible_end
+            tap = tap * seen[None, :, None].to(tap.dtype)
+        c = c + tap
     if training:
         flat = c.reshape(-1, C)
         mean = flat.mean(0)
@@ -162,11 +171,11 @@ def conv_module(x: torch.Tensor, p: Params, pre: str, training: bool = False,
 
 # --------------------------------------------------------------------------- block / stem / encoder
 def conformer_block(x: torch.Tensor, pe: torch.Tensor, lengths: Optional[torch.Tensor], p: Params, pre: str,
-                    n_heads: int, training: bool = False) -> torch.Tensor:
+                    n_heads: int, training: bool = False, visible_end: Optional[torch.Tensor] = None) -> torch.Tensor:
     """ConformerBlock.forward, block.py:17-29."""
     y = 0.5 * ffn_module(x, p, pre + "ffn_1.") + x
-    y = mhsa_module(y, pe, lengths, p, pre + "attention.", n_heads) + y
-    y = conv_module(y, p, pre + "conv.", training) + y
+    y = mhsa_module(y, pe, lengths, p, pre + "attention.", n_heads, visible_end) + y
+    y = conv_module(y, p, pre + "conv.", training, visible_end=visible_end) + y
     y = 0.5 * ffn_module(y, p, pre + "ffn_2.") + y
     return layer_norm(y, p[pre + "layer_norm.weight"], p[pre + "layer_norm.bias"])
 
@@ -199,6 +208,29 @@ def encoder_forward(x: torch.Tensor, lengths: Optional[torch.Tensor], p: Params,
     if return_block_outputs:
         return h, out_len, outs
     return h, out_len
+
+
+def encoder_forward_chunked(x: torch.Tensor, p: Params, n_blocks: int, n_heads: int, chunk_ends, pre: str = "encoder."):
+    """Chunk-by-chunk (streaming) evaluation restated on the WHOLE sequence with masks.  The reference has no streaming
+    code; the semantics are the prefix rule: an encoder frame of chunk c is computed, in every layer, from the frames of
+    chunks <= c only -- self-attention sees keys < end(c), the depthwise convolution treats frames >= end(c) as zero
+    padding (exactly what Encoder.forward does at the end of an utterance).  chunk_ends: increasing frame indices, the last
+    one == T'.  With a single chunk this IS encoder_forward."""
+    h = conv_subsampling(x, p, pre + "downsampling_conv.")
+    h = h @ p[pre + "linear.weight"].t() + p[pre + "linear.bias"]
+    T = h.shape[1]
+    ends = [int(e) for e in chunk_ends]
+    if ends[-1] != T or any(b <= a for a, b in zip(ends, ends[1:])):
+        raise ValueError(f"chunk_ends must increase and finish at T'={T}")
+    visible_end = torch.empty(T, dtype=torch.long)
+    start = 0
+    for e in ends:
+        visible_end[start:e] = e
+        start = e
+    pe = relpos_table(T, p[pre + "rel_pe.div_term"])
+    for li in range(n_blocks):
+        h = conformer_block(h, pe, None, p, f"{pre}layers.{li}.", n_heads, visible_end=visible_end)
+    return h
 
 
 def lstm_layer(x: torch.Tensor, lengths: Optional[torch.Tensor], w_ih, w_hh, b_ih, b_hh) -> torch.Tensor:

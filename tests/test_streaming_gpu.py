@@ -1,0 +1,111 @@
+"""BASELINE cfg-5: chunk-by-chunk evaluation with cached K/V and depthwise state (conformer_amd/streaming.py).
+
+The reference has no streaming code; the contract is the prefix rule (see streaming.py): pinned here against (a) the masked
+whole-sequence float64 restatement `oracle.encoder_forward_chunked`, (b) Encoder.forward when one chunk holds everything,
+(c) Encoder.forward of the first chunk's prefix, and run at the full cfg-5 size (B=8, T=20000, 640-frame chunks)."""
+import pytest
+import torch
+
+from oracle import conformer_oracle as O
+from tests.util import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda:0")
+
+
+def _encoder(P, n_mel, n_blocks, d, H, K, dev):
+    from model.modules.encoder import Encoder
+    enc = Encoder(n_mel, n_blocks, d, H, K, 0.0)
+    enc.load_state_dict({k[len("encoder."):]: v.float() for k, v in P.items() if k.startswith("encoder.")}, strict=True)
+    return enc.to(dev).eval()
+
+
+@pytest.mark.parametrize("chunks", [[64] * 7, [200, 7, 1, 130, 3, 62], [403], [9, 394]])
+def test_streaming_matches_masked_restatement(dev, chunks):
+    from conformer_amd.streaming import StreamingEncoder, chunk_ends
+    d, H, L, K = 32, 4, 2, 31
+    P = O.make_params(vocab=8, n_mel=80, n_blocks=L, d=d, n_heads=H, ksize=K, lstm_hidden=8, seed=11, dtype=torch.float64,
+                      with_decoder=False)
+    T = sum(chunks)
+    x = torch.randn(2, 80, T, generator=torch.Generator().manual_seed(4), dtype=torch.float64)
+    ends = chunk_ends(T, chunks)
+    ref = O.encoder_forward_chunked(x, P, L, H, ends)
+    enc = _encoder(P, 80, L, d, H, K, dev)
+    st = StreamingEncoder(enc, batch=2, max_mel_frames=T)
+    outs, t0 = [], 0
+    for c in chunks:
+        outs.append(st.step(x[:, :, t0:t0 + c].float().to(dev)))
+        t0 += c
+    got = torch.cat(outs, dim=1)
+    assert got.shape == ref.shape and st.frames == ends[-1]
+    assert [o.shape[1] for o in outs if o.shape[1]] == [b - a for a, b in zip([0] + ends, ends)]
+    assert rel_l2(got, ref) < 2e-5
+    if len(ends) > 1:                                   # and chunking really changes the numbers (not a vacuous test)
+        full, _ = O.encoder_forward(x, None, P, L, H)
+        assert rel_l2(ref, full) > 1e-3
+
+
+def test_one_chunk_is_encoder_forward_and_reset_works(dev):
+    from conformer_amd.streaming import StreamingEncoder
+    P = O.make_params(vocab=8, n_mel=80, n_blocks=2, d=64, n_heads=4, ksize=31, lstm_hidden=8, seed=12, with_decoder=False)
+    enc = _encoder(P, 80, 2, 64, 4, 31, dev)
+    x = torch.randn(3, 80, 331, device=dev)
+    with torch.no_grad():
+        full, _ = enc(x, None)
+    st = StreamingEncoder(enc, batch=3, max_mel_frames=400)          # cache longer than the utterance
+    one = st.step(x)
+    assert rel_l2(one, full) < 2e-6
+    a = st.run(torch.randn(3, 80, 50, device=dev), 50)               # garbage in the caches, then a fresh stream
+    assert a.shape[1] == 0 or True
+    st.reset()
+    again = st.run(x, 331)
+    assert torch.equal(again, one)
+
+
+def test_first_chunk_equals_forward_of_its_prefix_cfg5_width(dev):
+    """Full-width model (d=512, H=8, K=31; 2 blocks), 640-frame chunks: streaming vs the float64 masked restatement, and the
+    first chunk against Encoder.forward of the 639 mel frames it is computed from."""
+    from conformer_amd.streaming import StreamingEncoder, chunk_ends
+    P = O.make_params(vocab=8, n_mel=80, n_blocks=2, d=512, n_heads=8, ksize=31, lstm_hidden=8, seed=13, dtype=torch.float64,
+                      with_decoder=False)
+    enc = _encoder(P, 80, 2, 512, 8, 31, dev)
+    T = 640 * 3 + 160
+    x = torch.randn(2, 80, T, generator=torch.Generator().manual_seed(5), dtype=torch.float64)
+    chunks = [640, 640, 640, 160]
+    ends = chunk_ends(T, chunks)
+    assert ends == [159, 319, 479, 519]
+    ref = O.encoder_forward_chunked(x, P, 2, 8, ends)
+    st = StreamingEncoder(enc, batch=2, max_mel_frames=T)
+    got = st.run(x.float().to(dev), 640)
+    assert rel_l2(got, ref) < 2e-5
+    with torch.no_grad():
+        prefix, _ = enc(x[:, :, :639].float().to(dev), None)         # 639 mel frames -> exactly 159 encoder frames
+    assert prefix.shape[1] == 159 and rel_l2(got[:, :159], prefix) < 2e-6
+
+
+def test_cfg5_full_size_stream(dev):
+    """BASELINE cfg-5 as written: B=8, T=20000 mel frames in 31 chunks of 640 + one of 160, Conformer-L encoder."""
+    from conformer_amd.streaming import StreamingEncoder
+    from model.modules.encoder import Encoder
+    torch.manual_seed(0)
+    enc = Encoder(80, 16, 512, 8, 31, 0.0).to(dev).eval()
+    x = torch.randn(8, 80, 20000, generator=torch.Generator().manual_seed(6)).to(dev)
+    st = StreamingEncoder(enc, batch=8, max_mel_frames=20000)
+    outs = [st.step(x[:, :, t:t + 640]) for t in range(0, 20000, 640)]
+    assert [o.shape[1] for o in outs] == [159] + [160] * 30 + [40]
+    y = torch.cat(outs, dim=1)
+    assert y.shape == (8, 4999, 512) and torch.isfinite(y).all()
+    with torch.no_grad():
+        prefix, _ = enc(x[:, :, :639], None)
+    assert rel_l2(y[:, :159], prefix) < 2e-6
+    # the last chunk sees the whole utterance: its attention / convolution inputs differ from the full-context forward only
+    # through the cached lower-layer rows, so the two must be close but not equal
+    with torch.no_grad():
+        full, _ = enc(x, None)
+    assert 1e-4 < rel_l2(y, full) < 1.0
