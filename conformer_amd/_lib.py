@@ -77,7 +77,7 @@ SIGNATURES = {
     "cfm_ctc_workspace_floats": (ctypes.c_int64, [_I, _I, _I]),
     "cfm_ctc_loss_fwd_f32": (c_int, [_P, _P, _P, _L, _L, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P]),
     "cfm_ctc_loss_bwd_f32": (c_int, [_P, _P, _P, _L, _L, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
-    "cfm_relpos_attention_rows_f32": (c_int, [_P, _P, _P, _L, _P, _L, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _P]),
+    "cfm_relpos_attention_rows_f32": (c_int, [_P, _P, _P, _L, _P, _L, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
     "cfm_debug_attention_trace_f32": (c_int, [_P, _P, _P, _L, _P, _L, _P, _P, _P, _P, _L, _I, _I, _I, _I, _P, _P]),
     "cfm_debug_set_bwd_tile": (c_int, [_I]),
     "cfm_debug_gemm_cfg_f32": (c_int, [_I, _P, _P, _P, _P, _F, _P, _L, _I, _I, _P, _P]),

@@ -33,6 +33,8 @@ struct AttnArgs {
     const int64_t* lengths; float* ctx; int64_t ldo; float* lse;
     int B, T, H, dh; float inv_sqrt_dh;
     int q_begin, q_end;                             // query rows computed by this launch: [q_begin, q_end) (streaming: the new rows)
+    int nsplit;                                     // > 1: the keys of every (b,h,row block) are split over nsplit workgroups, each
+    float* part_ctx; float* part_lse;               //      writing a normalised partial context + its log-sum-exp (merged afterwards)
     float drop_p; unsigned long long drop_seed;     // training: dropout on the softmax weights (attention.py:67)
     unsigned long long* trace;                      // diagnostics (cfm_debug_attention_trace_f32): phase stamps of one wave
 };
@@ -49,7 +51,8 @@ __global__ __launch_bounds__(256, 2) void relpos_attn_fwd_kernel(const AttnArgs 
     const int li = lane & 31, hf = lane >> 5;
     const int bh = blockIdx.y, b = bh / a.H, h = bh % a.H;
     const int T = a.T, dh = a.dh;
-    const int q0 = a.q_begin + blockIdx.x * 128;
+    const int split = a.nsplit > 1 ? (int)(blockIdx.x % (unsigned)a.nsplit) : 0;
+    const int q0 = a.q_begin + (int)(a.nsplit > 1 ? blockIdx.x / (unsigned)a.nsplit : blockIdx.x) * 128;
     const int i0 = q0 + wave * 32;
     const bool active = i0 < a.q_end;                                    // wave-uniform; idle waves still stage + barrier
 
@@ -60,7 +63,11 @@ __global__ __launch_bounds__(256, 2) void relpos_attn_fwd_kernel(const AttnArgs 
         if (L <= 0) uniform = true;                                // every key masked -> uniform weights
         else if (L < T) klen = (int)L;
     }
-    const int ntiles = (klen + 31) / 32;
+    const int ntiles_all = (klen + 31) / 32;
+    const int tiles_per_split = (ntiles_all + a.nsplit - 1) / a.nsplit;
+    const int kt_begin = split * tiles_per_split;                  // this workgroup's key tiles: [kt_begin, ntiles)
+    const int ntiles = min(ntiles_all, kt_begin + tiles_per_split);
+    if (kt_begin >= ntiles) return;                                // an empty split (short cache): uniform for the workgroup
 
     const float* kbase = a.k + (int64_t)b * T * a.ld + h * dh;
     const float* vbase = a.v + (int64_t)b * T * a.ld + h * dh;
@@ -101,7 +108,7 @@ __global__ __launch_bounds__(256, 2) void relpos_attn_fwd_kernel(const AttnArgs 
 
     // ---- prologue: ring rows [jlo, jlo+127] of tile 0 (the top 32 rows arrive with prefetch(0)), then tile 0
     {
-        const int jlo = T - 1 - q0 - 128;
+        const int jlo = T - 1 - q0 - 128 + 32 * kt_begin;
 #pragma unroll
         for (int p = 0; p < 8; ++p) {
             const int r = srow + 16 * p;                           // 0..127
@@ -112,9 +119,9 @@ __global__ __launch_bounds__(256, 2) void relpos_attn_fwd_kernel(const AttnArgs 
             *reinterpret_cast<f32x4*>(Pr + slot * KROW + sch * 4) = val;
         }
     }
-    prefetch(0);
-    commit(0);
-    if (ntiles > 1) prefetch(1);
+    prefetch(kt_begin);
+    commit(kt_begin);
+    if (kt_begin + 1 < ntiles) prefetch(kt_begin + 1);
     __syncthreads();
 
     // ---- (Q+u)^T and (Q+v)^T as MFMA B operands: lane (query li, half hf) holds dims 8c+4hf+e at step 4c+e
@@ -145,7 +152,7 @@ __global__ __launch_bounds__(256, 2) void relpos_attn_fwd_kernel(const AttnArgs 
 
     const bool tracer = a.trace && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0;
 #define ATT_STAMP(i) do { if (tracer) a.trace[16 * kt + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
-    for (int kt = 0; kt < ntiles; ++kt) {
+    for (int kt = kt_begin; kt < ntiles; ++kt) {
         const int k0 = kt * 32;
         ATT_STAMP(0);
         if (active) {
@@ -273,7 +280,9 @@ __global__ __launch_bounds__(256, 2) void relpos_attn_fwd_kernel(const AttnArgs 
     // ---- normalise and store: lane = query row, registers = head dims (4 consecutive dims per r>>2 group)
     if (active && i0 + li < a.q_end) {
         const float inv = 1.0f / lrow;
-        float* orow = a.ctx + ((int64_t)b * T + i0 + li) * a.ldo + h * dh;
+        const int qc = a.q_end - a.q_begin, il = i0 + li - a.q_begin;
+        float* orow = a.nsplit > 1 ? a.part_ctx + (((int64_t)split * a.B + b) * qc + il) * a.ldo + h * dh
+                                   : a.ctx + ((int64_t)b * T + i0 + li) * a.ldo + h * dh;
 #pragma unroll
         for (int n = 0; n < ND; ++n)
 #pragma unroll
@@ -284,8 +293,40 @@ __global__ __launch_bounds__(256, 2) void relpos_attn_fwd_kernel(const AttnArgs 
                     *reinterpret_cast<f32x4*>(orow + dd) = out;
                 }
             }
-        if (a.lse && hf == 0) a.lse[((int64_t)b * a.H + h) * T + i0 + li] = mrow + logf(lrow);
+        if (a.nsplit > 1) {
+            if (hf == 0) a.part_lse[(((int64_t)split * a.B + b) * a.H + h) * qc + il] = mrow + logf(lrow);
+        } else if (a.lse && hf == 0) {
+            a.lse[((int64_t)b * a.H + h) * T + i0 + li] = mrow + logf(lrow);
+        }
     }
+}
+
+// ctx[b, q_begin+il, h*dh + :] = sum_s exp(lse_s - lse) * part_s, lse = logsumexp over the splits that own keys of utterance b
+__global__ __launch_bounds__(256) void attn_merge_splits_kernel(const AttnArgs a) {
+    const int qc = a.q_end - a.q_begin, d4 = a.dh / 4;
+    const int64_t total = (int64_t)a.B * qc * a.H * d4;
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int c4 = (int)(idx % d4);
+    const int h = (int)((idx / d4) % a.H);
+    const int il = (int)((idx / ((int64_t)d4 * a.H)) % qc);
+    const int b = (int)(idx / ((int64_t)d4 * a.H * qc));
+    int klen = a.T;
+    if (a.lengths) { const int64_t L = a.lengths[b]; if (L > 0 && L < a.T) klen = (int)L; }
+    const int ntiles_all = (klen + 31) / 32, tps = (ntiles_all + a.nsplit - 1) / a.nsplit;
+    const int live = (ntiles_all + tps - 1) / tps;                 // splits with kt_begin < ntiles_all
+    float lmax = -INFINITY;
+    for (int s = 0; s < live; ++s) lmax = fmaxf(lmax, a.part_lse[(((int64_t)s * a.B + b) * a.H + h) * qc + il]);
+    float wsum = 0.f;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < live; ++s) {
+        const float w = exp_fast(a.part_lse[(((int64_t)s * a.B + b) * a.H + h) * qc + il] - lmax);
+        const f32x4 p = *reinterpret_cast<const f32x4*>(a.part_ctx + (((int64_t)s * a.B + b) * qc + il) * a.ldo + h * a.dh + 4 * c4);
+        acc = acc + p * w;
+        wsum += w;
+    }
+    const float inv = 1.0f / wsum;
+    *reinterpret_cast<f32x4*>(a.ctx + ((int64_t)b * a.T + a.q_begin + il) * a.ldo + h * a.dh + 4 * c4) = acc * inv;
 }
 
 }  // namespace
@@ -293,7 +334,8 @@ __global__ __launch_bounds__(256, 2) void relpos_attn_fwd_kernel(const AttnArgs 
 static int attention_launch(const float* q, const float* k, const float* v, int64_t ld, const float* pos, int64_t ldp,
                             const float* u, const float* vbias, const int64_t* lengths_or_null, float* ctx, int64_t ldo,
                             float* lse_or_null, int B, int T, int H, int dh, float drop_p, uint64_t drop_seed,
-                            cfm_stream_t stream, void* trace = nullptr, int q_begin = 0, int q_count = -1);
+                            cfm_stream_t stream, void* trace = nullptr, int q_begin = 0, int q_count = -1, int nsplit = 1,
+                            float* workspace = nullptr);
 
 // diagnostics only (tools/attn_probe.py trace): as cfm_relpos_attention_fwd_f32, plus s_memrealtime (100 MHz) stamps of
 // wave 0 of workgroup (0,0) at 9 phase boundaries of every key tile: trace[16*tile + phase], 16*ceil(T/32) uint64.
@@ -316,12 +358,16 @@ extern "C" int cfm_relpos_attention_fwd_f32(const float* q, const float* k, cons
 // Streaming / incremental form: only the query rows [q_begin, q_begin + q_count) are computed (ctx rows outside are left
 // untouched); K / V / the positional table are those of the whole (B,T,.) buffers and `lengths` bounds the visible keys --
 // rows of a growing K/V cache attend to everything cached so far (conformer_amd/streaming.py, BASELINE cfg-5).
+// nsplit > 1 (flash-decoding form, for long caches and few query rows): the key tiles of every (b, h, 128-row block) are
+// divided over nsplit workgroups that write normalised partial contexts + log-sum-exps into `workspace`
+// (nsplit*B*q_count*(H*dh + H) floats; ldo must equal H*dh, lengths required, every length >= 1), merged by a second kernel.
 extern "C" int cfm_relpos_attention_rows_f32(const float* q, const float* k, const float* v, int64_t ld,
                                              const float* pos, int64_t ldp, const float* u, const float* vbias,
                                              const int64_t* lengths_or_null, float* ctx, int64_t ldo, int B, int T, int H,
-                                             int dh, int q_begin, int q_count, cfm_stream_t stream) {
+                                             int dh, int q_begin, int q_count, int nsplit, float* workspace_or_null,
+                                             cfm_stream_t stream) {
     return attention_launch(q, k, v, ld, pos, ldp, u, vbias, lengths_or_null, ctx, ldo, nullptr, B, T, H, dh, 0.f, 0, stream,
-                            nullptr, q_begin, q_count);
+                            nullptr, q_begin, q_count, nsplit, workspace_or_null);
 }
 
 // training variant: dropout with probability drop_p on the softmax weights (mask index ((b*H+h)*T + i)*T + k)
@@ -338,7 +384,7 @@ extern "C" int cfm_relpos_attention_train_f32(const float* q, const float* k, co
 static int attention_launch(const float* q, const float* k, const float* v, int64_t ld, const float* pos, int64_t ldp,
                             const float* u, const float* vbias, const int64_t* lengths_or_null, float* ctx, int64_t ldo,
                             float* lse_or_null, int B, int T, int H, int dh, float drop_p, uint64_t drop_seed,
-                            cfm_stream_t stream, void* trace, int q_begin, int q_count) {
+                            cfm_stream_t stream, void* trace, int q_begin, int q_count, int nsplit, float* workspace) {
     CFM_REQUIRE(q && k && v && pos && u && vbias && ctx, CFM_ERR_NULL);
     CFM_REQUIRE(B > 0 && T > 0 && H > 0 && dh > 0 && (dh & 3) == 0, CFM_ERR_BAD_SHAPE);
     CFM_REQUIRE((ld & 3) == 0 && (ldp & 3) == 0 && (ldo & 3) == 0, CFM_ERR_BAD_SHAPE);
@@ -348,9 +394,13 @@ static int attention_launch(const float* q, const float* k, const float* v, int6
     CFM_REQUIRE((int64_t)B * H <= 65535 && T < (1 << 28), CFM_ERR_UNSUPPORTED);
     if (q_count < 0) q_count = T - q_begin;
     CFM_REQUIRE(q_begin >= 0 && q_count > 0 && q_begin + q_count <= T, CFM_ERR_BAD_SHAPE);
+    CFM_REQUIRE(nsplit >= 1 && nsplit <= 16 && (nsplit == 1 || (workspace && lengths_or_null && !lse_or_null && ldo == (int64_t)H * dh)),
+                CFM_ERR_BAD_SHAPE);
     AttnArgs a{q, k, v, ld, pos, ldp, u, vbias, lengths_or_null, ctx, ldo, lse_or_null, B, T, H, dh, 1.0f / sqrtf((float)dh),
-               q_begin, q_begin + q_count, drop_p, drop_seed, static_cast<unsigned long long*>(trace)};
-    const dim3 grid((unsigned)((q_count + 127) / 128), (unsigned)(B * H)), block(256);
+               q_begin, q_begin + q_count, nsplit, workspace,
+               workspace ? workspace + (int64_t)nsplit * B * q_count * ldo : nullptr, drop_p, drop_seed,
+               static_cast<unsigned long long*>(trace)};
+    const dim3 grid((unsigned)((q_count + 127) / 128) * nsplit, (unsigned)(B * H)), block(256);
     hipStream_t s = static_cast<hipStream_t>(stream);
 #define ATT_LAUNCH(NC, ND) hipLaunchKernelGGL((relpos_attn_fwd_kernel<NC, ND>), grid, block, 0, s, a)
     if (dh <= 8) ATT_LAUNCH(1, 1);
@@ -359,5 +409,9 @@ static int attention_launch(const float* q, const float* k, const float* v, int6
     else if (dh <= 40) ATT_LAUNCH(5, 2);
     else ATT_LAUNCH(8, 2);
 #undef ATT_LAUNCH
+    if (nsplit > 1) {
+        const int64_t total = (int64_t)B * q_count * H * (dh / 4);
+        hipLaunchKernelGGL(attn_merge_splits_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
+    }
     return cfm_launch_status();
 }

@@ -95,7 +95,7 @@ class StreamingEncoder:
         w, b = a._qkv_params()
         self.qkv[i][:, n0:n0 + k].copy_(ops.linear(xn, w, b))
         ops.relpos_attention_rows(self.qkv[i], self.pos_all[:, i * d:(i + 1) * d], a.content_bias, a.position_bias,
-                                  self.lengths, a.n_heads, n0, k, self.ctx)
+                                  self.lengths, a.n_heads, n0, k, self.ctx, keys_hint=n0 + k)
         y = ops.linear_residual(self.ctx[:, n0:n0 + k].contiguous(), a.out_proj.weight, a.out_proj.bias, y, 1.0)
         # ---- convolution module: the depthwise window reaches (K-1)/2 frames back into the cached GLU outputs
         cv, half = blk.conv, self.half[i]

@@ -354,11 +354,13 @@ int cfm_ctc_loss_bwd_f32(const float* logits, const int64_t* targets, const int6
 
 /* incremental / streaming attention (no reference counterpart: the reference has no streaming code; BASELINE cfg-5): as
  *      cfm_relpos_attention_fwd_f32 but only the query rows [q_begin, q_begin+q_count) are computed; q/k/v/ctx are the
- *      whole (B,T,.) buffers (a K/V cache that grows in place), lengths = keys visible so far. */
+ *      whole (B,T,.) buffers (a K/V cache that grows in place), lengths = keys visible so far.  nsplit in [1,16]: > 1
+ *      divides the key tiles over nsplit workgroups per (b, h, 128-row block) and merges their partial results
+ *      (workspace: nsplit*B*q_count*(H*dh + H) floats; needs ldo == H*dh, lengths != NULL with every length >= 1). */
 int cfm_relpos_attention_rows_f32(const float* q, const float* k, const float* v, int64_t ld, const float* pos,
                                   int64_t ldp, const float* u, const float* vbias, const int64_t* lengths_or_null,
                                   float* ctx, int64_t ldo, int B, int T, int H, int dh, int q_begin, int q_count,
-                                  cfm_stream_t stream);
+                                  int nsplit, float* workspace_or_null, cfm_stream_t stream);
 
 /* diagnostics only: cfm_relpos_attention_fwd_f32 + s_memrealtime stamps of one wave (trace: 16*ceil(T/32) uint64) */
 int cfm_debug_attention_trace_f32(const float* q, const float* k, const float* v, int64_t ld, const float* pos,

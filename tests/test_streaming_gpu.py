@@ -109,3 +109,23 @@ def test_cfg5_full_size_stream(dev):
     with torch.no_grad():
         full, _ = enc(x, None)
     assert 1e-4 < rel_l2(y, full) < 1.0
+
+
+@pytest.mark.parametrize("T,q_begin,q_count,lens", [(700, 640, 60, [700, 650]), (1300, 1100, 200, [1300, 1111]),
+                                                    (300, 0, 300, [300, 290]), (2600, 2440, 160, [2600, 2600])])
+def test_incremental_attention_rows_and_key_split(dev, T, q_begin, q_count, lens):
+    """cfm_relpos_attention_rows_f32 (with and without the key split) reproduces the rows of the full attention kernel."""
+    from conformer_amd import ops
+    H, dh = 4, 16
+    d = H * dh
+    g = torch.Generator().manual_seed(9)
+    qkv = torch.randn(2, T, 3 * d, generator=g).to(dev)
+    pos = torch.randn(2 * T - 1, d, generator=g).to(dev)
+    u, v = torch.randn(H, dh, generator=g).to(dev) * 0.1, torch.randn(H, dh, generator=g).to(dev) * 0.1
+    L = torch.tensor(lens, device=dev)
+    full = ops.relpos_attention(qkv, pos, u, v, L, H)
+    for hint in (None, 64):                                    # None -> split chosen from T; 64 -> no split
+        ctx = torch.full((2, T, d), float("nan"), device=dev)
+        ops.relpos_attention_rows(qkv, pos, u, v, L, H, q_begin, q_count, ctx, keys_hint=hint)
+        assert rel_l2(ctx[:, q_begin:q_begin + q_count], full[:, q_begin:q_begin + q_count]) < 2e-6
+        assert torch.isnan(ctx[:, :q_begin]).all() and torch.isnan(ctx[:, q_begin + q_count:]).all()   # other rows untouched
