@@ -159,3 +159,31 @@ def test_weight_caches_under_inference_mode(dev, mode):
         y2, _ = enc2(x, L)
     assert torch.equal(y1, y2)
     assert rel_l2(y1, ref) < (2e-2 if mode == "autocast" else 2e-6)
+
+
+def test_split_gemm_random_shapes_all_epilogues(dev):
+    """Ragged M / N / K (K % 16 == 0, GLU widths % 32 == 0) through every epilogue, both split modes, against float64."""
+    from conformer_amd import ops
+    import random
+    rnd = random.Random(7)
+    g = torch.Generator().manual_seed(7)
+    for it in range(36):
+        m = rnd.choice([1, 2, 31, 33, 64, 65, 127, 129, 200, 257, 700])
+        k = 16 * rnd.randint(1, 12)
+        epi = ("none", "swish", "relu", "resid", "glu")[it % 5]
+        n = 32 * rnd.randint(1, 6) if epi == "glu" else rnd.choice([1, 3, 8, 31, 32, 33, 64, 100, 129, 370])
+        a = torch.randn(m, k, generator=g).to(dev)
+        w = (torch.randn(2 * n if epi == "glu" else n, k, generator=g) / k ** 0.5).to(dev)
+        b = torch.randn(w.shape[0], generator=g).to(dev)
+        r = torch.randn(m, n, generator=g).to(dev)
+        z = torch.nn.functional.linear(a.double(), w.double(), b.double())
+        ref = {"none": lambda: z, "swish": lambda: z * torch.sigmoid(z), "relu": lambda: torch.relu(z),
+               "resid": lambda: 0.25 * z + r.double(), "glu": lambda: z[:, :n] * torch.sigmoid(z[:, n:])}[epi]()
+        for mode, tol in (("bf16x6", 2e-6), ("bf16x3", 1e-4)):
+            ops.set_fp32_matmul(mode)
+            y = {"none": lambda: ops.linear(a, w, b), "swish": lambda: ops.linear(a, w, b, "swish"),
+                 "relu": lambda: ops.linear(a, w, b, "relu"), "resid": lambda: ops.linear_residual(a, w, b, r, 0.25),
+                 "glu": lambda: ops.linear_glu(a, w, b)}[epi]()
+            assert y.shape == ref.shape
+            err = rel_l2(y, ref)
+            assert err < tol, f"{mode} {epi} M={m} N={n} K={k}: {err:.2e}"
