@@ -20,6 +20,8 @@
 // take 51 us (1.95 PFLOP/s, 78 % of the nominal bf16 peak -- the practical ceiling of the pipe), ~36 us are fixed
 // (65 MB epilogue, ramp, barriers), ~30 us are operand staging that is not yet hidden behind the MFMAs.  Three loop
 // structures (both operands through one LDS stage; K-tile 16 with two stages; this one) land within 5 % of each other.
+// Also measured and dropped: one LDS stage + three workgroups per CU for the 128x64 tile (the N = 512 GEMMs have only two
+// tiles per CU: -8 %), 64x64 tiles for those GEMMs (-15 %), letting the compiler schedule across the term groups (-8 %).
 #include "gemm_shared.h"
 
 namespace {
