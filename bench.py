@@ -1,8 +1,13 @@
 #!/usr/bin/env python3
 """Headline benchmark: Conformer-L encoder forward, audio(mel)-frames/sec on MI355X (BASELINE.json).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W]            # starts its own N ranks when no launcher did
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
+    python bench.py --train [--gpus N]                             # BASELINE cfg-3 / cfg-4: bf16 training step, B=64 per GPU, DDP
+
+Without RANK/WORLD_SIZE in the environment and with --gpus N > 1 this process is only a PARENT: it parses the arguments,
+starts N child processes of this same file with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT set
+(as the reference's train.py:364-379 spawns its own ranks) and relays rank 0's JSON line; it never touches the GPU itself.
 
 A "step" = one pass of the hot path (Encoder.forward: conv-subsampling stem -> input Linear -> 16 Conformer
 blocks) over one synthetic batch that is already resident in HBM.  Utterances shard over the batch axis, so
@@ -165,9 +170,138 @@ def pmc_traffic_bytes(kernel_substr: str):
     return None
 
 
+def _free_port() -> int:
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def launch_ranks(n: int, argv) -> int:
+    """Parent side of `bench.py --gpus N` when no launcher set RANK: one child per GPU, rendezvous on 127.0.0.1.
+    Rank 0 inherits stdout (its single JSON line is the result); the other ranks' stdout goes to stderr.  The first
+    failing child ends the job: the others are terminated by PID and its exit code is returned."""
+    import subprocess
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: RCCL needs it on this driver
+        env.setdefault("OMP_NUM_THREADS", str(max(1, host_cores() // n)))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *argv], env=env,
+                                      stdout=None if r == 0 else sys.stderr))
+    log(f"[bench] parent {os.getpid()}: started {n} ranks (pids {[p.pid for p in procs]}), rendezvous 127.0.0.1:{port}")
+    rc = 0
+    alive = list(procs)
+    while alive:
+        time.sleep(0.2)
+        for p in list(alive):
+            code = p.poll()
+            if code is None:
+                continue
+            alive.remove(p)
+            if code != 0 and rc == 0:
+                rc = code
+                log(f"[bench] rank process {p.pid} exited with {code}; stopping the other ranks")
+                for q in alive:
+                    q.terminate()
+    return rc
+
+
+def selftest_cpu(args, env):
+    """Plumbing only (no kernels, no GPU): the ranks this file started rendezvous over gloo and run the timing contract
+    on a trivial CPU step.  Exists so the N>1 launch path is exercised by `-m "not gpu"` tests."""
+    from conformer_amd import parallel
+    import torch.distributed as dist
+    started = parallel.init_distributed(env, torch.device("cpu"), backend="gloo")
+    a = torch.ones(64, 64)
+
+    def step():
+        (a @ a).sum().item()
+
+    dt = parallel.timed_steps(step, args.steps, args.warmup, lambda: None)
+    ranks = dist.get_world_size() if started else 1
+    seen = torch.zeros(ranks, dtype=torch.int64)
+    seen[env.rank] = 1 + env.local_rank
+    if started:
+        dist.all_reduce(seen)
+    if env.rank == 0:
+        print(json.dumps({"metric": "plumbing-selftest", "value": 0.0, "unit": "none", "n_gpus": env.world, "steps": args.steps,
+                          "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+                          "scaling": "weak", "vs_baseline": None, "dtype": "none", "data": "plumbing-selftest (no kernels)",
+                          "ranks": ranks, "collective_backend": "gloo" if started else None,
+                          "local_ranks_plus_one": seen.tolist(), "config": {"workload": "none"}}), flush=True)
+    if started:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def train_bench(args, env, dev, dist):
+    """BASELINE cfg-3 / cfg-4: one optimiser step of the reference's training loop (train.py:225-243) per "step":
+    Conformer-L under bf16 autocast -> CTC on fp32 logits -> backward (DDP all-reduce of the gradients over RCCL,
+    overlapped with the backward by the bucket hooks) -> Adam.  B=64 utterances per GPU, T=1000 mel frames, 40 target
+    tokens, train-mode BatchNorm, dropout 0.1 (the reference's default), synthetic data resident in HBM."""
+    from conformer_amd import parallel
+    from conformer_amd.evaluation import ConformerCriterion
+    from conformer_amd.optim import FusedAdam
+    from model.conformer import Conformer
+    B, T = 64, CFG["T"]
+    torch.manual_seed(0)
+    model = Conformer(370, CFG["n_mel"], CFG["n_blocks"], CFG["d"], CFG["n_heads"], CFG["ksize"], 640, 1, args.dropout).to(dev).train()
+    ddp = parallel.wrap_ddp(model, dev)
+    opt = FusedAdam(model.parameters(), lr=2e-5)
+    g = torch.Generator().manual_seed(100 + env.rank)
+    x = torch.randn(B, CFG["n_mel"], T, generator=g).to(dev)
+    lengths = torch.full((B,), T, dtype=torch.int64, device=dev)
+    targets = torch.randint(1, 370, (B, 40), generator=g).to(dev)
+    tlen = torch.full((B,), 40, dtype=torch.int64, device=dev)
+    crit = ConformerCriterion(blank_id=0)
+    last = {}
+
+    def step():
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            logits, out_len = ddp(x, lengths)
+            with torch.autocast("cuda", enabled=False):
+                loss = crit.ctc_loss(logits, targets, out_len, tlen)
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+        last["loss"] = loss
+
+    dt = parallel.timed_steps(step, args.steps, args.warmup, torch.cuda.synchronize, dev)
+    loss = float(last["loss"])
+    if not loss == loss:
+        raise SystemExit("non-finite training loss")
+    if env.rank == 0:
+        ms = dt / args.steps * 1e3
+        fwd = algorithmic_flops(B, T, CFG["d"], CFG["n_blocks"], CFG["ksize"])
+        print(json.dumps({
+            "metric": "training audio-frames/sec (Conformer-L bf16 autocast fwd+CTC+bwd+Adam, B=64/GPU, T=1000)",
+            "value": env.world * B * T * args.steps / dt, "unit": "audio-frames/sec", "n_gpus": env.world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16 MFMA operands, f32 accumulate / master weights / gradients (autocast)", "data": "synthetic",
+            "ranks": env.world, "collective_backend": (dist.get_backend() + " (RCCL)") if dist else None,
+            "config": {"workload": "cfg3/cfg4 Conformer-L training step: per-GPU B=64, T=1000 mel frames, 40 target tokens, "
+                                   f"dropout {args.dropout}, BatchNorm train, CTC fp32, FusedAdam, DDP gradient all-reduce",
+                       "per_gpu_batch": B, "global_batch": B * env.world, "mel_frames": T},
+            "encoder_fwd_bwd_tflops": 3 * fwd / (ms * 1e-3) / 1e12, "loss": loss,
+            "max_mem_gib": torch.cuda.max_memory_allocated() / 2 ** 30}), flush=True)
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--train", action="store_true",
+                    help="BASELINE cfg-3 (1 GPU) / cfg-4 (N GPUs): Conformer-L training step under bf16 autocast, B=64 per GPU, "
+                         "forward + CTC + backward + Adam, gradients all-reduced by DDP over RCCL")
+    ap.add_argument("--dropout", type=float, default=0.1, help="--train only (train.py default 0.1)")
+    ap.add_argument("--selftest-cpu", action="store_true",
+                    help="plumbing test only (tests/test_parallel_cpu.py): ranks rendezvous over gloo on the CPU and time a "
+                         "no-kernel step; the JSON line says so and carries value 0")
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -181,10 +315,20 @@ def main():
                          "computed from exact bf16 expansions of the fp32 operands (ops.set_fp32_matmul: six / three bf16 "
                          "MFMAs per K-step, fp32-class / 2^-15 error).  All but f32 are secondary results, never the default")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "RANK" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))          # parent only: nothing below runs in this process
 
     from conformer_amd import parallel
     env = parallel.env_from_os()
     world, rank, local = env.world, env.rank, env.local_rank
+    if args.gpus != world:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher set WORLD_SIZE={world}; start it as "
+                         f"`python bench.py --gpus {args.gpus}` (it spawns its own ranks) or as `python -m torch.distributed.run "
+                         f"--nnodes=1 --nproc-per-node {args.gpus} --master-addr 127.0.0.1 bench.py --gpus {args.gpus}`")
+    if args.selftest_cpu:
+        return selftest_cpu(args, env)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the Conformer hot path has no CPU fallback")
     torch.cuda.set_device(local)
@@ -193,8 +337,8 @@ def main():
     if parallel.init_distributed(env, dev):                 # backend "nccl" = RCCL on ROCm
         import torch.distributed as dist_
         dist = dist_
-    if args.gpus != world and rank == 0:
-        log(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; reporting n_gpus={world}")
+    if args.train:
+        return train_bench(args, env, dev, dist)
 
     from conformer_amd import _lib, ops
     _lib.check(_lib.load().cfm_device_check(), "cfm_device_check")
@@ -246,6 +390,7 @@ def main():
                   "f32x6": "f32 operands split exactly into 3 bf16 terms, 6 bf16 MFMAs per K-step, f32 accumulate/storage",
                   "f32x3": "f32 operands split into 2 bf16 terms, 3 bf16 MFMAs per K-step, f32 accumulate/storage"}[args.dtype],
         "data": "synthetic", "launch": "hipGraph replay" if graphed else "eager",
+        "ranks": world, "collective_backend": (dist.get_backend() + " (RCCL)") if dist else None,
         "config": {"workload": "cfg2 Conformer-L Encoder.forward: B=32/GPU, T=1000 mel frames (T'=249), d=512, 16 blocks, "
                                "8 heads, k=31, fp32, eval, random-init weights, batch-sharded replicas",
                    "per_gpu_batch": CFG["B"], "mel_frames": CFG["T"]},

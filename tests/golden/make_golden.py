@@ -20,11 +20,16 @@ import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
-sys.path.insert(0, ROOT)
-sys.path.insert(0, "/root/reference")
 sys.dont_write_bytecode = True
+# The repo's own ``model/`` (a regular package) would shadow the reference's ``model/`` (a namespace package) if the repo
+# root were importable, so only /root/reference goes on sys.path and the oracle is loaded by file path.
+sys.path = [p for p in sys.path if os.path.abspath(p or ".") != ROOT]
+sys.path.insert(0, "/root/reference")
+import importlib.util  # noqa: E402
 
-from oracle import conformer_oracle as O  # noqa: E402
+_spec = importlib.util.spec_from_file_location("conformer_oracle", os.path.join(ROOT, "oracle", "conformer_oracle.py"))
+O = importlib.util.module_from_spec(_spec)
+_spec.loader.exec_module(O)
 
 from model.conformer import Conformer  # noqa: E402  (reference)
 from model.modules.encoder import Encoder  # noqa: E402

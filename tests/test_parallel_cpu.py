@@ -81,3 +81,45 @@ def test_shard_range_properties():
             assert parts[0][0] == 0 and parts[-1][1] == n
             assert all(parts[i][1] == parts[i + 1][0] for i in range(w - 1))
             assert max(h - l for l, h in parts) - min(h - l for l, h in parts) <= 1
+
+
+def _run_bench(argv, env_extra=None, timeout=300):
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra or {})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *argv], env=env, capture_output=True, text=True,
+                       timeout=timeout)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    return r.returncode, [json.loads(l) for l in lines], r.stderr
+
+
+def test_bench_gpus_n_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher (WORLD_SIZE unset) must itself start two rank processes, rendezvous
+    them on 127.0.0.1 and print exactly ONE JSON line from rank 0 (the driver's scale command; reference train.py:364-379).
+    Plumbing only: --selftest-cpu swaps the kernels for a no-op step over gloo."""
+    rc, js, err = _run_bench(["--gpus", "2", "--steps", "3", "--warmup", "1", "--selftest-cpu"])
+    assert rc == 0, err
+    assert len(js) == 1
+    j = js[0]
+    assert j["n_gpus"] == 2 and j["ranks"] == 2 and j["collective_backend"] == "gloo"
+    assert j["local_ranks_plus_one"] == [1, 2]              # rank r ran with LOCAL_RANK r
+    assert j["steps"] == 3 and j["warmup"] == 1 and j["scaling"] == "weak"
+
+
+def test_bench_under_a_launcher_and_mismatch():
+    """Started by a launcher (RANK/WORLD_SIZE set) the file is a rank, not a parent; a --gpus that disagrees with
+    WORLD_SIZE is an error, not a silently relabelled single-rank run (round-1 finding)."""
+    rc, js, err = _run_bench(["--gpus", "1", "--selftest-cpu", "--steps", "2"], dict(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0"))
+    assert rc == 0 and js[0]["n_gpus"] == 1 and js[0]["ranks"] == 1, err
+    rc, js, err = _run_bench(["--gpus", "2", "--selftest-cpu"], dict(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0"))
+    assert rc != 0 and not js and "WORLD_SIZE=1" in err
+
+
+def test_bench_parent_propagates_a_failing_rank():
+    """Without a GPU every rank of the real bench exits non-zero (no CPU fallback); the parent must report failure."""
+    if torch.cuda.is_available():
+        pytest.skip("needs a GPU-less host")
+    rc, js, err = _run_bench(["--gpus", "2", "--steps", "1", "--warmup", "0"])
+    assert rc != 0 and not js
+    assert "no CPU fallback" in err

@@ -27,3 +27,21 @@ def cfg_params(meta, dtype=torch.float32):
     from oracle import conformer_oracle as O
     keys = ("vocab", "n_mel", "n_blocks", "d", "n_heads", "ksize", "lstm_hidden", "seed")
     return O.make_params(**{k: meta[k] for k in keys}, dtype=dtype)
+
+
+def golden_pick(t: torch.Tensor, key: str) -> torch.Tensor:
+    """The element selection a golden key was stored with: the whole tensor, or the strided sample ``flat[3::p]`` for keys
+    ending in ``@s<p>`` (tests/golden/make_golden_autocast.py)."""
+    if "@s" in key:
+        return t.detach().flatten()[3::int(key.rsplit("@s", 1)[1])]
+    return t.detach()
+
+
+def golden_find(g: dict, stem: str):
+    """Key of ``stem`` in a golden dict, with or without a sampling suffix; None if absent."""
+    if stem in g:
+        return stem
+    for k in g:
+        if k.startswith(stem + "@s"):
+            return k
+    return None
