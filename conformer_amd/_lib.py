@@ -10,7 +10,8 @@ import os
 from ctypes import c_char_p, c_float, c_int, c_int64, c_uint64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libconformer_hip.so")
+# (CONFORMER_AMD_LIB: A/B a differently built library from tools/*, development only)
+LIB_PATH = os.environ.get("CONFORMER_AMD_LIB") or os.path.join(_HERE, "lib", "libconformer_hip.so")
 
 _P, _I, _L, _F, _U = c_void_p, c_int, c_int64, c_float, c_uint64
 

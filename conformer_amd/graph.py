@@ -11,9 +11,21 @@ from typing import Optional, Tuple
 import torch
 
 
+def _weights_fingerprint(module: torch.nn.Module):
+    from conformer_amd.model.utils._guard import _EPOCH, _ver
+    return (_EPOCH[0],) + tuple((t.data_ptr(), _ver(t)) for t in list(module.parameters()) + list(module.buffers()))
+
+
 class GraphedEncoder:
     """Wraps an eval-mode Encoder for fixed (B, n_mel, T) inputs.  `lengths` is part of the static input (its VALUES may
-    change between replays: the attention kernel reads them from device memory)."""
+    change between replays: the attention kernel reads them from device memory).
+
+    Precondition: FROZEN WEIGHTS.  The captured graph holds the addresses of the parameters AND of the derived weight
+    copies built during warm-up (fused QKV matrix, packed conv / linear weights, projected position tables, 16-bit / split
+    planes).  Every call compares the (address, in-place version) of each parameter and buffer with the capture-time
+    record; after an optimizer step, `load_state_dict` or any in-place update the graph is captured again (the old one
+    is dropped first) instead of replaying stale packs.  Writes that bypass the version counter (`param.data.copy_`)
+    need `conformer_amd.model.utils._guard.invalidate_weight_caches()`, which this check also sees."""
 
     def __init__(self, encoder: torch.nn.Module, example_x: torch.Tensor, example_lengths: Optional[torch.Tensor],
                  warmup: int = 2) -> None:
@@ -22,6 +34,14 @@ class GraphedEncoder:
         self.encoder = encoder
         self.static_x = example_x.clone()
         self.static_len = None if example_lengths is None else example_lengths.clone()
+        self.warmup = warmup
+        self.captures = 0
+        self._capture()
+
+    def _capture(self) -> None:
+        encoder, warmup = self.encoder, self.warmup
+        self.graph = None                                # free the previous graph's pool before building the new one
+        self.static_y = self.static_out_len = None
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side), torch.no_grad():
@@ -32,10 +52,16 @@ class GraphedEncoder:
         self.graph = torch.cuda.CUDAGraph()
         with torch.no_grad(), torch.cuda.graph(self.graph):
             self.static_y, self.static_out_len = encoder(self.static_x, self.static_len)
+        self._fingerprint = _weights_fingerprint(encoder)
+        self.captures += 1
 
     def __call__(self, x: torch.Tensor, lengths: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
         if x.shape != self.static_x.shape:
             raise ValueError(f"graph captured for input {tuple(self.static_x.shape)}, got {tuple(x.shape)}")
+        if self.encoder.training:
+            raise ValueError("GraphedEncoder replays the inference path: the wrapped encoder was switched to .train()")
+        if _weights_fingerprint(self.encoder) != self._fingerprint:
+            self._capture()                              # weights changed since the capture: never replay stale packs
         if x.data_ptr() != self.static_x.data_ptr():
             self.static_x.copy_(x)
         if self.static_len is not None and lengths is not None and lengths.data_ptr() != self.static_len.data_ptr():

@@ -477,9 +477,42 @@ def linear_swish_save(a, w, b):
     return c, z
 
 
+_SEED_GEN = {}
+
+
+def _mix64(*vals: int) -> int:
+    z = 0x243F6A8885A308D3
+    for v in vals:
+        z = ((z ^ (v & 0xFFFFFFFFFFFFFFFF)) * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
+        z ^= z >> 29
+        z = (z * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
+        z ^= z >> 32
+    return z & 0x3FFFFFFFFFFFFFFF
+
+
+def _rank() -> int:
+    import os
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
+        return torch.distributed.get_rank()
+    return int(os.environ.get("RANK", "0"))
+
+
 def new_seeds(n: int):
-    """n dropout seeds from torch's default CPU generator (so torch.manual_seed makes training runs reproducible)."""
-    return [int(v) for v in torch.randint(0, 2 ** 62, (n,), dtype=torch.int64)]
+    """n dropout seeds (one per fused-dropout site and step).  They come from the (seed, offset) state of the current
+    device's default generator -- the state stock dropout kernels consume -- mixed with the data-parallel rank: the offset
+    advances by 4 per seed, torch.manual_seed() rewinds it (a re-seeded run replays its masks), replicas seeded alike draw
+    DIFFERENT masks, and the default CPU generator (SpecAugment's band draws) is neither consumed nor consulted."""
+    if torch.cuda.is_available():
+        g = torch.cuda.default_generators[torch.cuda.current_device()]
+        seed, off = g.initial_seed(), g.get_offset()
+        g.set_offset(off + 4 * n)
+        return [_mix64(seed, _rank(), off + 4 * i) for i in range(n)]
+    key = (torch.initial_seed(), _rank())                     # GPU-less hosts (host-logic tests only): a private counter
+    if _SEED_GEN.get("key") != key:
+        _SEED_GEN["key"], _SEED_GEN["off"] = key, 0
+    off = _SEED_GEN["off"]
+    _SEED_GEN["off"] = off + 4 * n
+    return [_mix64(key[0], key[1], off + 4 * i) for i in range(n)]
 
 
 def linear_train(epi: str, a, w, b, *, residual=None, alpha: float = 1.0, drop_p: float = 0.0, seed: int = 0,

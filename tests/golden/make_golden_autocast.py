@@ -46,17 +46,18 @@ from model.utils.position import RelativePositionalEncoding  # noqa: E402
 
 torch.set_num_threads(8)
 SAMPLE_ABOVE = 8000
-PRIMES = (3, 7, 13, 29, 61, 127, 251, 509, 1021)
+PRIMES = (3, 7, 13, 29, 61, 127, 251, 509, 1021, 2039, 4093, 8191, 16381)
 
 
 def sub(P, prefix):
     return {k[len(prefix):]: v.clone() for k, v in P.items() if k.startswith(prefix)}
 
 
-def put(out, key, t):
+def put(out, key, t, cap=None):
     t = t.detach().float().cpu()
-    if t.numel() > SAMPLE_ABOVE:
-        p = next(q for q in PRIMES if t.numel() / q <= SAMPLE_ABOVE)
+    cap = cap or SAMPLE_ABOVE
+    if t.numel() > cap:
+        p = next(q for q in PRIMES if t.numel() / q <= cap)
         out[f"{key}@s{p}"] = t.flatten()[3::p].contiguous().numpy()
     else:
         out[key] = t.numpy()
@@ -112,7 +113,7 @@ def module_cases(tag, d, H, K, B, T, lengths, seed):
     save(f"autocast_modules_{tag}", dict(cfg, B=B, T=T), out)
 
 
-def model_case(tag, vocab, n_blocks, d, H, K, hid, B, T, lengths, seed, tgt_len):
+def model_case(tag, vocab, n_blocks, d, H, K, hid, B, T, lengths, seed, tgt_len, cap=None):
     cfg = dict(vocab=vocab, n_mel=80, n_blocks=n_blocks, d=d, n_heads=H, ksize=K, lstm_hidden=hid, seed=seed)
     P = O.make_params(**cfg)
     g = torch.Generator().manual_seed(seed + 1)
@@ -120,7 +121,11 @@ def model_case(tag, vocab, n_blocks, d, H, K, hid, B, T, lengths, seed, tgt_len)
     L = torch.tensor(lengths, dtype=torch.int64)
     tg = torch.randint(1, vocab, (B, max(tgt_len)), generator=g)
     TL = torch.tensor(tgt_len, dtype=torch.int64)
-    out = dict(x=x.numpy(), lengths=L.numpy(), targets=tg.numpy(), target_lengths=TL.numpy())
+    out = dict(lengths=L.numpy(), targets=tg.numpy(), target_lengths=TL.numpy())
+    if cap is None:
+        out["x"] = x.numpy()          # (the big case regenerates x from the seed: same torch build, CPU generator)
+    else:
+        out["x_check"] = x.flatten()[::997].numpy()
     ctc = torch.nn.CTCLoss(blank=0, zero_infinity=True)                      # evaluation.py:10
     for prec in ("f32", "bf16"):
         model = Conformer(vocab, 80, n_blocks, d, H, K, hid, 1, 0.0).eval()
@@ -128,8 +133,8 @@ def model_case(tag, vocab, n_blocks, d, H, K, hid, B, T, lengths, seed, tgt_len)
         with torch.no_grad(), amp(prec == "bf16"):
             enc, L2 = model.encoder(x, L)
             logits, _ = model(x, L)
-        put(out, f"eval.{prec}.enc", enc)
-        put(out, f"eval.{prec}.logits", logits)
+        put(out, f"eval.{prec}.enc", enc, cap)
+        put(out, f"eval.{prec}.logits", logits, cap)
         out[f"eval.{prec}.argmax"] = logits.float().argmax(-1).numpy()
         out["out_lengths"] = L2.numpy()
         # one training step, train.py:225,232-240 (GradScaler is a no-op for bf16; dropout 0)
@@ -141,18 +146,22 @@ def model_case(tag, vocab, n_blocks, d, H, K, hid, B, T, lengths, seed, tgt_len)
                 loss = ctc(outputs.float().log_softmax(dim=-1).transpose(0, 1), tg.float(), xl, TL)   # evaluation.py:12-16
         loss.backward()
         out[f"train.{prec}.loss"] = np.array(float(loss))
-        put(out, f"train.{prec}.logits", outputs)
+        put(out, f"train.{prec}.logits", outputs, cap)
         for n, p_ in model.named_parameters():
             if p_.grad is not None:
-                put(out, f"train.{prec}.grad.{n}", p_.grad)
+                put(out, f"train.{prec}.grad.{n}", p_.grad, cap)
         for n, b_ in model.named_buffers():
             if n.endswith("running_mean") or n.endswith("running_var"):
-                put(out, f"train.{prec}.buf.{n}", b_)
+                put(out, f"train.{prec}.buf.{n}", b_, cap)
     save(f"autocast_model_{tag}", dict(cfg, B=B, T=T), out)
 
 
 if __name__ == "__main__":
     torch.manual_seed(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "L":
+        model_case("L_b4", vocab=370, n_blocks=16, d=512, H=8, K=31, hid=640, B=4, T=1000, lengths=[1000, 1000, 870, 640],
+                   seed=51, tgt_len=[40, 40, 33, 21], cap=1500)
+        sys.exit(0)
     module_cases("d32_t48", d=32, H=4, K=31, B=2, T=48, lengths=[48, 33], seed=12)
     module_cases("d144_t49", d=144, H=4, K=31, B=2, T=49, lengths=[49, 39], seed=14)
     # Conformer-L block geometry (cfg-2/3: d=512, H=8, K=31, T'=249)
@@ -161,3 +170,6 @@ if __name__ == "__main__":
                tgt_len=[5, 4, 2])
     model_case("cfg1_S", vocab=370, n_blocks=4, d=144, H=4, K=31, hid=320, B=2, T=200, lengths=[200, 160], seed=41,
                tgt_len=[12, 9])
+    # BASELINE cfg-3 geometry (Conformer-L: 16 blocks, d=512, H=8, lstm 640, vocab 370, T=1000 -> T'=249) at B=4
+    model_case("L_b4", vocab=370, n_blocks=16, d=512, H=8, K=31, hid=640, B=4, T=1000, lengths=[1000, 1000, 870, 640], seed=51,
+               tgt_len=[40, 40, 33, 21], cap=1500)

@@ -1,0 +1,62 @@
+"""Host-side caches and seed plumbing (no GPU): PackCache keys, cache invalidation, per-rank dropout seeds."""
+import os
+
+import torch
+
+from conformer_amd.model.utils import _guard
+
+
+def test_packcache_handles_inference_tensors_and_in_place_updates():
+    """Inference tensors carry no version counter (`_version` raises): the reference's infer.py / test.py run under
+    torch.inference_mode(), where cached packs and position tables are such tensors (round-1 advisor finding)."""
+    cache = _guard.PackCache()
+    with torch.inference_mode():
+        w = torch.ones(4, 4)
+        b = torch.zeros(4)
+    calls = []
+
+    def make():
+        calls.append(1)
+        return (w.sum() + b.sum()).clone()
+
+    v1 = cache.get("k", (w, b), make)
+    v2 = cache.get("k", (w, b), make)
+    assert v1 is v2 and len(calls) == 1
+    p = torch.nn.Parameter(torch.ones(3))
+    mk = lambda: p.detach().clone()
+    a = cache.get("p", (p,), mk)
+    assert cache.get("p", (p,), mk) is a
+    with torch.no_grad():
+        p.mul_(2.0)                                  # optimizer-step-like update: version bump -> rebuilt
+    a2 = cache.get("p", (p,), mk)
+    assert a2 is not a and float(a2[0]) == 2.0
+    p.data.copy_(torch.full((3,), 5.0))              # bypasses the version counter: invisible ...
+    assert cache.get("p", (p,), mk) is a2
+    _guard.invalidate_weight_caches()                # ... until the documented invalidation call
+    assert float(cache.get("p", (p,), mk)[0]) == 5.0
+
+
+def test_packcache_identity_not_only_address():
+    cache = _guard.PackCache()
+    t1 = torch.ones(8)
+    v1 = cache.get("k", (t1,), lambda: t1 * 2)
+    t2 = t1.detach()                                 # same storage address and version, different tensor object
+    v2 = cache.get("k", (t2,), lambda: t2 * 3)
+    assert v2 is not v1 and float(v2[0]) == 3.0
+
+
+def test_dropout_seeds_are_per_rank_and_leave_the_default_generator_alone(monkeypatch):
+    from conformer_amd import ops
+    torch.manual_seed(1234)
+    before = torch.get_rng_state().clone()
+    monkeypatch.setenv("RANK", "0")
+    s0 = ops.new_seeds(4)
+    assert torch.equal(torch.get_rng_state(), before)          # SpecAugment's band draws are not perturbed
+    monkeypatch.setenv("RANK", "1")
+    s1 = ops.new_seeds(4)
+    assert s0 != s1 and len(set(s0 + s1)) == 8                  # replicas seeded alike draw different masks
+    torch.manual_seed(1234)
+    monkeypatch.setenv("RANK", "0")
+    ops._SEED_GEN.clear()
+    assert ops.new_seeds(4) == s0                               # torch.manual_seed still reproduces a run
+    assert ops.new_seeds(4) != s0                               # and the stream advances from step to step

@@ -1,8 +1,8 @@
 """16-bit-MFMA path (torch.autocast with bfloat16, or float16 as the reference's --fp16 1): (a) forward and backward GEMMs
 against an fp64 product of the ROUNDED operands (tight: only fp32 accumulation error remains), (b) per-block output
 against the fp32 oracle within the north_star's 1e-2 rel for bf16 (each block is fed the oracle's fp32 input),
-(c) argmax indices of the cfg-1 model vs the fp32 golden, (d) a full training step under autocast (+GradScaler for fp16)
-against the fp32 golden gradients."""
+(c) the fp16 (reference AMP dtype) encoder gradients against the fp32 golden gradients.  The bf16 end-to-end and
+per-tensor gradient checks against the reference's OWN autocast goldens live in tests/test_autocast_golden_gpu.py."""
 import math
 
 import pytest
@@ -128,21 +128,21 @@ def test_mfma16_stem_backward_vs_fp32_path(dev, dt16):
     assert rel_l2(outs["lowp"][3], outs["f32"][3].double()) > 1e-6          # really took the 16-bit path
 
 
-@pytest.mark.parametrize("dt16", DT)
-def test_mfma16_encoder_grads_vs_fp32_golden(dev, dt16):
-    """model_tiny encoder: forward under autocast, backward of a (loss-scaled, as GradScaler does for fp16: train.py:217,
-    239-240) scalar; every parameter gradient vs the reference's fp32 gradients within the 16-bit budget."""
+def test_fp16_encoder_grads_vs_fp32_golden(dev):
+    """model_tiny encoder under float16 autocast (the reference's own AMP dtype, train.py:6,217,232-240), backward of a
+    loss-scaled scalar as GradScaler does: every parameter gradient vs the reference's fp32 gradients.  fp16 carries three
+    more mantissa bits than bf16; its budget here is 1e-2 per tensor end to end.  (bfloat16 is graded per tensor against
+    the reference's own autocast goldens in tests/test_autocast_golden_gpu.py.)"""
     from model.modules.encoder import Encoder
     meta, g = load_golden("model_tiny")
     P = cfg_params(meta)
     enc = Encoder(80, meta["n_blocks"], meta["d"], meta["n_heads"], meta["ksize"], 0.0)
     enc.load_state_dict({k[len("encoder."):]: v for k, v in P.items() if k.startswith("encoder.")}, strict=True)
     enc = enc.to(dev).eval()
-    with torch.autocast("cuda", dtype=dt16):
+    with torch.autocast("cuda", dtype=torch.float16):
         y, _ = enc(g["x"].to(dev), g["lengths"].to(dev))
     assert y.dtype == torch.float32
-    tol_y, tol_g = (2e-2, 8e-2) if dt16 == torch.bfloat16 else (3e-3, 1.5e-2)
-    assert 1e-6 < rel_l2(y, g["enc"]) < tol_y
+    assert 1e-6 < rel_l2(y, g["enc"]) < 3e-3
     scale = 1024.0
     ((y * g["w"].to(dev)).sum() * scale).backward()
     worst, checked = 0.0, 0
@@ -152,7 +152,7 @@ def test_mfma16_encoder_grads_vs_fp32_golden(dev, dt16):
             continue
         worst = max(worst, rel_l2(p.grad / scale, g[gk]))
         checked += 1
-    assert checked > 50 and worst < tol_g, worst
+    assert checked > 50 and worst < 1e-2, worst
 
 
 def test_block_bf16_within_1e2_of_fp32_oracle(dev):
@@ -176,26 +176,6 @@ def test_block_bf16_within_1e2_of_fp32_oracle(dev):
     assert 1e-5 < err < 1e-2, err            # really on the bf16 path, and inside the bf16 budget
     err16 = rel_l2(y16, ref)
     assert 1e-6 < err16 < 2e-3, err16        # fp16 operands carry 3 more mantissa bits
-
-
-def test_cfg1_model_bf16_argmax_and_drift(dev):
-    """BASELINE cfg-1 (Conformer-S): under bf16 autocast the encoder drifts < 2e-2 end to end (the reference's own CPU
-    bf16 autocast drifts 0.9e-2 after 4 blocks) and the CTC argmax indices agree with the fp32 reference
-    except at near-ties (reported, must be < 2 % of the frames)."""
-    from model.conformer import Conformer
-    meta, g = load_golden("model_cfg1_S")
-    P = cfg_params(meta)
-    m = Conformer(meta["vocab"], 80, meta["n_blocks"], meta["d"], meta["n_heads"], meta["ksize"], meta["lstm_hidden"], 1, 0.0)
-    m.load_state_dict(P, strict=True)
-    m = m.to(dev).eval()
-    x, L = g["x"].to(dev), g["lengths"].to(dev)
-    with torch.no_grad():
-        with torch.autocast("cuda", dtype=torch.bfloat16):
-            enc, L2 = m.encoder(x, L)
-        logits = m.decoder(enc, L2)
-    assert rel_l2(enc, g["enc"]) < 2e-2
-    mism = (logits.argmax(-1).cpu() != g["argmax"]).float().mean().item()
-    assert mism < 0.02, mism
 
 
 @pytest.mark.parametrize("dt16", DT)
@@ -237,7 +217,7 @@ def test_mfma16_attention_forward(dev, B, T, H, dh, lengths, dt16):
                                   v.double(), L)
     tol_p = 6e-3 if dt16 == torch.bfloat16 else 8e-4
     assert rel_l2(ctx, ref16) < tol_p
-    assert rel_l2(ctx, ref) < (2e-2 if dt16 == torch.bfloat16 else 3e-3)
+    assert rel_l2(ctx, ref) < (1e-2 if dt16 == torch.bfloat16 else 2e-3)
 
 
 @pytest.mark.parametrize("dt16", DT)

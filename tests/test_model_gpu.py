@@ -244,3 +244,48 @@ def test_graphed_encoder_matches_eager(dev):
         ref, _ = enc(x2, L3)
     y2, _ = ge(x2, L3)
     assert torch.equal(y2, ref)
+
+
+def test_graphed_encoder_recaptures_after_a_weight_update(dev):
+    """The captured graph holds addresses of derived weight packs: after an in-place weight update (optimizer step,
+    load_state_dict) a replay would compute with stale packs -- the wrapper must notice and capture again."""
+    from conformer_amd.graph import GraphedEncoder
+    from model.modules.encoder import Encoder
+    meta, g = load_golden("model_tiny")
+    P = cfg_params(meta)
+    enc = Encoder(80, meta["n_blocks"], meta["d"], meta["n_heads"], meta["ksize"], 0.0)
+    enc.load_state_dict({k[len("encoder."):]: v for k, v in P.items() if k.startswith("encoder.")}, strict=True)
+    enc = enc.to(dev).eval()
+    x, L = g["x"].to(dev), g["lengths"].to(dev)
+    ge = GraphedEncoder(enc, x, L)
+    y0 = ge(x, L)[0].clone()
+    assert ge.captures == 1
+    ge(x, L)
+    assert ge.captures == 1                                   # unchanged weights: plain replay
+    with torch.no_grad():
+        enc.layers[0].attention.attention.query_proj.weight.mul_(1.5)      # goes through the fused-QKV pack
+        enc.linear.weight.add_(0.01)                                       # goes through the packed input-linear weight
+        ref, _ = enc(x, L)
+    y1, _ = ge(x, L)
+    assert ge.captures == 2
+    assert torch.equal(y1, ref) and not torch.equal(y1, y0)
+
+
+def test_inference_mode_with_cached_projected_positions(dev):
+    """infer.py / test.py of the reference run under torch.inference_mode(): the cached packs and position tables are
+    then inference tensors (no version counter) -- the pack cache must accept them as keys (round-1 advisor finding)."""
+    from model.modules.encoder import Encoder
+    meta, g = load_golden("model_tiny")
+    P = cfg_params(meta)
+    enc = Encoder(80, meta["n_blocks"], meta["d"], meta["n_heads"], meta["ksize"], 0.0)
+    enc.load_state_dict({k[len("encoder."):]: v for k, v in P.items() if k.startswith("encoder.")}, strict=True)
+    enc = enc.to(dev).eval()
+    enc.cache_projected_positions = True
+    x, L = g["x"].to(dev), g["lengths"].to(dev)
+    with torch.inference_mode():
+        y1, _ = enc(x, L)
+        y2, _ = enc(x, L)
+    assert rel_l2(y1, g["enc"]) < 1e-4 and torch.equal(y1, y2)
+    with torch.no_grad():                                     # and the same module afterwards outside inference mode
+        y3, _ = enc(x, L)
+    assert torch.equal(y3, y1)
