@@ -685,9 +685,39 @@ def relpos_attention_train(qkv, pos, u, v, lengths, n_heads, drop_p: float = 0.0
 
 def relpos_attention_bwd(qkv, pos, u, v, lengths, n_heads, ctx, lse, dctx, drop_p: float = 0.0, seed: int = 0):
     """Backward of the attention core.  Returns (dqkv (B,T,3d), dpos (2T-1,d), du (H,dh), dv (H,dh)).
-    Round-1 form: batched MFMA GEMMs over re-materialised (B,H,T,T) tensors (attention_bwd_f32.hip).
-    Under autocast every product runs on the 16-bit matrix pipe with the operand rounding of the 16-bit forward kernel
-    (attention_mfma16.hip), so the recomputed probabilities match the forward's log-sum-exp."""
+    fp32: ONE fused flash-style kernel (attention_bwd_flash_f32.hip) that recomputes score tiles from the forward's
+    log-sum-exp -- no (B,H,T,T) / (H,B,T,2T-1) tensor is ever allocated."""
+    if not mfma16_prec() and not _FORCE_MATERIALISED_ATTN_BWD:
+        return _relpos_attention_bwd_flash(qkv, pos, u, v, lengths, n_heads, ctx, lse, dctx, drop_p, seed)
+    return _relpos_attention_bwd_materialised(qkv, pos, u, v, lengths, n_heads, ctx, lse, dctx, drop_p, seed)
+
+
+_FORCE_MATERIALISED_ATTN_BWD = False        # tools only: time the round-1 form against the fused kernel
+
+
+def _relpos_attention_bwd_flash(qkv, pos, u, v, lengths, n_heads, ctx, lse, dctx, drop_p: float = 0.0, seed: int = 0):
+    qkv = _req(qkv, "qkv"); pos = _req(pos, "pos"); ctx = _req(ctx, "ctx"); lse = _req(lse, "lse")
+    dctx = _req(dctx, "dctx")
+    B, T, d3 = qkv.shape
+    d = d3 // 3
+    dh = d // n_heads
+    ctx, dctx = ctx.contiguous(), dctx.contiguous()
+    P = 2 * T - 1
+    dqkv, dpos, du, dvb = _zeros_split(qkv.device, qkv.dtype, (B, T, d3), (P, d), (n_heads, dh), (n_heads, dh))
+    base, dbase = qkv.data_ptr(), dqkv.data_ptr()
+    st = _lib.load().cfm_relpos_attention_bwd_f32(base, base + 4 * d, base + 8 * d, d3, pos.data_ptr(), pos.stride(0),
+                                                  u.data_ptr(), v.data_ptr(), _p(lengths), ctx.data_ptr(), dctx.data_ptr(), d,
+                                                  lse.data_ptr(), dbase, dbase + 4 * d, dbase + 8 * d, d3, dpos.data_ptr(), d,
+                                                  du.data_ptr(), dvb.data_ptr(), B, T, n_heads, dh, float(drop_p), int(seed),
+                                                  _stream())
+    _lib.check(st, "cfm_relpos_attention_bwd_f32")
+    return dqkv, dpos, du, dvb
+
+
+def _relpos_attention_bwd_materialised(qkv, pos, u, v, lengths, n_heads, ctx, lse, dctx, drop_p: float = 0.0, seed: int = 0):
+    """Round-1 form, still used under autocast: batched MFMA GEMMs over re-materialised (B,H,T,T) tensors
+    (attention_bwd_f32.hip); every product runs on the 16-bit matrix pipe with the operand rounding of the 16-bit forward
+    kernel (attention_mfma16.hip), so the recomputed probabilities match the forward's log-sum-exp."""
     lib = _lib.load()
     B, T, d3 = qkv.shape
     d = d3 // 3

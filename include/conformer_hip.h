@@ -259,6 +259,18 @@ int cfm_attn_softmax_bwd_f32(float* content_to_p, float* posfull_to_dposfull, fl
 int cfm_add_strided_f32(float* dst, int64_t ld_dst, const float* src, int64_t ld_src, int64_t rows, int cols,
                         cfm_stream_t stream);
 
+/* ---- fused (flash-style) backward of the attention core: ONE launch, no (B,H,T,T) / (H,B,T,2T-1) tensor
+ *      (replaces autograd through model/utils/attention.py:47-72,94-102).  Arguments as cfm_relpos_attention_train_f32,
+ *      plus the forward's context `ctx` and log-sum-exp `lse` (B,H,T) and the context gradient `dctx` (layout of ctx,
+ *      row stride ldo).  dq / dk / dv: row stride ldg.  dq, dpos ((2T-1) rows, stride lddp), du and dvbias (H*dh) are
+ *      ACCUMULATED INTO with fp32 atomics (the caller zero-fills them); dk / dv are written. */
+int cfm_relpos_attention_bwd_f32(const float* q, const float* k, const float* v, int64_t ld, const float* pos,
+                                 int64_t ldp, const float* u, const float* vbias, const int64_t* lengths_or_null,
+                                 const float* ctx, const float* dctx, int64_t ldo, const float* lse, float* dq,
+                                 float* dk, float* dv, int64_t ldg, float* dpos, int64_t lddp, float* du,
+                                 float* dvbias, int B, int T, int H, int dh, float drop_p, uint64_t drop_seed,
+                                 cfm_stream_t stream);
+
 /* ---- tuning / diagnostics: the residual-epilogue GEMM with a forced block-tile shape
  *      (cfg 0..3 = 128x128, 128x64, 64x128, 64x64; -1 = built-in heuristic).  Same results for every cfg.
  *      trace_or_null: 8 x uint64 per block {start, main-loop end, HW_ID, XCC_ID, epilogue issued,

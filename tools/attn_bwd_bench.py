@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""Attention-core backward at cfg-2 / cfg-3 shapes: the fused flash kernel vs the round-1 materialising form (fp32), and
+the autocast (16-bit pipe) form.  Prints JSON lines."""
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from conformer_amd import ops  # noqa: E402
+
+dev = torch.device("cuda:0")
+
+
+def timeit(fn, iters=20):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e3
+
+
+for B in (32, 64):
+    T, d, H = 249, 512, 8
+    g = torch.Generator(device=dev).manual_seed(0)
+    qkv = torch.randn(B, T, 3 * d, device=dev, generator=g) * 0.5
+    pos = torch.randn(2 * T - 1, d, device=dev, generator=g) * 0.5
+    u = torch.randn(H, d // H, device=dev, generator=g) * 0.1
+    v = torch.randn(H, d // H, device=dev, generator=g) * 0.1
+    L = torch.full((B,), T, dtype=torch.int64, device=dev)
+    dy = torch.randn(B, T, d, device=dev, generator=g)
+    ctx, lse = ops.relpos_attention_train(qkv, pos, u, v, L, H)
+    flops = 10.0 * B * T * T * d + 2.0 * 2 * B * T * T * d        # 5 products + the two positional ones (algorithmic, 2*MAC)
+    row = {"B": B, "T": T, "d": d, "H": H}
+    row["flash_f32_us"] = timeit(lambda: ops.relpos_attention_bwd(qkv, pos, u, v, L, H, ctx, lse, dy))
+    mem0 = torch.cuda.max_memory_allocated()
+    ops._FORCE_MATERIALISED_ATTN_BWD = True
+    row["materialised_f32_us"] = timeit(lambda: ops.relpos_attention_bwd(qkv, pos, u, v, L, H, ctx, lse, dy))
+    ops._FORCE_MATERIALISED_ATTN_BWD = False
+    a = ops.relpos_attention_bwd(qkv, pos, u, v, L, H, ctx, lse, dy)
+    ops._FORCE_MATERIALISED_ATTN_BWD = True
+    b = ops.relpos_attention_bwd(qkv, pos, u, v, L, H, ctx, lse, dy)
+    ops._FORCE_MATERIALISED_ATTN_BWD = False
+    row["rel_l2_flash_vs_materialised"] = [float((x - y).norm() / y.norm()) for x, y in zip(a, b)]
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        c16, l16 = ops.relpos_attention_train(qkv, pos, u, v, L, H)
+        row["autocast_bf16_us"] = timeit(lambda: ops.relpos_attention_bwd(qkv, pos, u, v, L, H, c16, l16, dy))
+    row["flash_f32_tflops_algorithmic"] = flops / row["flash_f32_us"] / 1e6
+    print(json.dumps(row), flush=True)
