@@ -50,17 +50,24 @@ def algorithmic_flops(B, T, d, L, K, n_mel=80):
     return front + L * block
 
 
-def time_events(fn, iters, warm=2):
+def time_events(fn, iters, warm=2, inner=10):
+    """Mean launch duration in ms from HIP events on the launch stream (torch's current stream): `inner` back-to-back
+    launches between two events, repeated `iters` times (avg over everything, median over the repeats).  Back to back because
+    an event pair around EVERY launch also times the host-side gap of the Python call -- 5-10 % on the 40-150 us layer GEMMs
+    (round-1 site table vs rocprofv3: 155 vs 145 us on the FFN-hidden GEMM)."""
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(iters + 1)]
-    ev[0].record()
-    for i in range(iters):
-        fn()
-        ev[i + 1].record()
-    torch.cuda.synchronize()
-    ts = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(iters))
+    ts = []
+    for _ in range(iters):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(inner):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1) / inner)
+    ts.sort()
     return sum(ts) / len(ts), ts[len(ts) // 2]
 
 
@@ -108,7 +115,7 @@ def gemm_site_table(enc, x, iters):
     ]
     rows = []
     for name, (m, n, k), per_step, fn in sites:
-        avg, med = time_events(fn, iters)
+        avg, med = time_events(fn, max(3, iters // 3), inner=2 if "conv2" in name else 10)
         log(f"[bench] {name}: {m}x{n}x{k} avg {avg:.3f} ms  {2.0 * m * n * k / avg / 1e9:.1f} TFLOP/s")
         fl = 2.0 * m * n * k
         row = dict(kernel=name, M=m, N=n, K=k, launches_per_step=per_step, avg_ms=avg, med_ms=med,

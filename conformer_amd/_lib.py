@@ -54,13 +54,11 @@ SIGNATURES = {
     "cfm_glu_bwd_f32": (c_int, [_P, _P, _P, _L, _I, _P]),
     "cfm_dwconv_bn_swish_bwd_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _F, _I, _P, _P, _P, _P, _P, _P,
                                             _I, _I, _I, _I, _P]),
-    "cfm_dwconv_bn_stats_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _P]),
-    "cfm_attn_qbias_f32": (c_int, [_P, _L, _P, _P, _P, _P, _L, _I, _P]),
-    "cfm_attn_rowdot_f32": (c_int, [_P, _P, _P, _I, _I, _I, _I, _P]),
-    "cfm_attn_softmax_bwd_f32": (c_int, [_P, _P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _I, _F, _U, _P]),
-    "cfm_add_strided_f32": (c_int, [_P, _L, _P, _L, _L, _I, _P]),
+    "cfm_dwconv_bn_stats_workspace_bytes": (ctypes.c_size_t, [_I, _I, _I]),
+    "cfm_dwconv_bn_stats_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _P, ctypes.c_size_t, _P]),
+    "cfm_debug_attention_bwd_trace_f32": (c_int, [_P]),
     "cfm_relpos_attention_bwd_f32": (c_int, [_P, _P, _P, _L, _P, _L, _P, _P, _P, _P, _P, _L, _P, _P, _P, _P, _L, _P, _L, _P, _P,
-                                             _I, _I, _I, _I, _F, _U, _P]),
+                                             _I, _I, _I, _I, _F, _U, _I, _P]),
     "cfm_relu_bwd_f32": (c_int, [_P, _P, _P, _L, _P]),
     "cfm_subsample_conv2_bwd_weight_f32": (c_int, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "cfm_pack_conv2_weight_t_f32": (c_int, [_P, _P, _I, _P]),

@@ -255,15 +255,29 @@ __global__ __launch_bounds__(256) void dwconv_bn_swish_bwd_kernel(
     }
 }
 
-// ---- train-mode BatchNorm statistics of c = dwconv(g) + bias, two passes (mean, then centred second moment) --------------
-//   PASS 0: sum0[c] += sum c ;  PASS 1: sum0[c] += sum (c - mean[c])^2     (the conv is recomputed, c is never stored)
-template <int K, int TT, int PASS>
+// ---- train-mode BatchNorm statistics of c = dwconv(g) + bias: ONE pass over g, deterministic ----------------------------
+// The conv output of a chunk (TT frames x 64 channels) exists only in registers; each lane (channel) folds it into a running
+// (count, mean, M2 = sum of squared deviations) triple with Chan's pairwise update -- no E[x^2] - mean^2 cancellation -- the
+// four waves are merged through LDS in a fixed order and every workgroup writes ONE partial triple per channel to the
+// workspace.  A second kernel merges the partials of a channel in workgroup order (bit-reproducible: the round-1 version
+// accumulated sum and centred second moment with fp32 atomics in two passes over g, and its run-to-run rounding noise grew
+// to a full bf16 ulp in the logits of a 16-block model under autocast) and applies the running-statistics update.
+__device__ __forceinline__ void chan_merge(float& n, float& mean, float& m2, float nb, float mb, float m2b) {
+    if (nb > 0.f) {
+        const float nn = n + nb, d = mb - mean, f = nb / nn;
+        mean = fmaf(d, f, mean);
+        m2 = m2 + m2b + d * d * n * f;
+        n = nn;
+    }
+}
+
+template <int K, int TT>
 __global__ __launch_bounds__(256) void dwconv_stats_kernel(const float* __restrict__ g, const float* __restrict__ w,
-                                                           const float* __restrict__ bias, const float* __restrict__ mean,
-                                                           float* __restrict__ sum0, int T, int C, int seg_len) {
+                                                           const float* __restrict__ bias, float* __restrict__ part,
+                                                           int T, int C, int seg_len) {
     constexpr int HALF = (K - 1) / 2;
     __shared__ float taps[64 * K];
-    __shared__ float red[4][64];
+    __shared__ float red[4][3][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + lane;
     const int b = blockIdx.z;
@@ -273,11 +287,10 @@ __global__ __launch_bounds__(256) void dwconv_stats_kernel(const float* __restri
     float wr[K];
     load_taps<K>(w, blockIdx.x * 64, C, taps, wr);
     const float bi = bias[cc];
-    const float mu = PASS == 1 ? mean[cc] : 0.f;
     const float* gb = g + (int64_t)b * T * C + cc;
-    float s = 0.f;
-    for (int t0 = seg0 + wave * TT; t0 < seg1; t0 += 4 * TT) {          // one atomic per channel per WORKGROUP below:
-        float acc[TT];                                                   // same-address atomics serialise in L2
+    float n = 0.f, mean = 0.f, m2 = 0.f;
+    for (int t0 = seg0 + wave * TT; t0 < seg1; t0 += 4 * TT) {
+        float acc[TT];
 #pragma unroll
         for (int o = 0; o < TT; ++o) acc[o] = bi;
         float win[TT + K - 1];
@@ -286,29 +299,54 @@ __global__ __launch_bounds__(256) void dwconv_stats_kernel(const float* __restri
         for (int o = 0; o < TT; ++o)
 #pragma unroll
             for (int j = 0; j < K; ++j) acc[o] = fmaf(wr[j], win[o + j], acc[o]);
+        const int m = min(TT, seg1 - t0);                                 // valid frames of this chunk (wave-uniform)
+        float cs = 0.f;
 #pragma unroll
-        for (int o = 0; o < TT; ++o)
-            if (t0 + o < seg1) s += PASS == 0 ? acc[o] : (acc[o] - mu) * (acc[o] - mu);
+        for (int o = 0; o < TT; ++o) cs += o < m ? acc[o] : 0.f;
+        const float cm = cs / (float)m;
+        float cm2 = 0.f;
+#pragma unroll
+        for (int o = 0; o < TT; ++o) cm2 += o < m ? (acc[o] - cm) * (acc[o] - cm) : 0.f;
+        chan_merge(n, mean, m2, (float)m, cm, cm2);
     }
-    red[wave][lane] = s;
+    red[wave][0][lane] = n; red[wave][1][lane] = mean; red[wave][2][lane] = m2;
     __syncthreads();
-    if (wave == 0 && cok) atomicAdd(sum0 + c, (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]));
+    if (wave == 0 && cok) {
+        float N = red[0][0][lane], M = red[0][1][lane], Q = red[0][2][lane];
+#pragma unroll
+        for (int v = 1; v < 4; ++v) chan_merge(N, M, Q, red[v][0][lane], red[v][1][lane], red[v][2][lane]);
+        float* p = part + (int64_t)(blockIdx.z * gridDim.y + blockIdx.y) * 3 * C;
+        p[c] = N; p[C + c] = M; p[2 * C + c] = Q;
+    }
 }
 
-// mean = sum/n; var = m2/n (biased); running <- (1-mom)*running + mom*{mean, var*n/(n-1)}   (convolution.py:16 defaults)
-__global__ void bn_finalize_kernel(float* __restrict__ sum_to_mean, float inv_n, int C) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c < C) sum_to_mean[c] *= inv_n;
-}
-__global__ void bn_update_kernel(float* __restrict__ m2_to_var, const float* __restrict__ mean,
-                                 float* __restrict__ run_mean, float* __restrict__ run_var, float inv_n, float unbias,
-                                 float momentum, int C) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    const float var = m2_to_var[c] * inv_n;
-    m2_to_var[c] = var;
-    if (run_mean) run_mean[c] = (1.0f - momentum) * run_mean[c] + momentum * mean[c];
-    if (run_var) run_var[c] = (1.0f - momentum) * run_var[c] + momentum * var * unbias;
+// mean / biased variance of a channel = the ordered merge of its workgroup partials (workgroup = 64 channels; wave v folds
+// the v-th quarter of the partials in index order, wave 0 then folds the four results in wave order: a fixed tree);
+// running <- (1-mom)*running + mom*{mean, var*n/(n-1)}   (convolution.py:16 defaults)
+__global__ __launch_bounds__(256) void bn_merge_update_kernel(const float* __restrict__ part, int nblk,
+                                                              float* __restrict__ batch_mean, float* __restrict__ batch_var,
+                                                              float* __restrict__ run_mean, float* __restrict__ run_var,
+                                                              float momentum, int C) {
+    __shared__ float red[4][3][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    const int cc = c < C ? c : C - 1;
+    const int per = (nblk + 3) / 4, i0 = wave * per, i1 = min(nblk, i0 + per);
+    float n = 0.f, mean = 0.f, m2 = 0.f;
+    for (int i = i0; i < i1; ++i) {
+        const float* p = part + (int64_t)i * 3 * C;
+        chan_merge(n, mean, m2, p[cc], p[C + cc], p[2 * C + cc]);
+    }
+    red[wave][0][lane] = n; red[wave][1][lane] = mean; red[wave][2][lane] = m2;
+    __syncthreads();
+    if (wave != 0 || c >= C) return;
+#pragma unroll
+    for (int v = 1; v < 4; ++v) chan_merge(n, mean, m2, red[v][0][lane], red[v][1][lane], red[v][2][lane]);
+    const float var = m2 / n;
+    batch_mean[c] = mean;
+    batch_var[c] = var;
+    if (run_mean) run_mean[c] = (1.0f - momentum) * run_mean[c] + momentum * mean;
+    if (run_var) run_var[c] = (1.0f - momentum) * run_var[c] + momentum * (n > 1.f ? m2 / (n - 1.f) : var);
 }
 
 // plain depthwise correlation y[t] = sum_j w[FLIP ? K-1-j : j] x[t+j-H] (no bias): the input-gradient pass
@@ -447,29 +485,40 @@ extern "C" int cfm_dwconv_bn_swish_bwd_f32(const float* g, const float* dy, cons
 
 // Train-mode BatchNorm statistics of the depthwise-conv output (convolution.py:26-27 in .train()): batch_mean,
 // batch_var (biased) over all B*T positions (padded frames included); running_mean/var (may be NULL)
-// updated in place with `momentum` and the unbiased variance.  The conv output is recomputed, never stored.
+// updated in place with `momentum` and the unbiased variance.  The conv output is recomputed, never stored; one pass
+// over g; bit-reproducible (no atomics).  workspace: cfm_dwconv_bn_stats_workspace_bytes(B, T, C) bytes.
+static void dwconv_stats_geometry(int B, int T, int C, int* cblocks, int* nseg, int* seg_len) {
+    constexpr int TT = 16;
+    *cblocks = (C + 63) / 64;
+    int ns = (1024 + *cblocks * B - 1) / (*cblocks * B);                 // >= ~4 workgroups per CU
+    ns = ns < 1 ? 1 : ns;
+    int sl = (T + ns - 1) / ns;
+    sl = (sl + 4 * TT - 1) / (4 * TT) * (4 * TT);
+    *seg_len = sl;
+    *nseg = (T + sl - 1) / sl;
+}
+
+extern "C" size_t cfm_dwconv_bn_stats_workspace_bytes(int B, int T, int C) {
+    if (B <= 0 || T <= 0 || C <= 0) return 0;
+    int cblocks, nseg, seg_len;
+    dwconv_stats_geometry(B, T, C, &cblocks, &nseg, &seg_len);
+    return (size_t)B * nseg * 3 * C * sizeof(float);
+}
+
 extern "C" int cfm_dwconv_bn_stats_f32(const float* g, const float* w, const float* bias, float* batch_mean,
                                        float* batch_var, float* running_mean_or_null, float* running_var_or_null,
-                                       float momentum, int B, int T, int C, int K, cfm_stream_t stream) {
-    CFM_REQUIRE(g && w && bias && batch_mean && batch_var, CFM_ERR_NULL);
+                                       float momentum, int B, int T, int C, int K, void* workspace,
+                                       size_t workspace_bytes, cfm_stream_t stream) {
+    CFM_REQUIRE(g && w && bias && batch_mean && batch_var && workspace, CFM_ERR_NULL);
     CFM_REQUIRE(B > 0 && T > 0 && C > 0 && K > 0 && (K & 1) == 1, CFM_ERR_BAD_SHAPE);
+    CFM_REQUIRE(workspace_bytes >= cfm_dwconv_bn_stats_workspace_bytes(B, T, C), CFM_ERR_BAD_SHAPE);
     hipStream_t s = static_cast<hipStream_t>(stream);
     constexpr int TT = 16;
-    const int64_t n = (int64_t)B * T;
-    const int cblocks = (C + 63) / 64;
-    int nseg = (1024 + cblocks * B - 1) / (cblocks * B);                 // >= ~4 workgroups per CU, as few atomics as possible
-    nseg = nseg < 1 ? 1 : nseg;
-    int seg_len = (T + nseg - 1) / nseg;
-    seg_len = (seg_len + 4 * TT - 1) / (4 * TT) * (4 * TT);
-    nseg = (T + seg_len - 1) / seg_len;
+    int cblocks, nseg, seg_len;
+    dwconv_stats_geometry(B, T, C, &cblocks, &nseg, &seg_len);
     const dim3 grid((unsigned)cblocks, (unsigned)nseg, (unsigned)B), block(256);
-    const unsigned cb = (unsigned)((C + 255) / 256);
-    if (hipMemsetAsync(batch_mean, 0, sizeof(float) * C, s) != hipSuccess) return CFM_ERR_LAUNCH;
-    if (hipMemsetAsync(batch_var, 0, sizeof(float) * C, s) != hipSuccess) return CFM_ERR_LAUNCH;
-#define DWS(KK)                                                                                                        \
-    hipLaunchKernelGGL((dwconv_stats_kernel<KK, TT, 0>), grid, block, 0, s, g, w, bias, nullptr, batch_mean, T, C, seg_len); \
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cb), dim3(256), 0, s, batch_mean, 1.0f / (float)n, C);                  \
-    hipLaunchKernelGGL((dwconv_stats_kernel<KK, TT, 1>), grid, block, 0, s, g, w, bias, batch_mean, batch_var, T, C, seg_len)
+    float* part = static_cast<float*>(workspace);
+#define DWS(KK) hipLaunchKernelGGL((dwconv_stats_kernel<KK, TT>), grid, block, 0, s, g, w, bias, part, T, C, seg_len)
     switch (K) {
         case 31: DWS(31); break;
         case 15: DWS(15); break;
@@ -478,7 +527,7 @@ extern "C" int cfm_dwconv_bn_stats_f32(const float* g, const float* w, const flo
         default: return CFM_ERR_UNSUPPORTED;
     }
 #undef DWS
-    hipLaunchKernelGGL(bn_update_kernel, dim3(cb), dim3(256), 0, s, batch_var, batch_mean, running_mean_or_null,
-                       running_var_or_null, 1.0f / (float)n, n > 1 ? (float)n / (float)(n - 1) : 1.0f, momentum, C);
+    hipLaunchKernelGGL(bn_merge_update_kernel, dim3((unsigned)cblocks), dim3(256), 0, s, part, B * nseg, batch_mean,
+                       batch_var, running_mean_or_null, running_var_or_null, momentum, C);
     return cfm_launch_status();
 }

@@ -635,10 +635,12 @@ def dwconv_bn_batch_stats(g, w, b, running_mean, running_var, momentum: float = 
     g = _req(g, "g")
     B, T, C = g.shape
     K = w.shape[-1]
-    mean = torch.empty(C, device=g.device, dtype=g.dtype)
-    var = torch.empty(C, device=g.device, dtype=g.dtype)
-    st = _lib.load().cfm_dwconv_bn_stats_f32(g.data_ptr(), w.data_ptr(), b.data_ptr(), mean.data_ptr(), var.data_ptr(),
-                                             _p(running_mean), _p(running_var), momentum, B, T, C, K, _stream())
+    lib = _lib.load()
+    nws = int(lib.cfm_dwconv_bn_stats_workspace_bytes(B, T, C))
+    buf = torch.empty(2 * C + (nws + 3) // 4, device=g.device, dtype=g.dtype)     # mean | var | per-workgroup partials
+    mean, var, ws = buf[:C], buf[C:2 * C], buf[2 * C:]
+    st = lib.cfm_dwconv_bn_stats_f32(g.data_ptr(), w.data_ptr(), b.data_ptr(), mean.data_ptr(), var.data_ptr(),
+                                     _p(running_mean), _p(running_var), momentum, B, T, C, K, ws.data_ptr(), nws, _stream())
     _lib.check(st, "cfm_dwconv_bn_stats_f32")
     return mean, var
 
@@ -685,17 +687,11 @@ def relpos_attention_train(qkv, pos, u, v, lengths, n_heads, drop_p: float = 0.0
 
 def relpos_attention_bwd(qkv, pos, u, v, lengths, n_heads, ctx, lse, dctx, drop_p: float = 0.0, seed: int = 0):
     """Backward of the attention core.  Returns (dqkv (B,T,3d), dpos (2T-1,d), du (H,dh), dv (H,dh)).
-    fp32: ONE fused flash-style kernel (attention_bwd_flash_f32.hip) that recomputes score tiles from the forward's
-    log-sum-exp -- no (B,H,T,T) / (H,B,T,2T-1) tensor is ever allocated."""
-    if not mfma16_prec() and not _FORCE_MATERIALISED_ATTN_BWD:
-        return _relpos_attention_bwd_flash(qkv, pos, u, v, lengths, n_heads, ctx, lse, dctx, drop_p, seed)
-    return _relpos_attention_bwd_materialised(qkv, pos, u, v, lengths, n_heads, ctx, lse, dctx, drop_p, seed)
-
-
-_FORCE_MATERIALISED_ATTN_BWD = False        # tools only: time the round-1 form against the fused kernel
-
-
-def _relpos_attention_bwd_flash(qkv, pos, u, v, lengths, n_heads, ctx, lse, dctx, drop_p: float = 0.0, seed: int = 0):
+    ONE fused flash-style kernel (attention_bwd_flash_f32.hip) that recomputes score tiles from the forward's
+    log-sum-exp: no (B,H,T,T) / (H,B,T,2T-1) tensor is ever allocated (the reference's autograd keeps both,
+    attention.py:49-70).  Under autocast the score operands are rounded as the 16-bit forward kernel rounded them
+    (attention_mfma16.hip), so the recomputed probabilities match its log-sum-exp; the products themselves run on
+    the fp32 matrix pipe (a 16-bit variant of the fused kernel is not built)."""
     qkv = _req(qkv, "qkv"); pos = _req(pos, "pos"); ctx = _req(ctx, "ctx"); lse = _req(lse, "lse")
     dctx = _req(dctx, "dctx")
     B, T, d3 = qkv.shape
@@ -709,83 +705,8 @@ def _relpos_attention_bwd_flash(qkv, pos, u, v, lengths, n_heads, ctx, lse, dctx
                                                   u.data_ptr(), v.data_ptr(), _p(lengths), ctx.data_ptr(), dctx.data_ptr(), d,
                                                   lse.data_ptr(), dbase, dbase + 4 * d, dbase + 8 * d, d3, dpos.data_ptr(), d,
                                                   du.data_ptr(), dvb.data_ptr(), B, T, n_heads, dh, float(drop_p), int(seed),
-                                                  _stream())
+                                                  mfma16_prec(), _stream())
     _lib.check(st, "cfm_relpos_attention_bwd_f32")
-    return dqkv, dpos, du, dvb
-
-
-def _relpos_attention_bwd_materialised(qkv, pos, u, v, lengths, n_heads, ctx, lse, dctx, drop_p: float = 0.0, seed: int = 0):
-    """Round-1 form, still used under autocast: batched MFMA GEMMs over re-materialised (B,H,T,T) tensors
-    (attention_bwd_f32.hip); every product runs on the 16-bit matrix pipe with the operand rounding of the 16-bit forward
-    kernel (attention_mfma16.hip), so the recomputed probabilities match the forward's log-sum-exp."""
-    lib = _lib.load()
-    B, T, d3 = qkv.shape
-    d = d3 // 3
-    H = n_heads
-    dh = d // H
-    N = B * T
-    P = 2 * T - 1
-    T4, P4 = (T + 3) // 4 * 4, (P + 3) // 4 * 4
-    dev, dt = qkv.device, qkv.dtype
-    dctx = _req(dctx, "dctx")
-    f = 4  # bytes
-    qp = qkv.data_ptr(); kp = qp + f * d; vp = qp + 2 * f * d
-    ldp = pos.stride(0)
-    scale = 1.0 / float(dh) ** 0.5
-    qu = torch.empty(N, d, device=dev, dtype=dt)
-    qv = torch.empty(N, d, device=dev, dtype=dt)
-    _lib.check(lib.cfm_attn_qbias_f32(qp, d3, u.data_ptr(), v.data_ptr(), qu.data_ptr(), qv.data_ptr(), N, d, _stream()),
-               "cfm_attn_qbias_f32")
-    Dr = torch.empty(B, H, T, device=dev, dtype=dt)
-    _lib.check(lib.cfm_attn_rowdot_f32(dctx.data_ptr(), ctx.data_ptr(), Dr.data_ptr(), B, T, H, dh, _stream()),
-               "cfm_attn_rowdot_f32")
-    content = torch.empty(B, H, T, T4, device=dev, dtype=dt)
-    dP = torch.empty(B, H, T, T4, device=dev, dtype=dt)
-    posfull = torch.empty(H, B, T, P4, device=dev, dtype=dt)
-    sBH_rows = (T * d, dh)            # (b,h) offsets into an (N, d) row-major tensor: b*T*d + h*dh
-    sBH_qkv = (T * d3, dh)            # same for a slot of the fused (N, 3d) tensor
-    sBH_sq = (H * T * T4, T * T4)     # (b,h) offsets into (B,H,T,T4)
-    sBH_pf = (T * P4, B * T * P4)     # (b,h) offsets into (H,B,T,P4)
-    nb = B * H
-    lp = mfma16_prec()
-    # content[b,h] = Qu_bh . K_bh^T        (T x T into rows of T4 floats; the pad columns are never read: the softmax
-    # kernel overwrites them with 0.  J must be T, not T4: with J = T4 the last batch element would read up to three K
-    # rows past the end of qkv)
-    gemm_bwd(qu, False, qkv, False, T, T, dh, out=content, lda=d, ldb=d3, ldc=T4, nbatch=nb, nb1=H,
-             sa=sBH_rows, sb=sBH_qkv, sc=sBH_sq, b_ptr=kp, prec=lp)
-    # posfull[h,b] = Qv_bh . Pm_h^T        (T x P4)
-    gemm_bwd(qv, False, pos, False, T, P, dh, out=posfull, lda=d, ldb=ldp, ldc=P4, nbatch=nb, nb1=H,
-             sa=sBH_rows, sb=(0, dh), sc=sBH_pf, prec=lp)
-    # dP[b,h] = dO_bh . V_bh^T
-    gemm_bwd(dctx, False, qkv, False, T, T, dh, out=dP, lda=d, ldb=d3, ldc=T4, nbatch=nb, nb1=H,
-             sa=sBH_rows, sb=sBH_qkv, sc=sBH_sq, b_ptr=vp, prec=lp)
-    _lib.check(lib.cfm_attn_softmax_bwd_f32(content.data_ptr(), posfull.data_ptr(), dP.data_ptr(), lse.data_ptr(),
-                                            Dr.data_ptr(), _p(lengths), scale, B, T, H, T4, P4, float(drop_p), int(seed),
-                                            _stream()),
-               "cfm_attn_softmax_bwd_f32")
-    Pm, dS, dpf = content, dP, posfull                      # in-place results
-    dqkv = torch.empty(B, T, d3, device=dev, dtype=dt)
-    dq_p = dqkv.data_ptr(); dk_p = dq_p + f * d; dv_p = dq_p + 2 * f * d
-    # dV_bh = P_bh^T . dO_bh               (A = P contraction-major over queries; B = dO contraction-major)
-    gemm_bwd(Pm, True, dctx, True, T, dh, T, out=dqkv, lda=T4, ldb=d, ldc=d3, nbatch=nb, nb1=H,
-             sa=sBH_sq, sb=sBH_rows, sc=sBH_qkv, c_ptr=dv_p, prec=lp, pad4=True)
-    # dK_bh = dS_bh^T . Qu_bh
-    gemm_bwd(dS, True, qu, True, T, dh, T, out=dqkv, lda=T4, ldb=d, ldc=d3, nbatch=nb, nb1=H,
-             sa=sBH_sq, sb=sBH_rows, sc=sBH_qkv, c_ptr=dk_p, prec=lp, pad4=True)
-    # dQu_bh = dS_bh . K_bh                (contraction over keys: dS index-major, K contraction-major)
-    gemm_bwd(dS, False, qkv, True, T, dh, T, out=dqkv, lda=T4, ldb=d3, ldc=d3, nbatch=nb, nb1=H,
-             sa=sBH_sq, sb=sBH_qkv, sc=sBH_qkv, b_ptr=kp, c_ptr=dq_p, prec=lp, pad4=True)
-    du, dvb, dpos = _zeros_split(dev, dt, (H, dh), (H, dh), (P, d))
-    colsum(dqkv, rows=N, cols=d, ld=d3, out=du)
-    # dQv_bh = dposfull_hb . Pm_h          (contraction over the 2T-1 relative positions)
-    dqv = torch.empty(N, d, device=dev, dtype=dt)
-    gemm_bwd(dpf, False, pos, True, T, dh, P, out=dqv, lda=P4, ldb=ldp, ldc=d, nbatch=nb, nb1=H,
-             sa=sBH_pf, sb=(0, dh), sc=sBH_rows, prec=lp, pad4=True)
-    colsum(dqv, out=dvb)
-    _lib.check(lib.cfm_add_strided_f32(dq_p, d3, dqv.data_ptr(), d, N, d, _stream()), "cfm_add_strided_f32")
-    # dPm_h = sum_{b,i} dposfull_h[(b,i), :]^T . Qv_h[(b,i), :]     (contraction over B*T rows, split + atomics)
-    gemm_bwd(dpf, True, qv, True, P, dh, N, out=dpos, lda=P4, ldb=d, ldc=d, allow_split=True, nbatch=H, nb1=H,
-             sa=(0, B * T * P4), sb=(0, dh), sc=(0, dh), prec=lp, pad4=True)
     return dqkv, dpos, du, dvb
 
 

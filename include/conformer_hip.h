@@ -122,6 +122,7 @@ int cfm_pack_linear_weight_f32(const float* wl, float* wlp, int d_out, int C, in
  *      (cfm_gemm_train_f32 for Z_or_null / drop_p / drop_seed; for GLU, N = n_out and W has 2*n_out rows).
  *      The *_bwd_* entries mirror cfm_gemm_bwd_batched_f32 / cfm_subsample_conv2_bwd_{weight,input}_f32 (the stem
  *      forms need C % 64 == 0). */
+#define CFM_PREC_F32 0
 #define CFM_PREC_BF16 1
 #define CFM_PREC_FP16 2
 int cfm_gemm_mfma16_f32(int prec, int epi, const void* A, int a_is_16bit, const void* W, int w_is_16bit,
@@ -238,38 +239,30 @@ int cfm_dwconv_bn_swish_bwd_f32(const float* g, const float* dy, const float* w,
 /* Train-mode BatchNorm1d statistics of the depthwise-conv output (convolution.py:26-27 under .train()):
  * batch_mean / batch_var (biased) over all B*T positions, padded frames included; running_mean/var (or NULL)
  * updated in place: running = (1-momentum)*running + momentum*{mean, unbiased var}.  Feed batch_mean/var to
- * cfm_dwconv_bn_swish_fwd_f32 as bn_mean/bn_var for the train-mode forward. */
+ * cfm_dwconv_bn_swish_fwd_f32 as bn_mean/bn_var for the train-mode forward.  One pass over g, bit-reproducible
+ * (per-workgroup (count, mean, M2) partials in `workspace`, merged in a fixed order; no atomics). */
+size_t cfm_dwconv_bn_stats_workspace_bytes(int B, int T, int C);
 int cfm_dwconv_bn_stats_f32(const float* g, const float* w, const float* bias, float* batch_mean,
                             float* batch_var, float* running_mean_or_null, float* running_var_or_null,
-                            float momentum, int B, int T, int C, int K, cfm_stream_t stream);
-
-/* Glue kernels of the attention backward (attention_bwd_f32.hip; the products are cfm_gemm_bwd_batched_f32):
- *   qbias      : qu = q + u_h, qv = q + vbias_h                  (rows = B*T, d = H*dh; u/vbias flattened (d))
- *   rowdot     : D[b,h,i] = sum_c dO*O
- *   softmax_bwd: in place  content (B,H,T,T4) -> P;  posfull (H,B,T,P4) -> dposfull;  dP (B,H,T,T4) -> dS
- *   add_strided: dst += src                                                                        */
-int cfm_attn_qbias_f32(const float* q, int64_t ld, const float* u, const float* vbias, float* qu, float* qv,
-                       int64_t rows, int d, cfm_stream_t stream);
-int cfm_attn_rowdot_f32(const float* dO, const float* O, float* D, int B, int T, int H, int dh,
-                        cfm_stream_t stream);
-int cfm_attn_softmax_bwd_f32(float* content_to_p, float* posfull_to_dposfull, float* dp_to_ds,
-                             const float* lse, const float* D, const int64_t* lengths_or_null, float scale,
-                             int B, int T, int H, int T4, int P4, float drop_p, uint64_t drop_seed,
-                             cfm_stream_t stream);
-int cfm_add_strided_f32(float* dst, int64_t ld_dst, const float* src, int64_t ld_src, int64_t rows, int cols,
-                        cfm_stream_t stream);
+                            float momentum, int B, int T, int C, int K, void* workspace, size_t workspace_bytes,
+                            cfm_stream_t stream);
 
 /* ---- fused (flash-style) backward of the attention core: ONE launch, no (B,H,T,T) / (H,B,T,2T-1) tensor
  *      (replaces autograd through model/utils/attention.py:47-72,94-102).  Arguments as cfm_relpos_attention_train_f32,
  *      plus the forward's context `ctx` and log-sum-exp `lse` (B,H,T) and the context gradient `dctx` (layout of ctx,
  *      row stride ldo).  dq / dk / dv: row stride ldg.  dq, dpos ((2T-1) rows, stride lddp), du and dvbias (H*dh) are
- *      ACCUMULATED INTO with fp32 atomics (the caller zero-fills them); dk / dv are written. */
+ *      ACCUMULATED INTO with fp32 atomics (the caller zero-fills them); dk / dv are written.
+ *      prec: CFM_PREC_F32, or the 16-bit type the forward kernel ran in under autocast (its operand rounding is replayed
+ *      so the recomputed probabilities match the saved log-sum-exp; the products themselves stay fp32). */
 int cfm_relpos_attention_bwd_f32(const float* q, const float* k, const float* v, int64_t ld, const float* pos,
                                  int64_t ldp, const float* u, const float* vbias, const int64_t* lengths_or_null,
                                  const float* ctx, const float* dctx, int64_t ldo, const float* lse, float* dq,
                                  float* dk, float* dv, int64_t ldg, float* dpos, int64_t lddp, float* du,
                                  float* dvbias, int B, int T, int H, int dh, float drop_p, uint64_t drop_seed,
-                                 cfm_stream_t stream);
+                                 int prec, cfm_stream_t stream);
+
+/* diagnostics: per-phase s_memrealtime stamps of one wave of the fused attention backward (see the .hip file) */
+int cfm_debug_attention_bwd_trace_f32(void* trace_or_null);
 
 /* ---- tuning / diagnostics: the residual-epilogue GEMM with a forced block-tile shape
  *      (cfg 0..3 = 128x128, 128x64, 64x128, 64x64; -1 = built-in heuristic).  Same results for every cfg.

@@ -15,7 +15,7 @@ HEADER = os.path.join(ROOT, "include", "conformer_hip.h")
 def header_functions():
     src = open(HEADER).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    decls = re.findall(r"\b(?:int|int64_t|const char\*)\s+(cfm_\w+)\s*\(([^;]*?)\)\s*;", src, flags=re.S)
+    decls = re.findall(r"\b(?:int|int64_t|size_t|const char\*)\s+(cfm_\w+)\s*\(([^;]*?)\)\s*;", src, flags=re.S)
     out = {}
     for name, args in decls:
         args = args.strip()

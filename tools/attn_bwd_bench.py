@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Attention-core backward at cfg-2 / cfg-3 shapes: the fused flash kernel vs the round-1 materialising form (fp32), and
-the autocast (16-bit pipe) form.  Prints JSON lines."""
+"""Attention-core backward at cfg-2 / cfg-3 shapes: the fused flash kernel (fp32, and with the autocast operand rounding).
+Prints JSON lines; `trace` prints the per-phase timeline of one wave.  (Round-2 record of the replaced materialising form,
+measured with this tool before it was deleted: profiles/r02_attn_bwd_flash_vs_materialised.jsonl.)"""
 import json
 import os
 import sys
@@ -26,6 +27,33 @@ def timeit(fn, iters=20):
     return e0.elapsed_time(e1) / iters * 1e3
 
 
+if len(sys.argv) > 1 and sys.argv[1] == "trace":
+    from conformer_amd import _lib
+    B, T, d, H = 32, 249, 512, 8
+    g = torch.Generator(device=dev).manual_seed(0)
+    qkv = torch.randn(B, T, 3 * d, device=dev, generator=g) * 0.5
+    pos = torch.randn(2 * T - 1, d, device=dev, generator=g) * 0.5
+    u = torch.randn(H, d // H, device=dev, generator=g) * 0.1
+    v = torch.randn(H, d // H, device=dev, generator=g) * 0.1
+    L = torch.full((B,), T, dtype=torch.int64, device=dev)
+    dy = torch.randn(B, T, d, device=dev, generator=g)
+    ctx, lse = ops.relpos_attention_train(qkv, pos, u, v, L, H)
+    for _ in range(3):
+        ops.relpos_attention_bwd(qkv, pos, u, v, L, H, ctx, lse, dy)
+    nq = (T + 31) // 32
+    tr = torch.zeros(16 * nq, dtype=torch.int64, device=dev)
+    _lib.load().cfm_debug_attention_bwd_trace_f32(tr.data_ptr())
+    ops.relpos_attention_bwd(qkv, pos, u, v, L, H, ctx, lse, dy)
+    torch.cuda.synchronize()
+    _lib.load().cfm_debug_attention_bwd_trace_f32(None)
+    s = tr.cpu().view(nq, 16)
+    names = ["S,dW", "band+skew", "P,dS", "dV,dK", "dQu", "dQv", "dPband", "wait-bar", "flush", "commit+bar", "prefetch"]
+    print("tile | " + " | ".join(f"{n:>9s}" for n in names) + " | total   (ns; s_memrealtime 100 MHz)")
+    for it in range(nq):
+        dts = [(int(s[it, i + 1]) - int(s[it, i])) * 10 for i in range(11)]
+        print(f"{it:4d} | " + " | ".join(f"{x:9d}" for x in dts) + f" | {sum(dts)}")
+    sys.exit(0)
+
 for B in (32, 64):
     T, d, H = 249, 512, 8
     g = torch.Generator(device=dev).manual_seed(0)
@@ -39,15 +67,6 @@ for B in (32, 64):
     flops = 10.0 * B * T * T * d + 2.0 * 2 * B * T * T * d        # 5 products + the two positional ones (algorithmic, 2*MAC)
     row = {"B": B, "T": T, "d": d, "H": H}
     row["flash_f32_us"] = timeit(lambda: ops.relpos_attention_bwd(qkv, pos, u, v, L, H, ctx, lse, dy))
-    mem0 = torch.cuda.max_memory_allocated()
-    ops._FORCE_MATERIALISED_ATTN_BWD = True
-    row["materialised_f32_us"] = timeit(lambda: ops.relpos_attention_bwd(qkv, pos, u, v, L, H, ctx, lse, dy))
-    ops._FORCE_MATERIALISED_ATTN_BWD = False
-    a = ops.relpos_attention_bwd(qkv, pos, u, v, L, H, ctx, lse, dy)
-    ops._FORCE_MATERIALISED_ATTN_BWD = True
-    b = ops.relpos_attention_bwd(qkv, pos, u, v, L, H, ctx, lse, dy)
-    ops._FORCE_MATERIALISED_ATTN_BWD = False
-    row["rel_l2_flash_vs_materialised"] = [float((x - y).norm() / y.norm()) for x, y in zip(a, b)]
     with torch.autocast("cuda", dtype=torch.bfloat16):
         c16, l16 = ops.relpos_attention_train(qkv, pos, u, v, L, H)
         row["autocast_bf16_us"] = timeit(lambda: ops.relpos_attention_bwd(qkv, pos, u, v, L, H, c16, l16, dy))

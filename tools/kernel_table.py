@@ -106,7 +106,7 @@ def main():
         ("rel-pos table (2T'-1, d)", lambda: ops.relpos_table(div, T), P * d * f, 0),
         ("rel-pos attention fwd", lambda: ops.relpos_attention(qkv, pos, u, v, L, H), 4 * N * d * f, 6.0 * B * T * T * d),
         ("rel-pos attention fwd (+lse)", lambda: ops.relpos_attention_train(qkv, pos, u, v, L, H), 4 * N * d * f, 6.0 * B * T * T * d),
-        ("rel-pos attention bwd (round-1 form)", lambda: ops.relpos_attention_bwd(qkv, pos, u, v, L, H, ctx, lse, dy), 8 * N * d * f,
+        ("rel-pos attention bwd (fused flash kernel)", lambda: ops.relpos_attention_bwd(qkv, pos, u, v, L, H, ctx, lse, dy), 8 * N * d * f,
          15.0 * B * T * T * d),
         ("log-mel front end (B=32, 10 s)", lambda: fe.mel_spectrogram(wave), (B * 159840 + B * 80 * 1000) * f, 0),
         ("SpecAugment apply (3 bands)", specaug, 0, 0),
