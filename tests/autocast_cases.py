@@ -37,20 +37,24 @@ def _entry(rows, name, ours_t, g, stem):
     got = golden_pick(ours_t, k32).float().cpu()
     sib = _math_zero_sibling(name)
     if sib is not None or float(ref32.norm()) < ZERO_GRAD:
+        rms = lambda t: float(t.double().pow(2).mean().sqrt())
         rows.append(dict(tensor=name, zero=True, ours_abs=float(got.abs().max()), ref_abs=float(ref16.abs().max()),
-                         sibling_scale=_sibling_scale(g, stem, name, sib)))
+                         ours_rms=rms(got), ref_rms=rms(ref16), sibling_scale=_sibling_scale(g, stem, name, sib),
+                         sibling_rms=_sibling_scale(g, stem, name, sib, rms=True)))
         return
     rows.append(dict(tensor=name, zero=False, ours=rel_l2(got, ref32), ref=rel_l2(ref16, ref32), cross=rel_l2(got, ref16)))
 
 
-def _sibling_scale(g, stem, name, sib):
-    """max |reference fp32 gradient| of the non-zero sibling parameter of a mathematically-zero gradient (or None)."""
+def _sibling_scale(g, stem, name, sib, rms=False):
+    """max (or rms) |reference fp32 gradient| of the non-zero sibling parameter of a mathematically-zero gradient (or None)."""
     if sib is None:
         return None
     suffix = next(s for s, _, _ in MATH_ZERO if name.endswith(s))
     sib_suffix = sib[len(name) - len(suffix):]
     k = golden_find(g, stem.replace("{p}", "f32")[: -len(suffix)] + sib_suffix)
-    return None if k is None else float(g[k].abs().max())
+    if k is None:
+        return None
+    return float(g[k].double().pow(2).mean().sqrt()) if rms else float(g[k].abs().max())
 
 
 def module_rows(case, dev, dtype=torch.bfloat16):
