@@ -23,7 +23,6 @@
 // D_i = dO_i.O_i is computed while the query tile is staged (no separate row-dot kernel, no qbias kernel).
 #include "cfm_common.h"
 #include <math.h>
-#include <type_traits>
 
 namespace {
 
@@ -63,27 +62,9 @@ __device__ __forceinline__ f32x4 round16(f32x4 x, int prec) {
 // across all phases (measured: 256 + 256 registers and 800 bytes of scratch per lane without this).
 #define ATB_FRESH_LANE() int li = li_; int hf = hf_; asm volatile("" : "+v"(li), "+v"(hf))
 
-// T16 = void: every product on the fp32 matrix pipe.  T16 = __bf16 / _Float16 (autocast): the three score-side products
-// -- S = (Q+u).K^T, G = (Q+v).Pband^T, dW = dO.V^T, 128 of the 352 fp32 MFMAs per query tile -- run on
-// v_mfma_f32_32x32x16_{bf16,f16} from 16-bit copies of the staged rows (144-byte LDS rows: conflict-free ds_read_b128 =
-// the 8 k-values of one MFMA) and 16-bit K / V registers: exactly the operand rounding of the 16-bit forward kernel, so
-// the recomputed P matches its log-sum-exp.  The gradient products (dV, dK, dq, dpos) stay on the fp32 pipe.
-constexpr int QROW16 = 72;   // 16-bit row pitch (elements)
-
-template <int NC, int ND, typename T16>
+template <int NC, int ND>
 __global__ __launch_bounds__(256, 1) void relpos_attn_bwd_kernel(const AttnBwdArgs a) {
-    constexpr bool LP = !std::is_void<T16>::value;
-    constexpr int NS = (8 * NC + 15) / 16;                 // 16-deep contraction steps of the 16-bit MFMAs
-    constexpr int F32_WORDS = 3 * 32 * QROW + 64 + RING * QROW + 4 * 32 * SROW + 4 * 32 * 64;
-    constexpr int LP_WORDS = LP ? (3 * 32 + RING) * QROW16 / 2 : 0;
-    __shared__ __attribute__((aligned(16))) float smem[F32_WORDS + LP_WORDS];
-    typedef typename std::conditional<LP, T16, __bf16>::type E16;
-    typedef typename Lowp<E16>::x8 x8;
-    typedef typename Lowp<E16>::x4 x4;
-    E16* Qu16 = reinterpret_cast<E16*>(smem + F32_WORDS);  // [32][QROW16] 16-bit copies of q+u, q+v, dO and of the ring
-    E16* Qv16 = Qu16 + 32 * QROW16;
-    E16* dO16 = Qv16 + 32 * QROW16;
-    E16* Pr16 = dO16 + 32 * QROW16;                        // [RING][QROW16]
+    __shared__ __attribute__((aligned(16))) float smem[3 * 32 * QROW + 64 + RING * QROW + 4 * 32 * SROW + 4 * 32 * 64];
     float* Qu = smem;                       // [32][QROW]  q + u      (this query tile)
     float* Qv = Qu + 32 * QROW;             // [32][QROW]  q + v
     float* dOs = Qv + 32 * QROW;            // [32][QROW]  dO
@@ -115,33 +96,18 @@ __global__ __launch_bounds__(256, 1) void relpos_attn_bwd_kernel(const AttnBwdAr
 
     // ---- this wave's keys: K and V as MFMA B operands (lane = key, registers = head dims 8c+4hf+e), and K once more
     //      with the head dim on the lane (B operand of d(Q+u) = dS.K)
-    float kreg[LP ? 1 : 4 * NC], vreg[LP ? 1 : 4 * NC], k2reg[ND][16];
-    x8 k16[NS], v16[NS];
-    (void)kreg; (void)vreg; (void)k16; (void)v16;
+    float kreg[4 * NC], vreg[4 * NC], k2reg[ND][16];
     {
         const int key = min(k0 + li, T - 1);
         const float* krow = a.k + ((int64_t)b * T + key) * a.ld + h * dh;
         const float* vrow = a.v + ((int64_t)b * T + key) * a.ld + h * dh;
-        if constexpr (LP) {
 #pragma unroll
-            for (int st = 0; st < NS; ++st)
+        for (int c = 0; c < NC; ++c) {
+            const int dd = 8 * c + 4 * hf;
+            f32x4 kk = {0.f, 0.f, 0.f, 0.f}, vv = kk;
+            if (dd < dh) { kk = *reinterpret_cast<const f32x4*>(krow + dd); vv = *reinterpret_cast<const f32x4*>(vrow + dd); }
 #pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    const int dd = 16 * st + 8 * hf + 4 * q;
-                    f32x4 kk = {0.f, 0.f, 0.f, 0.f}, vv = kk;
-                    if (dd < dh) { kk = *reinterpret_cast<const f32x4*>(krow + dd); vv = *reinterpret_cast<const f32x4*>(vrow + dd); }
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { k16[st][4 * q + e] = (E16)kk[e]; v16[st][4 * q + e] = (E16)vv[e]; }
-                }
-        } else {
-#pragma unroll
-            for (int c = 0; c < NC; ++c) {
-                const int dd = 8 * c + 4 * hf;
-                f32x4 kk = {0.f, 0.f, 0.f, 0.f}, vv = kk;
-                if (dd < dh) { kk = *reinterpret_cast<const f32x4*>(krow + dd); vv = *reinterpret_cast<const f32x4*>(vrow + dd); }
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { kreg[4 * c + e] = kk[e]; vreg[4 * c + e] = vv[e]; }
-            }
+            for (int e = 0; e < 4; ++e) { kreg[4 * c + e] = round16(kk[e], a.prec); vreg[4 * c + e] = round16(vv[e], a.prec); }
         }
 #pragma unroll
         for (int nt = 0; nt < ND; ++nt)
@@ -188,19 +154,12 @@ __global__ __launch_bounds__(256, 1) void relpos_attn_bwd_kernel(const AttnBwdAr
             const int r = srow + 16 * p;
             const bool use = i0 + r < T && sok;                                    // rows past T: zero operands, P = exp(s - inf) = 0
             const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-            const f32x4 qu4 = use ? round16(pq[p] + ubias, a.prec) : z, qv4 = use ? round16(pq[p] + vbias, a.prec) : z;
-            const f32x4 do4 = use ? pdo[p] : z;
-            *reinterpret_cast<f32x4*>(Qu + r * QROW + sch * 4) = qu4;
-            *reinterpret_cast<f32x4*>(Qv + r * QROW + sch * 4) = qv4;
-            *reinterpret_cast<f32x4*>(dOs + r * QROW + sch * 4) = do4;
-            if constexpr (LP) {
-                *reinterpret_cast<x4*>(Qu16 + r * QROW16 + sch * 4) = Lowp<E16>::cvt4(qu4);
-                *reinterpret_cast<x4*>(Qv16 + r * QROW16 + sch * 4) = Lowp<E16>::cvt4(qv4);
-                *reinterpret_cast<x4*>(dO16 + r * QROW16 + sch * 4) = Lowp<E16>::cvt4(do4);
-            }
-            // D_i = dO_i . O_i with dO rounded as the dW = dO.V^T product rounds it (LP), so that sum_k P (dW - D) = 0 holds to
-            // the accuracy of P alone -- the gradients of the key / position projection biases are exactly this sum
-            const f32x4 dor = LP ? round16(pdo[p], a.prec) : pdo[p];
+            *reinterpret_cast<f32x4*>(Qu + r * QROW + sch * 4) = use ? round16(pq[p] + ubias, a.prec) : z;
+            *reinterpret_cast<f32x4*>(Qv + r * QROW + sch * 4) = use ? round16(pq[p] + vbias, a.prec) : z;
+            *reinterpret_cast<f32x4*>(dOs + r * QROW + sch * 4) = use ? round16(pdo[p], a.prec) : z;
+            // D_i = dO_i . O_i.  Under autocast (prec != 0: the small-head fallback of the 16-bit kernel) dO is rounded here and in
+            // dW = dO.V^T alike, so that sum_k P (dW - D) = 0 holds to the accuracy of P (see attention_bwd_flash_mfma16.hip)
+            const f32x4 dor = round16(pdo[p], a.prec);
             float dot = use ? po[p][0] * dor[0] + po[p][1] * dor[1] + po[p][2] * dor[2] + po[p][3] * dor[3] : 0.f;
             dot += __shfl_xor(dot, 8, 64); dot += __shfl_xor(dot, 4, 64);
             dot += __shfl_xor(dot, 2, 64); dot += __shfl_xor(dot, 1, 64);       // the 16 chunks of a row sit in 16 adjacent lanes
@@ -208,7 +167,6 @@ __global__ __launch_bounds__(256, 1) void relpos_attn_bwd_kernel(const AttnBwdAr
             if (ring_rows) {
                 const int slot = (jlo_of(i0) + r + ring_bias) % RING;
                 *reinterpret_cast<f32x4*>(Pr + slot * QROW + sch * 4) = round16(ppr[p], a.prec);
-                if constexpr (LP) *reinterpret_cast<x4*>(Pr16 + slot * QROW16 + sch * 4) = Lowp<E16>::cvt4(ppr[p]);
             }
         }
     };
@@ -231,7 +189,6 @@ __global__ __launch_bounds__(256, 1) void relpos_attn_bwd_kernel(const AttnBwdAr
             const f32x4 z = {0.f, 0.f, 0.f, 0.f};
             const f32x4 val = ch * 4 < dh ? *reinterpret_cast<const f32x4*>(a.pos + (int64_t)j * a.ldp + h * dh + ch * 4) : z;
             *reinterpret_cast<f32x4*>(Pr + ((jlo + r + ring_bias) % RING) * QROW + ch * 4) = round16(val, a.prec);
-            if constexpr (LP) *reinterpret_cast<x4*>(Pr16 + ((jlo + r + ring_bias) % RING) * QROW16 + ch * 4) = Lowp<E16>::cvt4(val);
         }
     }
     for (int idx = tid; idx < 4 * 32 * 16; idx += 256) *reinterpret_cast<f32x4*>(dQs + idx * 4) = f32x4{0.f, 0.f, 0.f, 0.f};   // (idle waves never write theirs)
@@ -271,17 +228,11 @@ __global__ __launch_bounds__(256, 1) void relpos_attn_bwd_kernel(const AttnBwdAr
                 ATB_FRESH_LANE();
 #pragma unroll
                 for (int r = 0; r < 16; ++r) S[r] = 0.f;
-                if constexpr (LP) {
 #pragma unroll
-                    for (int st = 0; st < NS; ++st)
-                        S = Lowp<E16>::mfma(*reinterpret_cast<const x8*>(Qu16 + li * QROW16 + 16 * st + 8 * hf), k16[st], S);
-                } else {
+                for (int c = 0; c < NC; ++c) {
+                    const f32x4 aq = *reinterpret_cast<const f32x4*>(Qu + li * QROW + 8 * c + 4 * hf);
 #pragma unroll
-                    for (int c = 0; c < NC; ++c) {
-                        const f32x4 aq = *reinterpret_cast<const f32x4*>(Qu + li * QROW + 8 * c + 4 * hf);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) S = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[e], kreg[4 * c + e], S, 0, 0, 0);
-                    }
+                    for (int e = 0; e < 4; ++e) S = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[e], kreg[4 * c + e], S, 0, 0, 0);
                 }
             }
             ATB_STAMP(1);
@@ -293,22 +244,15 @@ __global__ __launch_bounds__(256, 1) void relpos_attn_bwd_kernel(const AttnBwdAr
                 ATB_FRESH_LANE();
                 int slot = slot0 - (32 * mt + li);
                 slot += slot < 0 ? RING : 0;
+                const float* prow = Pr + slot * QROW + 4 * hf;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) G[r] = 0.f;
-                if constexpr (LP) {
 #pragma unroll
-                    for (int st = 0; st < NS; ++st)
-                        G = Lowp<E16>::mfma(*reinterpret_cast<const x8*>(Qv16 + li * QROW16 + 16 * st + 8 * hf),
-                                            *reinterpret_cast<const x8*>(Pr16 + slot * QROW16 + 16 * st + 8 * hf), G);
-                } else {
-                    const float* prow = Pr + slot * QROW + 4 * hf;
+                for (int c = 0; c < NC; ++c) {
+                    const f32x4 av = *reinterpret_cast<const f32x4*>(Qv + li * QROW + 8 * c + 4 * hf);
+                    const f32x4 bp = *reinterpret_cast<const f32x4*>(prow + 8 * c);
 #pragma unroll
-                    for (int c = 0; c < NC; ++c) {
-                        const f32x4 av = *reinterpret_cast<const f32x4*>(Qv + li * QROW + 8 * c + 4 * hf);
-                        const f32x4 bp = *reinterpret_cast<const f32x4*>(prow + 8 * c);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) G = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], bp[e], G, 0, 0, 0);
-                    }
+                    for (int e = 0; e < 4; ++e) G = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], bp[e], G, 0, 0, 0);
                 }
             };
             auto spill = [&](const f32x16& G) {
@@ -337,17 +281,11 @@ __global__ __launch_bounds__(256, 1) void relpos_attn_bwd_kernel(const AttnBwdAr
                 ATB_FRESH_LANE();
 #pragma unroll
                 for (int r = 0; r < 16; ++r) dW[r] = 0.f;
-                if constexpr (LP) {
 #pragma unroll
-                    for (int st = 0; st < NS; ++st)
-                        dW = Lowp<E16>::mfma(*reinterpret_cast<const x8*>(dO16 + li * QROW16 + 16 * st + 8 * hf), v16[st], dW);
-                } else {
+                for (int c = 0; c < NC; ++c) {
+                    const f32x4 ad = *reinterpret_cast<const f32x4*>(dOs + li * QROW + 8 * c + 4 * hf);
 #pragma unroll
-                    for (int c = 0; c < NC; ++c) {
-                        const f32x4 ad = *reinterpret_cast<const f32x4*>(dOs + li * QROW + 8 * c + 4 * hf);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) dW = __builtin_amdgcn_mfma_f32_32x32x2f32(ad[e], vreg[4 * c + e], dW, 0, 0, 0);
-                    }
+                    for (int e = 0; e < 4; ++e) dW = __builtin_amdgcn_mfma_f32_32x32x2f32(ad[e], vreg[4 * c + e], dW, 0, 0, 0);
                 }
             }
             unskew(1);
@@ -638,12 +576,7 @@ extern "C" int cfm_relpos_attention_bwd_f32(const float* q, const float* k, cons
                   B, T, H, dh, 1.0f / sqrtf((float)dh), drop_p, drop_seed, prec, g_atb_trace};
     const dim3 grid((unsigned)((T + 127) / 128), (unsigned)(B * H)), block(256);
     hipStream_t s = static_cast<hipStream_t>(stream);
-#define ATB_LAUNCH(NC, ND)                                                                                                  \
-    do {                                                                                                                    \
-        if (prec == CFM_PREC_BF16) hipLaunchKernelGGL((relpos_attn_bwd_kernel<NC, ND, __bf16>), grid, block, 0, s, a);       \
-        else if (prec == CFM_PREC_FP16) hipLaunchKernelGGL((relpos_attn_bwd_kernel<NC, ND, _Float16>), grid, block, 0, s, a); \
-        else hipLaunchKernelGGL((relpos_attn_bwd_kernel<NC, ND, void>), grid, block, 0, s, a);                               \
-    } while (0)
+#define ATB_LAUNCH(NC, ND) hipLaunchKernelGGL((relpos_attn_bwd_kernel<NC, ND>), grid, block, 0, s, a)
     if (dh <= 8) ATB_LAUNCH(1, 1);
     else if (dh <= 16) ATB_LAUNCH(2, 1);
     else if (dh <= 32) ATB_LAUNCH(4, 1);

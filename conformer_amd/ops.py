@@ -706,9 +706,9 @@ def relpos_attention_bwd(qkv, pos, u, v, lengths, n_heads, ctx, lse, dctx, drop_
     """Backward of the attention core.  Returns (dqkv (B,T,3d), dpos (2T-1,d), du (H,dh), dv (H,dh)).
     ONE fused flash-style kernel (attention_bwd_flash_f32.hip) that recomputes score tiles from the forward's
     log-sum-exp: no (B,H,T,T) / (H,B,T,2T-1) tensor is ever allocated (the reference's autograd keeps both,
-    attention.py:49-70).  Under autocast the score operands are rounded as the 16-bit forward kernel rounded them
-    (attention_mfma16.hip), so the recomputed probabilities match its log-sum-exp; the products themselves run on
-    the fp32 matrix pipe (a 16-bit variant of the fused kernel is not built)."""
+    attention.py:49-70).  Under autocast: the same algorithm with every product on the 16-bit matrix pipe
+    (attention_bwd_flash_mfma16.hip) and the operand rounding of the 16-bit forward kernel (attention_mfma16.hip), so the
+    recomputed probabilities match its log-sum-exp."""
     qkv = _req(qkv, "qkv"); pos = _req(pos, "pos"); ctx = _req(ctx, "ctx"); lse = _req(lse, "lse")
     dctx = _req(dctx, "dctx")
     B, T, d3 = qkv.shape
@@ -718,12 +718,16 @@ def relpos_attention_bwd(qkv, pos, u, v, lengths, n_heads, ctx, lse, dctx, drop_
     P = 2 * T - 1
     dqkv, dpos, du, dvb = _zeros_split(qkv.device, qkv.dtype, (B, T, d3), (P, d), (n_heads, dh), (n_heads, dh))
     base, dbase = qkv.data_ptr(), dqkv.data_ptr()
-    st = _lib.load().cfm_relpos_attention_bwd_f32(base, base + 4 * d, base + 8 * d, d3, pos.data_ptr(), pos.stride(0),
-                                                  u.data_ptr(), v.data_ptr(), _p(lengths), ctx.data_ptr(), dctx.data_ptr(), d,
-                                                  lse.data_ptr(), dbase, dbase + 4 * d, dbase + 8 * d, d3, dpos.data_ptr(), d,
-                                                  du.data_ptr(), dvb.data_ptr(), B, T, n_heads, dh, float(drop_p), int(seed),
-                                                  mfma16_prec(), _stream())
-    _lib.check(st, "cfm_relpos_attention_bwd_f32")
+    args = (base, base + 4 * d, base + 8 * d, d3, pos.data_ptr(), pos.stride(0), u.data_ptr(), v.data_ptr(), _p(lengths),
+            ctx.data_ptr(), dctx.data_ptr(), d, lse.data_ptr(), dbase, dbase + 4 * d, dbase + 8 * d, d3, dpos.data_ptr(), d,
+            du.data_ptr(), dvb.data_ptr(), B, T, n_heads, dh, float(drop_p), int(seed))
+    prec = mfma16_prec()
+    if prec and dh > 16:
+        _lib.check(_lib.load().cfm_relpos_attention_bwd_mfma16_f32(prec, *args, _stream()), "cfm_relpos_attention_bwd_mfma16_f32")
+    else:
+        # fp32 products; under autocast with heads of <= 16 dims (too few contraction terms for 16-bit products to average
+        # out, and no matrix work worth saving) still the fp32 kernel, replaying the forward's operand rounding (`prec`)
+        _lib.check(_lib.load().cfm_relpos_attention_bwd_f32(*args, prec, _stream()), "cfm_relpos_attention_bwd_f32")
     return dqkv, dpos, du, dvb
 
 

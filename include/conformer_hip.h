@@ -261,6 +261,15 @@ int cfm_relpos_attention_bwd_f32(const float* q, const float* k, const float* v,
                                  float* dvbias, int B, int T, int H, int dh, float drop_p, uint64_t drop_seed,
                                  int prec, cfm_stream_t stream);
 
+/* the same under torch.autocast (prec = CFM_PREC_BF16 / CFM_PREC_FP16, the type cfm_relpos_attention_mfma16_f32 ran in):
+ * every product on the 16-bit matrix pipe with autocast's operand rounding, fp32 softmax / accumulation / outputs */
+int cfm_relpos_attention_bwd_mfma16_f32(int prec, const float* q, const float* k, const float* v, int64_t ld,
+                                        const float* pos, int64_t ldp, const float* u, const float* vbias,
+                                        const int64_t* lengths_or_null, const float* ctx, const float* dctx, int64_t ldo,
+                                        const float* lse, float* dq, float* dk, float* dv, int64_t ldg, float* dpos,
+                                        int64_t lddp, float* du, float* dvbias, int B, int T, int H, int dh,
+                                        float drop_p, uint64_t drop_seed, cfm_stream_t stream);
+
 /* diagnostics: per-phase s_memrealtime stamps of one wave of the fused attention backward (see the .hip file) */
 int cfm_debug_attention_bwd_trace_f32(void* trace_or_null);
 

@@ -47,7 +47,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "trace":
     torch.cuda.synchronize()
     _lib.load().cfm_debug_attention_bwd_trace_f32(None)
     s = tr.cpu().view(nq, 16)
-    names = ["S,dW", "band+skew", "P,dS", "dV,dK", "dQu", "dQv", "dPband", "wait-bar", "flush", "commit+bar", "prefetch"]
+    names = ["S", "band+skew+dW", "P,dS", "dV,dK", "dQu", "dQv", "dPband", "wait-bar", "commit", "flush+bar", "prefetch"]
     print("tile | " + " | ".join(f"{n:>9s}" for n in names) + " | total   (ns; s_memrealtime 100 MHz)")
     for it in range(nq):
         dts = [(int(s[it, i + 1]) - int(s[it, i])) * 10 for i in range(11)]
