@@ -255,27 +255,24 @@ __global__ __launch_bounds__(256, 1) void relpos_attn_bwd_kernel(const AttnBwdAr
                     for (int e = 0; e < 4; ++e) G = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], bp[e], G, 0, 0, 0);
                 }
             };
-            auto spill = [&](const f32x16& G) {
-                ATB_FRESH_LANE();
-#pragma unroll
-                for (int r = 0; r < 16; ++r) gs[rho(r, hf) * SROW + li] = G[r];
-                wave_lds_fence();
-            };
-            auto unskew = [&](int mt) {
+            // The "relative shift" S[il][kl] += G[il][il - kl + 31]: with the key on the lane it is, per accumulator register (one
+            // query row per lane half), a ROTATION of the 32 lanes of that half -- one ds_bpermute_b32 per register and band
+            // tile through the LDS crossbar, no LDS memory, no wave fence (the first version spilled G to a per-wave LDS
+            // tile and read it back skewed: 1.0-1.4 us of write / fence / read latency per query tile).
+            auto unskew = [&](const f32x16& G, int mt) {
                 ATB_FRESH_LANE();
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int il = rho(r, hf);
-                    const float val = gs[il * SROW + ((il - li + 31) & 31)];
+                    const int src = ((il - li + 31) & 31) + 32 * hf;          // lane holding column jj & 31 of this half's row
+                    const float gr = G[r];                                   // (bit_cast straight from the vector element picks element 0)
+                    const float val = __int_as_float(__builtin_amdgcn_ds_bpermute(src << 2, __float_as_int(gr)));
                     sk[r] = mt == 0 ? val : (il > li ? val : sk[r]);         // jj >= 32  <=>  il > kl : second band tile
                 }
-                wave_lds_fence();
             };
             band(G0, 0);
-            spill(G0);
-            band(G1, 1);                                            // MFMAs in flight while the skewed reads of tile 0 return
-            unskew(0);
-            spill(G1);
+            band(G1, 1);                                            // MFMAs in flight while the rotated reads of tile 0 return
+            unskew(G0, 0);
             // ---- (2) dW = dO.V^T
             {
                 ATB_FRESH_LANE();
@@ -288,7 +285,7 @@ __global__ __launch_bounds__(256, 1) void relpos_attn_bwd_kernel(const AttnBwdAr
                     for (int e = 0; e < 4; ++e) dW = __builtin_amdgcn_mfma_f32_32x32x2f32(ad[e], vreg[4 * c + e], dW, 0, 0, 0);
                 }
             }
-            unskew(1);
+            unskew(G1, 1);
             __builtin_amdgcn_sched_barrier(0);
             ATB_STAMP(2);
             // ---- (4) probabilities and (5) score gradient: lane = key, register r = query row rho(r, hf)

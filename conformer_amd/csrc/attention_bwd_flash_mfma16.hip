@@ -35,6 +35,7 @@ struct AttnBwd16Args {
     float* dq; float* dk; float* dv; int64_t ldg;
     float* dpos; int64_t lddp; float* du; float* dvb;
     int B, T, H, dh; float scale; float drop_p; unsigned long long drop_seed;
+    unsigned long long* trace;            // diagnostics: s_memrealtime stamps of wave 0 of workgroup (0,0), 16 per query tile
 };
 
 __device__ __forceinline__ int rho(int r, int hf) { return (r & 3) + 8 * (r >> 2) + 4 * hf; }
@@ -47,16 +48,20 @@ __device__ __forceinline__ void glob_add(float* p, float v) { atomicAdd(p, v); }
 
 #define ATB_FRESH_LANE() int li = li_; int hf = hf_; asm volatile("" : "+v"(li), "+v"(hf))
 
-// per-wave LDS region (bytes): fp32 skew tile | dS [il][kl] | pad (the dq slab aliases these three) | dG [il][jj] | dG^T [jj][il]
-constexpr int WV_GS = 0, WV_T1 = 32 * SROW * 4, WV_T2 = 8192, WV_T3 = WV_T2 + 32 * P16 * 2, WV_BYTES = WV_T3 + 64 * PT40 * 2;
-static_assert(WV_T1 + 32 * PT40 * 2 <= WV_T2, "dS tile must end before the dq slab ends");
+// per-wave LDS region (bytes): fp32 skew tile | dS [il][kl] | dG [il][jj] | dG^T [jj][il].  The wave's fp32 dq slab (8 KB)
+// aliases the first three: it is written when nothing of them is needed any more; the part of dG it clobbers is zeroed again
+// after the flush.
+constexpr int WV_GS = 0, WV_T1 = 32 * SROW * 4, WV_T2 = WV_T1 + 32 * PT40 * 2, WV_T3 = WV_T2 + 32 * P16 * 2,
+              WV_BYTES = WV_T3 + 64 * PT40 * 2, WV_SLAB = 32 * 64 * 4;
+static_assert(WV_SLAB > WV_T2 && WV_SLAB < WV_T3 && (WV_SLAB - WV_T2) % 16 == 0, "the dq slab must end inside the dG tile");
 // workgroup LDS (bytes)
 constexpr int O_QU = 0, O_QV = O_QU + 32 * P16 * 2, O_DO = O_QV + 32 * P16 * 2, O_PR = O_DO + 32 * P16 * 2,
               O_QUT = O_PR + RING * P16 * 2, O_DOT = O_QUT + 64 * PT36 * 2, O_QVT = O_DOT + 64 * PT36 * 2,
-              O_PRT = O_QVT + 64 * PT40 * 2, O_LSE = O_PRT + 64 * PRT * 2, O_WV = O_LSE + 256, LDS_BYTES = O_WV + 4 * WV_BYTES;
+              O_PRT = O_QVT + 64 * PT40 * 2, O_LSE = O_PRT + 64 * PRT * 2, O_WV = O_LSE + 256, O_CH = O_WV + 4 * WV_BYTES,
+              LDS_BYTES = O_CH + 3 * WV_SLAB;                       // 3 chain slabs: wave w -> wave w+1
 static_assert(O_PR % 16 == 0 && O_QUT % 16 == 0 && O_DOT % 16 == 0 && O_QVT % 16 == 0 && O_PRT % 16 == 0 && O_WV % 16 == 0 &&
               WV_BYTES % 16 == 0 && WV_T1 % 16 == 0 && WV_T3 % 16 == 0, "16-byte alignment of every LDS array");
-static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+static_assert(LDS_BYTES <= 160 * 1024 && O_CH % 16 == 0 && WV_T2 % 16 == 0, "LDS budget / alignment");
 
 template <typename T16, int NS, int ND>
 __global__ __launch_bounds__(256, 1) void relpos_attn_bwd16_kernel(const AttnBwd16Args a) {
@@ -78,11 +83,12 @@ __global__ __launch_bounds__(256, 1) void relpos_attn_bwd16_kernel(const AttnBwd
     const int li = lane & 31, hf = lane >> 5;
     const int li_ = li, hf_ = hf;
     unsigned char* wv = smem + O_WV + wave * WV_BYTES;
-    float* gs = reinterpret_cast<float*>(wv + WV_GS);      // [32][SROW] fp32 skew tile
     T16* T1 = reinterpret_cast<T16*>(wv + WV_T1);          // [32][PT40]  dS[il][kl]
     T16* T2 = reinterpret_cast<T16*>(wv + WV_T2);          // [32][P16]   dG[il][jj]
     T16* T3 = reinterpret_cast<T16*>(wv + WV_T3);          // [64][PT40]  dG^T[jj][il]
-    float* dQs = reinterpret_cast<float*>(wv);             // [32][64] fp32 dq slab of this wave (aliases gs | T1 | pad)
+    float* dQs = reinterpret_cast<float*>(wv);             // [32][64] fp32 dq slab of this wave (aliases gs | T1 | head of T2)
+    float* chain_out = reinterpret_cast<float*>(smem + O_CH + (wave < 3 ? wave : 0) * WV_SLAB);       // [32][64] to wave + 1
+    const float* chain_in = reinterpret_cast<const float*>(smem + O_CH + (wave > 0 ? wave - 1 : 0) * WV_SLAB);
     const int bh = blockIdx.y, b = bh / a.H, h = bh % a.H;
     const int T = a.T, dh = a.dh;
     const int kb = blockIdx.x * 128, k0 = kb + 32 * wave;
@@ -100,8 +106,14 @@ __global__ __launch_bounds__(256, 1) void relpos_attn_bwd16_kernel(const AttnBwd
     const int biasT = T + 30 + ring_bias;                          // slot'(j) = (biasT - j) % RING;  biasT - j > 0 always
     const int nq = (T + 31) / 32;
 
-    // ---- zero this wave's dG tiles once (cells outside the band parallelogram are never written) and the pad
+    // ---- zero this wave's dG tiles once (cells outside the band parallelogram are never written) and the chain slabs
     for (int off = lane * 16; off < WV_BYTES; off += 64 * 16) *reinterpret_cast<f32x4*>(wv + off) = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int off = tid * 16; off < 3 * WV_SLAB; off += 256 * 16) *reinterpret_cast<f32x4*>(smem + O_CH + off) = f32x4{0.f, 0.f, 0.f, 0.f};
+    // dpos rows: wave w's completed band tile at query tile t and wave w+1's at t+1 are the SAME 32 table rows, so the partial
+    // sums travel wave 0 -> 1 -> 2 -> 3 through the chain slabs and only the last live wave issues atomics: 4x fewer than one
+    // tile per wave (134 MB per layer at cfg-2, which kept the chip's fp32 atomic units ~60 % busy and stalled the waves at
+    // their 16 outstanding atomics).
+    const bool chain_tail = wave == 3 || k0 + 32 >= T;             // nobody downstream: this wave's tiles go to memory
 
     // ---- this wave's keys as 16-bit MFMA B fragments: K, V with the key on the lane (scores, dW) and K with the head dim on
     //      the lane (d(Q+u) = dS.K)
@@ -167,31 +179,53 @@ __global__ __launch_bounds__(256, 1) void relpos_attn_bwd16_kernel(const AttnBwd
 #pragma unroll
         for (int e = 0; e < 4; ++e) PrT[(ch * 4 + e) * PRT + st] = v16b[e];
     };
-    auto commit = [&](int it, bool ring_rows) {
+    // commit = convert (registers only: touches the prefetched rows, i.e. it is where the wait for their loads lands) + store
+    // (LDS only).  convert() runs BEFORE the tile's dpos atomics are issued: vmcnt is in-order, so a wait for the prefetched
+    // rows placed after the atomics waits for the atomics as well (1-3 us per tile in the phase trace).
+    x4 cqu[2], cqv[2], cdo[2], cpr[2];
+    float cD[2], clse[2];
+    auto convert = [&](int it) {
         const int i0 = 32 * it;
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
             const int r = srow + 16 * p;
             const bool use = i0 + r < T && sok;
             const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-            const x4 qu = Lowp<T16>::cvt4(use ? pq[p] + ubias : z), qv = Lowp<T16>::cvt4(use ? pq[p] + vbias : z);
-            const x4 dd = Lowp<T16>::cvt4(use ? pdo[p] : z);
-            *reinterpret_cast<x4*>(Qu16 + r * P16 + sch * 4) = qu;
-            *reinterpret_cast<x4*>(Qv16 + r * P16 + sch * 4) = qv;
-            *reinterpret_cast<x4*>(dO16 + r * P16 + sch * 4) = dd;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                QuT[(sch * 4 + e) * PT36 + r] = qu[e];
-                dOT[(sch * 4 + e) * PT36 + r] = dd[e];
-                QvT[(sch * 4 + e) * PT40 + r] = qv[e];
-            }
+            cqu[p] = Lowp<T16>::cvt4(use ? pq[p] + ubias : z);
+            cqv[p] = Lowp<T16>::cvt4(use ? pq[p] + vbias : z);
+            cdo[p] = Lowp<T16>::cvt4(use ? pdo[p] : z);
+            cpr[p] = Lowp<T16>::cvt4(ppr[p]);
             float dot = 0.f;                                          // D_i from the ROUNDED dO (see the file header)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) dot += use ? po[p][e] * (float)dd[e] : 0.f;
+            for (int e = 0; e < 4; ++e) dot += use ? po[p][e] * (float)cdo[p][e] : 0.f;
             dot += __shfl_xor(dot, 8, 64); dot += __shfl_xor(dot, 4, 64);
             dot += __shfl_xor(dot, 2, 64); dot += __shfl_xor(dot, 1, 64);
-            if (sch == 0) { lseS[r] = i0 + r < T ? plse[p] : INFINITY; DS[r] = dot; }
-            if (ring_rows) put_ring_row(jlo_of(i0) + r, ppr[p], sch);
+            cD[p] = dot;
+            clse[p] = i0 + r < T ? plse[p] : INFINITY;
+        }
+    };
+    auto put_ring_row16 = [&](int jraw, const x4 v16b, int ch) {
+        *reinterpret_cast<x4*>(Pr16 + ((jraw + ring_bias) % RING) * P16 + ch * 4) = v16b;
+        const int st = (biasT - jraw) % RING;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) PrT[(ch * 4 + e) * PRT + st] = v16b[e];
+    };
+    auto store = [&](int it, bool ring_rows) {
+        const int i0 = 32 * it;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int r = srow + 16 * p;
+            *reinterpret_cast<x4*>(Qu16 + r * P16 + sch * 4) = cqu[p];
+            *reinterpret_cast<x4*>(Qv16 + r * P16 + sch * 4) = cqv[p];
+            *reinterpret_cast<x4*>(dO16 + r * P16 + sch * 4) = cdo[p];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                QuT[(sch * 4 + e) * PT36 + r] = cqu[p][e];
+                dOT[(sch * 4 + e) * PT36 + r] = cdo[p][e];
+                QvT[(sch * 4 + e) * PT40 + r] = cqv[p][e];
+            }
+            if (sch == 0) { lseS[r] = clse[p]; DS[r] = cD[p]; }
+            if (ring_rows) put_ring_row16(jlo_of(i0) + r, cpr[p], sch);
         }
     };
     auto lds_barrier = [&]() {                                       // LDS-only: __syncthreads() would also drain the atomics
@@ -211,7 +245,8 @@ __global__ __launch_bounds__(256, 1) void relpos_attn_bwd16_kernel(const AttnBwd
         }
     }
     prefetch(0);
-    commit(0, false);
+    convert(0);
+    store(0, false);
     __syncthreads();
     if (nq > 1) prefetch(1);
 
@@ -226,10 +261,14 @@ __global__ __launch_bounds__(256, 1) void relpos_attn_bwd16_kernel(const AttnBwd
     const float inv_keep = a.drop_p > 0.f ? 1.0f / (1.0f - a.drop_p) : 1.0f;
     const float inv_T = 1.0f / (float)T;
 
+    const bool tracer = a.trace && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0;
+#define ATB_STAMP(i) do { if (tracer) a.trace[16 * it + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
     for (int it = 0; it < nq; ++it) {
         const int i0 = 32 * it;
+        ATB_STAMP(0);
+        const int jtop = T + 30 - i0 + k0;                           // table row of band row jj: j = jtop - jj
+        f32x16 dQ[ND], dPb[ND];                                      // (live across the mid-tile barrier)
         if (wactive) {
-            const int jtop = T + 30 - i0 + k0;                       // table row of band row jj: j = jtop - jj
             const int slot0 = (jtop + ring_bias) % RING;             // row-major ring: slot(jtop - jj) = slot0 - jj (+RING)
             const int slotT0 = (((i0 - k0) % RING) + RING) % RING;   // transposed ring: slot'(jtop - jj) = (slotT0 + jj) % RING,
                                                                      // slotT0 a multiple of 32: a band tile never wraps
@@ -244,6 +283,7 @@ __global__ __launch_bounds__(256, 1) void relpos_attn_bwd16_kernel(const AttnBwd
                 for (int st = 0; st < NS; ++st)
                     S = Lowp<T16>::mfma(*reinterpret_cast<const x8*>(Qu16 + li * P16 + 16 * st + 8 * hf), k16[st], S);
             }
+            ATB_STAMP(1);
             // ---- (3) band G[il][jj] = (Q+v).Pband^T, jj = il - kl + 31, and the "relative shift" through the fp32 skew tile;
             //      (2) dW = dO.V^T runs while the second tile's LDS round trip is in flight
             auto band = [&](f32x16& G, int mt) {
@@ -257,27 +297,24 @@ __global__ __launch_bounds__(256, 1) void relpos_attn_bwd16_kernel(const AttnBwd
                     G = Lowp<T16>::mfma(*reinterpret_cast<const x8*>(Qv16 + li * P16 + 16 * st + 8 * hf),
                                         *reinterpret_cast<const x8*>(Pr16 + slot * P16 + 16 * st + 8 * hf), G);
             };
-            auto spill = [&](const f32x16& G) {
-                ATB_FRESH_LANE();
-#pragma unroll
-                for (int r = 0; r < 16; ++r) gs[rho(r, hf) * SROW + li] = G[r];
-                wave_lds_fence();
-            };
-            auto unskew = [&](int mt) {
+            // The "relative shift" S[il][kl] += G[il][il - kl + 31]: with the key on the lane it is, per accumulator register (one
+            // query row per lane half), a ROTATION of the 32 lanes of that half -- one ds_bpermute_b32 per register and band
+            // tile through the LDS crossbar, no LDS memory, no wave fence (the first version spilled G to a per-wave LDS
+            // tile and read it back skewed: 1.0-1.4 us of write / fence / read latency per query tile).
+            auto unskew = [&](const f32x16& G, int mt) {
                 ATB_FRESH_LANE();
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int il = rho(r, hf);
-                    const float val = gs[il * SROW + ((il - li + 31) & 31)];
-                    sk[r] = mt == 0 ? val : (il > li ? val : sk[r]);
+                    const int src = ((il - li + 31) & 31) + 32 * hf;          // lane holding column jj & 31 of this half's row
+                    const float gr = G[r];                                   // (bit_cast straight from the vector element picks element 0)
+                    const float val = __int_as_float(__builtin_amdgcn_ds_bpermute(src << 2, __float_as_int(gr)));
+                    sk[r] = mt == 0 ? val : (il > li ? val : sk[r]);         // jj >= 32  <=>  il > kl : second band tile
                 }
-                wave_lds_fence();
             };
             band(G0, 0);
-            spill(G0);
             band(G1, 1);
-            unskew(0);
-            spill(G1);
+            unskew(G0, 0);
             {
                 ATB_FRESH_LANE();
 #pragma unroll
@@ -286,8 +323,9 @@ __global__ __launch_bounds__(256, 1) void relpos_attn_bwd16_kernel(const AttnBwd
                 for (int st = 0; st < NS; ++st)
                     dW = Lowp<T16>::mfma(*reinterpret_cast<const x8*>(dO16 + li * P16 + 16 * st + 8 * hf), v16[st], dW);
             }
-            unskew(1);
+            unskew(G1, 1);
             __builtin_amdgcn_sched_barrier(0);
+            ATB_STAMP(2);
             // ---- (4) probabilities, (5) score gradient: lane = key, register r = query row rho(r, hf)
             {
                 ATB_FRESH_LANE();
@@ -325,6 +363,7 @@ __global__ __launch_bounds__(256, 1) void relpos_attn_bwd16_kernel(const AttnBwd
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
+            ATB_STAMP(3);
             // ---- dS -> the three per-wave 16-bit tiles (2-byte scatter; the inverse relative shift happens HERE)
             x8 wb[2], dsb[2];                                        // W and dS as B fragments: registers 8s..8s+7 = k-step s
             {
@@ -341,6 +380,7 @@ __global__ __launch_bounds__(256, 1) void relpos_attn_bwd16_kernel(const AttnBwd
                 }
                 wave_lds_fence();
             }
+            ATB_STAMP(4);
             // ---- (6) dV^T[c][kl] += dO^T.W, (7) dK^T[c][kl] += (Q+u)^T.dS : the accumulator-as-B-operand k-order
             //      (element j of lane half hf <-> query row 16s + 8(j>>2) + 4hf + (j&3)) is met by two 8-byte reads of the
             //      transposed query tile
@@ -358,9 +398,10 @@ __global__ __launch_bounds__(256, 1) void relpos_attn_bwd16_kernel(const AttnBwd
                     }
             }
             __builtin_amdgcn_sched_barrier(0);
+            ATB_STAMP(5);
             // ---- (8) d(Q+u)[il][c] = dS.K ; (9) d(Q+v)[il][c] = dG.Pband
-            f32x16 dQ[ND], dQp[ND];
             {
+                f32x16 dQp[ND];
                 ATB_FRESH_LANE();
 #pragma unroll
                 for (int n = 0; n < ND; ++n)
@@ -389,42 +430,55 @@ __global__ __launch_bounds__(256, 1) void relpos_attn_bwd16_kernel(const AttnBwd
                 for (int nt = 0; nt < ND; ++nt) {
                     float cu = 0.f, cv = 0.f;
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) { cu += dQ[nt][r]; cv += dQp[nt][r]; }
+                    for (int r = 0; r < 16; ++r) { cu += dQ[nt][r]; cv += dQp[nt][r]; dQ[nt][r] += dQp[nt][r]; }
                     du_acc[nt] += cu;
                     dv_acc[nt] += cv;
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
-            // ---- (10) dPband[jj][c] = dG^T.(Q+v): upper band tile from the carry -> complete -> dpos atomics; lower tile -> carry
+            ATB_STAMP(6);
+            // ---- (10a) upper dPband tile starts from the carry (own lower tile of the previous query tile) plus the chain slab
+            //      of wave - 1 (its upper tile of the previous query tile): same 32 table rows
             {
-                f32x16 dPb[ND];
-                {
-                    ATB_FRESH_LANE();
+                ATB_FRESH_LANE();
 #pragma unroll
-                    for (int n = 0; n < ND; ++n) dPb[n] = dPcarry[n];
+                for (int n = 0; n < ND; ++n)
 #pragma unroll
-                    for (int n = 0; n < ND; ++n)
+                    for (int r = 0; r < 16; ++r)
+                        dPb[n][r] = dPcarry[n][r] + (wave > 0 ? chain_in[rho(r, hf) * 64 + 32 * n + li] : 0.f);
+            }
+        }
+        if (it + 1 < nq) convert(it + 1);                           // (before the atomics below: see convert())
+        lds_barrier();                                             // chain slabs: every read above precedes every write below
+        if (wactive) {
+            // ---- (10b) dPband[jj][c] += dG^T.(Q+v); upper tile -> chain slab of the next wave (or dpos atomics at the chain's
+            //      tail / on the last query tile); lower tile -> carry
+            {
+                ATB_FRESH_LANE();
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) dPcarry[n][r] = 0.f;
+                for (int n = 0; n < ND; ++n)
 #pragma unroll
-                    for (int st = 0; st < 2; ++st) {
-                        const x8 a0 = *reinterpret_cast<const x8*>(T3 + li * PT40 + 16 * st + 8 * hf);
-                        const x8 a1 = *reinterpret_cast<const x8*>(T3 + (32 + li) * PT40 + 16 * st + 8 * hf);
+                    for (int r = 0; r < 16; ++r) dPcarry[n][r] = 0.f;
 #pragma unroll
-                        for (int nt = 0; nt < ND; ++nt) {
-                            const x8 bq = *reinterpret_cast<const x8*>(QvT + (32 * nt + li) * PT40 + 16 * st + 8 * hf);
-                            dPb[nt] = Lowp<T16>::mfma(a0, bq, dPb[nt]);
-                            dPcarry[nt] = Lowp<T16>::mfma(a1, bq, dPcarry[nt]);
-                        }
+                for (int st = 0; st < 2; ++st) {
+                    const x8 a0 = *reinterpret_cast<const x8*>(T3 + li * PT40 + 16 * st + 8 * hf);
+                    const x8 a1 = *reinterpret_cast<const x8*>(T3 + (32 + li) * PT40 + 16 * st + 8 * hf);
+#pragma unroll
+                    for (int nt = 0; nt < ND; ++nt) {
+                        const x8 bq = *reinterpret_cast<const x8*>(QvT + (32 * nt + li) * PT40 + 16 * st + 8 * hf);
+                        dPb[nt] = Lowp<T16>::mfma(a0, bq, dPb[nt]);
+                        dPcarry[nt] = Lowp<T16>::mfma(a1, bq, dPcarry[nt]);
                     }
                 }
-                wave_lds_fence();                                    // every read of gs | T1 is done: the dq slab may overwrite them
-                {
-                    ATB_FRESH_LANE();
+            }
+            wave_lds_fence();                                        // every read of gs | T1 | T2 is done: the dq slab may overwrite them
+            {
+                ATB_FRESH_LANE();
 #pragma unroll
-                    for (int nt = 0; nt < ND; ++nt)
+                for (int nt = 0; nt < ND; ++nt)
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) dQs[rho(r, hf) * 64 + 32 * nt + li] = dQ[nt][r] + dQp[nt][r];
+                    for (int r = 0; r < 16; ++r) dQs[rho(r, hf) * 64 + 32 * nt + li] = dQ[nt][r];
+                if (chain_tail || it + 1 == nq) {                    // wave-uniform
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {                   // unconditional atomics: see the fp32 kernel
                         const int j = jtop - rho(r, hf);
@@ -436,13 +490,23 @@ __global__ __launch_bounds__(256, 1) void relpos_attn_bwd16_kernel(const AttnBwd
                             glob_add(prow + (cd < dh ? cd : 0), (jok && cd < dh) ? dPb[nt][r] : 0.f);
                         }
                     }
+                } else {
+#pragma unroll
+                    for (int nt = 0; nt < ND; ++nt)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) chain_out[rho(r, hf) * 64 + 32 * nt + li] = dPb[nt][r];
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
         }
+        ATB_STAMP(7);
         lds_barrier();                                             // every wave is done with this query tile; its dq slab is written
-        if (it + 1 < nq) commit(it + 1, true);
+        ATB_STAMP(8);
+        if (it + 1 < nq) store(it + 1, true);
+        ATB_STAMP(9);
         // ---- flush: the four waves' dq slabs summed -> global (atomics: the other key blocks of this (b,h) add too)
+        //      (excusing the chain's tail wave, which has just issued 32 dpos atomics, and sharing its rows among the other three
+        //      measured 2-4 % slower: dropped)
 #pragma unroll
         for (int p = 0; p < 8; ++p) {
             const int idx = p * 256 + tid, r = idx >> 6, c = idx & 63;
@@ -453,9 +517,16 @@ __global__ __launch_bounds__(256, 1) void relpos_attn_bwd16_kernel(const AttnBwd
             const bool ok = i0 + r < T && c < dh;
             glob_add(a.dq + ((int64_t)b * T + min(i0 + r, T - 1)) * a.ldg + h * dh + (c < dh ? c : 0), ok ? val : 0.f);
         }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // this thread's slab reads have returned ...
+        __builtin_amdgcn_s_barrier();                                 // ... and everybody else's
+        for (int off = WV_T2 + lane * 16; off < WV_SLAB; off += 64 * 16)     // the dG cells the dq slab clobbered: zero again
+            *reinterpret_cast<f32x4*>(wv + off) = f32x4{0.f, 0.f, 0.f, 0.f};
         lds_barrier();
+        ATB_STAMP(10);
         if (it + 2 < nq) prefetch(it + 2);
+        ATB_STAMP(11);
     }
+#undef ATB_STAMP
 
     // ---- epilogue: carried dPband rows, dK / dV of this wave's keys, du / dv
     if (wactive) {
@@ -509,6 +580,8 @@ int launch_bwd16(const AttnBwd16Args& a, hipStream_t s) {
 
 }  // namespace
 
+static unsigned long long* g_atb16_trace = nullptr;    // diagnostics only, set by cfm_debug_attention_bwd_trace_mfma16
+
 // The autocast form of cfm_relpos_attention_bwd_f32 (same arguments and accumulate-into convention; tensors stay fp32 in HBM):
 // prec = CFM_PREC_BF16 / CFM_PREC_FP16, the type the forward kernel cfm_relpos_attention_mfma16_f32 ran in.
 extern "C" int cfm_relpos_attention_bwd_mfma16_f32(int prec, const float* q, const float* k, const float* v, int64_t ld,
@@ -529,7 +602,13 @@ extern "C" int cfm_relpos_attention_bwd_mfma16_f32(int prec, const float* q, con
                 CFM_ALIGNED16(dv) && CFM_ALIGNED16(dpos), CFM_ERR_ALIGN);
     CFM_REQUIRE((int64_t)B * H <= 65535 && T < (1 << 24), CFM_ERR_UNSUPPORTED);
     AttnBwd16Args a{q, k, v, ld, pos, ldp, u, vbias, lengths_or_null, ctx, dctx, ldo, lse, dq, dk, dv, ldg, dpos, lddp, du, dvbias,
-                    B, T, H, dh, 1.0f / sqrtf((float)dh), drop_p, drop_seed};
+                    B, T, H, dh, 1.0f / sqrtf((float)dh), drop_p, drop_seed, g_atb16_trace};
     hipStream_t s = static_cast<hipStream_t>(stream);
     return prec == CFM_PREC_BF16 ? launch_bwd16<__bf16>(a, s) : launch_bwd16<_Float16>(a, s);
+}
+
+// diagnostics only: as cfm_debug_attention_bwd_trace_f32, for the 16-bit kernel (12 stamps per query tile, wave 0 of (0,0))
+extern "C" int cfm_debug_attention_bwd_trace_mfma16(void* trace_or_null) {
+    g_atb16_trace = static_cast<unsigned long long*>(trace_or_null);
+    return CFM_OK;
 }

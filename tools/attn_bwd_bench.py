@@ -27,8 +27,12 @@ def timeit(fn, iters=20):
     return e0.elapsed_time(e1) / iters * 1e3
 
 
-if len(sys.argv) > 1 and sys.argv[1] == "trace":
+if len(sys.argv) > 1 and sys.argv[1] in ("trace", "trace16"):
     from conformer_amd import _lib
+    import contextlib
+    lp = sys.argv[1] == "trace16"
+    amp = (lambda: torch.autocast("cuda", dtype=torch.bfloat16)) if lp else contextlib.nullcontext
+    setter = "cfm_debug_attention_bwd_trace_mfma16" if lp else "cfm_debug_attention_bwd_trace_f32"
     B, T, d, H = 32, 249, 512, 8
     g = torch.Generator(device=dev).manual_seed(0)
     qkv = torch.randn(B, T, 3 * d, device=dev, generator=g) * 0.5
@@ -37,17 +41,19 @@ if len(sys.argv) > 1 and sys.argv[1] == "trace":
     v = torch.randn(H, d // H, device=dev, generator=g) * 0.1
     L = torch.full((B,), T, dtype=torch.int64, device=dev)
     dy = torch.randn(B, T, d, device=dev, generator=g)
-    ctx, lse = ops.relpos_attention_train(qkv, pos, u, v, L, H)
-    for _ in range(3):
+    with amp():
+        ctx, lse = ops.relpos_attention_train(qkv, pos, u, v, L, H)
+        for _ in range(3):
+            ops.relpos_attention_bwd(qkv, pos, u, v, L, H, ctx, lse, dy)
+        nq = (T + 31) // 32
+        tr = torch.zeros(16 * nq, dtype=torch.int64, device=dev)
+        getattr(_lib.load(), setter)(tr.data_ptr())
         ops.relpos_attention_bwd(qkv, pos, u, v, L, H, ctx, lse, dy)
-    nq = (T + 31) // 32
-    tr = torch.zeros(16 * nq, dtype=torch.int64, device=dev)
-    _lib.load().cfm_debug_attention_bwd_trace_f32(tr.data_ptr())
-    ops.relpos_attention_bwd(qkv, pos, u, v, L, H, ctx, lse, dy)
-    torch.cuda.synchronize()
-    _lib.load().cfm_debug_attention_bwd_trace_f32(None)
+        torch.cuda.synchronize()
+        getattr(_lib.load(), setter)(None)
     s = tr.cpu().view(nq, 16)
-    names = ["S", "band+skew+dW", "P,dS", "dV,dK", "dQu", "dQv", "dPband", "wait-bar", "commit", "flush+bar", "prefetch"]
+    names = (["S", "band+skew+dW", "P,dS", "dS tiles", "dV,dK", "dQu+dQv", "dPband+dq+atomics", "wait-bar", "commit", "flush+bar", "prefetch"] if lp else
+             ["S", "band+skew+dW", "P,dS", "dV,dK", "dQu", "dQv", "dPband", "wait-bar", "commit", "flush+bar", "prefetch"])
     print("tile | " + " | ".join(f"{n:>9s}" for n in names) + " | total   (ns; s_memrealtime 100 MHz)")
     for it in range(nq):
         dts = [(int(s[it, i + 1]) - int(s[it, i])) * 10 for i in range(11)]
