@@ -58,6 +58,8 @@ SIGNATURES = {
     "cfm_dwconv_bn_stats_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _P, ctypes.c_size_t, _P]),
     "cfm_debug_attention_bwd_trace_f32": (c_int, [_P]),
     "cfm_debug_attention_bwd_trace_mfma16": (c_int, [_P]),
+    "cfm_debug_gemm_mfma16_trace": (c_int, [_P]),
+    "cfm_debug_gemm_mfma16_force_tile": (c_int, [_I]),
     "cfm_relpos_attention_bwd_mfma16_f32": (c_int, [_I, _P, _P, _P, _L, _P, _L, _P, _P, _P, _P, _P, _L, _P, _P, _P, _P, _L, _P, _L,
                                                     _P, _P, _I, _I, _I, _I, _F, _U, _P]),
     "cfm_relpos_attention_bwd_f32": (c_int, [_P, _P, _P, _L, _P, _L, _P, _P, _P, _P, _P, _L, _P, _P, _P, _P, _L, _P, _L, _P, _P,

@@ -18,14 +18,20 @@ namespace {
 // optimizer step): half the L2->LDS bytes of the operand that every row tile re-reads, and no conversion.
 // A16 (with W16): the activation operand is a 16-bit tensor too (LayerNorm / Swish / stem conv1 outputs written in the
 // 16-bit type by their producers), lda in elements; the stem's implicit-GEMM gather uses the same element offsets.
-template <typename T16, int BM, int BN, int EPI, bool CONV, bool W16, bool A16 = false>
-__global__ __launch_bounds__(256, 2) void gemm_mfma16_kernel(const GemmArgs g) {
+// WM = waves along M (2: 256 threads, block tiles up to 128x128; 4: 512 threads, 256x128 / 256x256 with one workgroup per CU).
+// The K-loop is bound by the operand stream L2 -> L1 -> LDS: at 128x128 two co-resident workgroups pull 64 KB per ~1 us K-tile
+// step into a CU (16 TB/s chip-wide, about half of the L2's peak) for 0.23 us of MFMA work each -- deeper prefetch and
+// fragment pipelining changed nothing -- so the big tiles exist to halve the bytes per MFMA.
+template <typename T16, int BM, int BN, int EPI, bool CONV, bool W16, bool A16 = false, int WM = 2>
+__global__ __launch_bounds__(WM * 128, 2) void gemm_mfma16_kernel(const GemmArgs g) {
     static_assert(!A16 || W16, "16-bit A operand comes together with 16-bit weights");
     using x8 = typename Lowp<T16>::x8;
     using x4 = typename Lowp<T16>::x4;
-    constexpr int TM = BM / 64, TN = BN / 64, BK = 64;
+    constexpr int NT = WM * 128;                              // threads
+    constexpr int TM = BM / (32 * WM), TN = BN / 64, BK = 64;
     constexpr int ROWB = 72;                                  // LDS row in bf16 elements: 64 + 8 pad = 144 B
-    constexpr int NA = BM / 16, NB = BN / 16;                 // float4 loads per thread per K-tile (rows / 16 passes)
+    constexpr int RP4 = NT / 16, RP8 = NT / 8;                // tile rows staged per pass: 16 lanes (fp32) / 8 lanes (16-bit) per row
+    constexpr int NA = BM / RP4, NB = BN / RP4;               // float4 loads per thread per K-tile
     static_assert(EPI != EPI_GLU || TN == 2, "GLU keeps value and gate tiles in one wave");
     __shared__ __attribute__((aligned(16))) T16 lds[2 * (BM + BN) * ROWB];
     T16* As = lds;                     // [2][BM][ROWB]
@@ -38,14 +44,14 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma16_kernel(const GemmArgs g) {
     const int n0 = (int)tn * (EPI == EPI_GLU ? BN / 2 : BN);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wr = wave >> 1, wc = wave & 1;
+    const int wr = wave >> 1, wc = wave & 1;                 // wr in [0, WM)
     const int li = lane & 31, hf = lane >> 5;
 
     // ---- staging: 16 lanes cover the 256 B of one tile row; pass p handles rows srow + 16 p
     const int srow = tid >> 4, sch = tid & 15;
-    constexpr int NBH = BN / 32;                              // W16: 16-byte loads per thread per K-tile (8 lanes per row)
+    constexpr int NBH = BN / RP8;                             // W16: 16-byte loads per thread per K-tile (8 lanes per row)
     const int hrow = tid >> 3, hch = tid & 7;
-    constexpr int NAH = BM / 32;
+    constexpr int NAH = BM / RP8;
     const float* a_ptr[A16 ? 1 : NA];
     const T16* ah_ptr[A16 ? NAH : 1];
     const float* w_ptr[W16 ? 1 : NB];
@@ -53,47 +59,54 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma16_kernel(const GemmArgs g) {
     if (A16) {
 #pragma unroll
         for (int p = 0; p < NAH; ++p) {
-            ah_ptr[p] = reinterpret_cast<const T16*>(g.A) + (a_row_ptr<CONV>(g, m0 + hrow + 32 * p) - g.A);   // element offset
+            ah_ptr[p] = reinterpret_cast<const T16*>(g.A) + (a_row_ptr<CONV>(g, m0 + hrow + RP8 * p) - g.A);   // element offset
         }
     } else {
 #pragma unroll
-        for (int p = 0; p < NA; ++p) a_ptr[p] = a_row_ptr<CONV>(g, m0 + srow + 16 * p);
+        for (int p = 0; p < NA; ++p) a_ptr[p] = a_row_ptr<CONV>(g, m0 + srow + RP4 * p);
     }
     if (W16) {
 #pragma unroll
         for (int p = 0; p < NBH; ++p)
-            wh_ptr[p] = reinterpret_cast<const T16*>(g.W) + (int64_t)w_row_index<EPI, BN>(g, n0, hrow + 32 * p) * g.K;
+            wh_ptr[p] = reinterpret_cast<const T16*>(g.W) + (int64_t)w_row_index<EPI, BN>(g, n0, hrow + RP8 * p) * g.K;
     } else {
 #pragma unroll
-        for (int p = 0; p < NB; ++p) w_ptr[p] = w_row_ptr<EPI, BN>(g, n0, srow + 16 * p);
+        for (int p = 0; p < NB; ++p) w_ptr[p] = w_row_ptr<EPI, BN>(g, n0, srow + RP4 * p);
     }
     // All loads are unconditional: a K-tile chunk beyond K (only possible in the last tile when K % 64 != 0) reads a clamped
     // address and is zeroed by a select when it is staged into LDS (`kvalid*`), after the MFMAs of the current tile.
-    f32x4 ra[A16 ? 1 : NA], rb[W16 ? 1 : NB];
-    x8 rah[A16 ? NAH : 1], rbh[W16 ? NBH : 1];
-    bool kvalid = true, kvalid_h = true;
-    auto load_tile = [&](int kt) {
+    // Two staging register sets: the loads of K-tiles kt+1 and kt+2 are both in flight while tile kt is multiplied.  The
+    // per-K-tile timeline (tools/gemm16_sites.py trace) showed 1.2-1.6 us per K-tile against 0.23 us of MFMA time with one
+    // tile in flight: a round trip to L2 under load per 64-deep step.
+    struct Stage {
+        f32x4 ra[A16 ? 1 : NA], rb[W16 ? 1 : NB];
+        x8 rah[A16 ? NAH : 1], rbh[W16 ? NBH : 1];
+        bool kvalid, kvalid_h;
+    };
+    constexpr bool DEEP = WM == 2;                            // 8-wave tiles: one set (the second one spills at 256x256)
+    Stage st0, st1;
+    auto load_tile = [&](Stage& t, int kt) {
         const int k = kt * BK + sch * 4, kh = kt * BK + hch * 8;       // K % 4 == 0 (K % 8 == 0 for 16-bit operands)
-        kvalid = k < g.K; kvalid_h = kh < g.K;
-        const int kc = min(k, g.K - 4), khc = min(kh, g.K - 8);
+        t.kvalid = k < g.K; t.kvalid_h = kh < g.K;
+        const int kc = max(0, min(k, g.K - 4)), khc = max(0, min(kh, g.K - 8));
         if (A16) {
             const int64_t ahoff = a_k_offset<CONV>(g, khc - hch * 8) + hch * 8;
 #pragma unroll
-            for (int p = 0; p < NAH; ++p) rah[p] = *reinterpret_cast<const x8*>(ah_ptr[p] + ahoff);
+            for (int p = 0; p < NAH; ++p) t.rah[p] = *reinterpret_cast<const x8*>(ah_ptr[p] + ahoff);
         } else {
             const int64_t aoff = a_k_offset<CONV>(g, kc - sch * 4) + sch * 4;
 #pragma unroll
-            for (int p = 0; p < NA; ++p) ra[p] = *reinterpret_cast<const f32x4*>(a_ptr[p] + aoff);
+            for (int p = 0; p < NA; ++p) t.ra[p] = *reinterpret_cast<const f32x4*>(a_ptr[p] + aoff);
         }
         if (W16) {
 #pragma unroll
-            for (int p = 0; p < NBH; ++p) rbh[p] = *reinterpret_cast<const x8*>(wh_ptr[p] + khc);
+            for (int p = 0; p < NBH; ++p) t.rbh[p] = *reinterpret_cast<const x8*>(wh_ptr[p] + khc);
         } else {
 #pragma unroll
-            for (int p = 0; p < NB; ++p) rb[p] = *reinterpret_cast<const f32x4*>(w_ptr[p] + kc);
+            for (int p = 0; p < NB; ++p) t.rb[p] = *reinterpret_cast<const f32x4*>(w_ptr[p] + kc);
         }
     };
-    auto store_tile = [&](int buf) {
+    auto store_tile = [&](const Stage& t, int buf) {
         const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
         x8 z8;
 #pragma unroll
@@ -101,20 +114,20 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma16_kernel(const GemmArgs g) {
         if (A16) {
 #pragma unroll
             for (int p = 0; p < NAH; ++p)
-                *reinterpret_cast<x8*>(As + (buf * BM + hrow + 32 * p) * ROWB + hch * 8) = kvalid_h ? rah[p] : z8;
+                *reinterpret_cast<x8*>(As + (buf * BM + hrow + RP8 * p) * ROWB + hch * 8) = t.kvalid_h ? t.rah[p] : z8;
         } else {
 #pragma unroll
             for (int p = 0; p < NA; ++p)
-                *reinterpret_cast<x4*>(As + (buf * BM + srow + 16 * p) * ROWB + sch * 4) = Lowp<T16>::cvt4(kvalid ? ra[p] : z4);
+                *reinterpret_cast<x4*>(As + (buf * BM + srow + RP4 * p) * ROWB + sch * 4) = Lowp<T16>::cvt4(t.kvalid ? t.ra[p] : z4);
         }
         if (W16) {
 #pragma unroll
             for (int p = 0; p < NBH; ++p)
-                *reinterpret_cast<x8*>(Bs + (buf * BN + hrow + 32 * p) * ROWB + hch * 8) = kvalid_h ? rbh[p] : z8;
+                *reinterpret_cast<x8*>(Bs + (buf * BN + hrow + RP8 * p) * ROWB + hch * 8) = t.kvalid_h ? t.rbh[p] : z8;
         } else {
 #pragma unroll
             for (int p = 0; p < NB; ++p)
-                *reinterpret_cast<x4*>(Bs + (buf * BN + srow + 16 * p) * ROWB + sch * 4) = Lowp<T16>::cvt4(kvalid ? rb[p] : z4);
+                *reinterpret_cast<x4*>(Bs + (buf * BN + srow + RP4 * p) * ROWB + sch * 4) = Lowp<T16>::cvt4(t.kvalid ? t.rb[p] : z4);
         }
     };
 
@@ -127,36 +140,77 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma16_kernel(const GemmArgs g) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     // lane (row li, half hf) feeds k = 16 s + 8 hf + {0..7} of MFMA step s: one 16-byte read
-    const int a_row = wr * (BM / 2) + li, b_row = wc * (BN / 2) + li;
+    const int a_row = wr * (BM / WM) + li, b_row = wc * (BN / 2) + li;
     const int nkt = (g.K + BK - 1) / BK;
-    load_tile(0);
-    store_tile(0);
+    const bool tracer = g.trace && tid == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x / 2);   // diagnostics only
+    unsigned long long* tr = g.trace + (blockIdx.x == 0 ? 0 : 64);
+    if (tracer) tr[0] = __builtin_amdgcn_s_memrealtime();
+    load_tile(st0, 0);
+    store_tile(st0, 0);
+    if (DEEP) {
+        load_tile(st1, 1);                                    // (tiles beyond K read a clamped address and are never staged)
+        load_tile(st0, 2);
+    } else {
+        load_tile(st0, 1);
+    }
     __syncthreads();
-    for (int kt = 0; kt < nkt; ++kt) {
+    if (tracer) tr[1] = __builtin_amdgcn_s_memrealtime();
+    auto k_step = [&](int kt, Stage& nxt) {                   // `nxt` holds tile kt+1 on entry and is refilled with tile kt+3
         const int cur = kt & 1;
         const bool more = kt + 1 < nkt;
-        if (more) load_tile(kt + 1);
-        __builtin_amdgcn_sched_barrier(0);                    // the loads stay in flight across this tile's MFMAs
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            x8 fa[TM], fb[TN];
+        // per-wave software pipeline: the fragments of MFMA step s+1 are read while step s multiplies (one exposed LDS
+        // latency per K-tile instead of four: the trace showed ~1.2 us per K-tile against 0.23 us of MFMA time)
+        constexpr int NF = (WM == 4 && BN == 256) ? 1 : 2;       // (the 256x256 tile has no registers left for a second set)
+        x8 fa[NF][TM], fb[NF][TN];
+        auto read_frags = [&](int set, int s) {
 #pragma unroll
             for (int t = 0; t < TM; ++t)
-                fa[t] = *reinterpret_cast<const x8*>(As + (cur * BM + a_row + 32 * t) * ROWB + 16 * s + 8 * hf);
+                fa[set][t] = *reinterpret_cast<const x8*>(As + (cur * BM + a_row + 32 * t) * ROWB + 16 * s + 8 * hf);
 #pragma unroll
             for (int t = 0; t < TN; ++t)
-                fb[t] = *reinterpret_cast<const x8*>(Bs + (cur * BN + b_row + 32 * t) * ROWB + 16 * s + 8 * hf);
+                fb[set][t] = *reinterpret_cast<const x8*>(Bs + (cur * BN + b_row + 32 * t) * ROWB + 16 * s + 8 * hf);
+        };
+        if (NF == 2) read_frags(0, 0);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            if (NF == 2) { if (s < 3) read_frags((s + 1) & 1, s + 1); }
+            else read_frags(0, s);
 #pragma unroll
             for (int mt = 0; mt < TM; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < TN; ++nt)
-                    acc[mt][nt] = Lowp<T16>::mfma(fb[nt], fa[mt], acc[mt][nt]);
+                    acc[mt][nt] = Lowp<T16>::mfma(fb[s & (NF - 1)][nt], fa[s & (NF - 1)][mt], acc[mt][nt]);
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (more) store_tile(cur ^ 1);
+        if (more) {
+            store_tile(nxt, cur ^ 1);
+            load_tile(nxt, kt + (DEEP ? 3 : 2));
+        }
         __syncthreads();
+        if (tracer && kt < 60) tr[2 + kt] = __builtin_amdgcn_s_memrealtime();
+    };
+    int kt = 0;
+    if (DEEP) {
+        for (; kt + 1 < nkt; kt += 2) {
+            k_step(kt, st1);
+            k_step(kt + 1, st0);
+        }
+        if (kt < nkt) k_step(kt, st1);
+    } else {
+        for (; kt < nkt; ++kt) k_step(kt, st0);
     }
-    gemm_epilogue<BM, BN, EPI, TM, TN>(g, acc, m0, n0, wr, wc, li, hf);
+    if constexpr (EPI == EPI_GLU) {
+        static_assert(WM == 2, "GLU tiles: 2x2 waves");
+        gemm_epilogue<BM, BN, EPI, TM, TN>(g, acc, m0, n0, wr, wc, li, hf);
+    } else {                                                 // (the K-loop ended on a __syncthreads: the staging buffers are free)
+        static_assert(2 * WM * 32 * (32 * TN + 4) * 4 <= 2 * (BM + BN) * ROWB * 2, "row-major epilogue scratch must fit the staging LDS");
+        gemm_epilogue_rows<BM, BN, EPI, TM, TN, WM>(g, acc, m0, n0, wr, wc, lane, reinterpret_cast<float*>(lds) + wave * 32 * (32 * TN + 4));
+    }
+    if (tracer) {
+        tr[62] = __builtin_amdgcn_s_memrealtime();                       // epilogue issued
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        tr[63] = __builtin_amdgcn_s_memrealtime();                       // ... and drained
+    }
 }
 
 template <typename T16, int BM, int BN, int EPI, bool CONV>
@@ -173,6 +227,22 @@ int launch_cfg(GemmArgs g, int src16, hipStream_t s) {          // src16: 0 = fp
     return cfm_launch_status();
 }
 
+inline bool gemm_epilogue_vec_ok_host(const GemmArgs& g, int epi) {      // the row-major epilogue's alignment conditions
+    return ((g.ldc & 3) == 0) && ((g.N & 3) == 0) && (epi != EPI_RESID || (g.ldr & 3) == 0) &&
+           ((reinterpret_cast<uintptr_t>(g.C) & (g.c_prec ? 7 : 15)) == 0) &&
+           (epi != EPI_RESID || (reinterpret_cast<uintptr_t>(g.R) & 15) == 0);
+}
+
+template <typename T16, int BM, int BN, int EPI>
+int launch_big(GemmArgs g, int src16, hipStream_t s) {          // 512-thread workgroups, 16-bit weights, no conv gather, no GLU
+    g.tiles_m = (unsigned)((g.M + BM - 1) / BM);
+    g.tiles_n = (unsigned)((g.N + BN - 1) / BN);
+    const dim3 grid(g.tiles_m * g.tiles_n);
+    if (src16 == 2) hipLaunchKernelGGL((gemm_mfma16_kernel<T16, BM, BN, EPI, false, true, true, 4>), grid, dim3(512), 0, s, g);
+    else hipLaunchKernelGGL((gemm_mfma16_kernel<T16, BM, BN, EPI, false, true, false, 4>), grid, dim3(512), 0, s, g);
+    return cfm_launch_status();
+}
+
 template <typename T16, int EPI, bool CONV>
 int launch_t(const GemmArgs& g, int src16, hipStream_t s) {
     const int ncols = EPI == EPI_GLU ? g.n_out : g.N;
@@ -181,6 +251,17 @@ int launch_t(const GemmArgs& g, int src16, hipStream_t s) {
     if constexpr (EPI == EPI_GLU) {
         return t128 >= 512 ? launch_cfg<T16, 128, 128, EPI, CONV>(g, src16, s) : launch_cfg<T16, 64, 128, EPI, CONV>(g, src16, s);
     } else {
+        if constexpr (!CONV) {
+            // big tiles (one 8-wave workgroup per CU) once they fill the chip about once over: half / three quarters of the
+            // operand bytes per MFMA of the 128x128 tile
+            const int force = g.occ_cap;                          // tuning hook: 1 = 128x128 family, 2 = 256x128, 3 = 256x256
+            if (src16 >= 1 && gemm_epilogue_vec_ok_host(g, EPI)) {
+                const int64_t rows256 = (g.M + 255) / 256;
+                const int64_t t256 = rows256 * ((g.N + 255) / 256), t2128 = rows256 * ((g.N + 127) / 128);
+                if (force == 3 || (force == 0 && t256 >= 224)) return launch_big<T16, 256, 256, EPI>(g, src16, s);
+                if (force == 2 || (force == 0 && t2128 >= 224)) return launch_big<T16, 256, 128, EPI>(g, src16, s);
+            }
+        }
         return t128 >= 512 ? launch_cfg<T16, 128, 128, EPI, CONV>(g, src16, s) : launch_cfg<T16, 64, 64, EPI, CONV>(g, src16, s);
     }
 }
@@ -201,6 +282,23 @@ int launch(int prec, const GemmArgs& g, int src16, hipStream_t s) {
 
 }  // namespace
 
+static unsigned long long* g_gemm16_trace = nullptr;     // diagnostics only (cfm_debug_gemm_mfma16_trace)
+static int g_gemm16_force_tile = 0;                       // tuning only (cfm_debug_gemm_mfma16_force_tile)
+
+// diagnostics only (tools/gemm16_sites.py trace): the next cfm_gemm_mfma16_f32 launches record s_memrealtime (100 MHz) stamps
+// of thread 0 of the first and of the middle workgroup: [0] start, [1] first K-tile staged, [2+kt] K-tile kt done, [62] epilogue
+// issued, [63] epilogue drained (2 x 64 uint64); NULL switches it off.
+extern "C" int cfm_debug_gemm_mfma16_trace(void* trace_or_null) {
+    g_gemm16_trace = static_cast<unsigned long long*>(trace_or_null);
+    return CFM_OK;
+}
+
+// tuning only (tools/gemm16_sites.py sweep): 0 = built-in choice, 1 = 128x128 / 64x64 family, 2 = 256x128, 3 = 256x256
+extern "C" int cfm_debug_gemm_mfma16_force_tile(int tile) {
+    g_gemm16_force_tile = tile;
+    return CFM_OK;
+}
+
 // prec: CFM_PREC_BF16 | CFM_PREC_FP16.  epi: 0 bias | 1 bias+swish | 2 bias+relu | 3 bias+GLU (N = n_out columns of C,
 // W has 2*n_out rows) | 4 alpha*y + R.  Same layouts and argument rules as the fp32 entry points (cfm_gemm_train_f32 for
 // Z_or_null / drop_p / drop_seed); results differ from them by the 16-bit rounding of A and W only.
@@ -219,6 +317,8 @@ extern "C" int cfm_gemm_mfma16_f32(int prec, int epi, const void* A, int a_is_16
     g.A = static_cast<const float*>(A); g.W = static_cast<const float*>(W); g.bias = bias; g.R = R_or_null;
     g.C = static_cast<float*>(C); g.c_prec = c_is_16bit ? prec : 0; g.M = M; g.K = K; g.lda = lda;
     g.ldr = ldr; g.ldc = ldc; g.alpha = alpha; g.Zsave = Z_or_null; g.drop_p = drop_p; g.drop_seed = drop_seed;
+    g.trace = g_gemm16_trace;
+    g.occ_cap = g_gemm16_force_tile;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (epi == EPI_GLU) {
         g.n_out = N; g.N = 2 * N;

@@ -66,86 +66,141 @@ __device__ __forceinline__ int64_t a_k_offset(const GemmArgs& g, int k) {   // k
 
 // The MFMAs are issued with W fragments as the A operand and activation fragments as the B operand, so an accumulator
 // tile is C^T: lane (li, hf) holds output ROW m = tile_row + li and, in registers 4q..4q+3, the four CONSECUTIVE
-// columns n = tile_col + 8q + 4hf + {0,1,2,3}.  The epilogue therefore moves 16 bytes per lane per instruction
-// (bias / residual loads and the C store): 4x fewer memory instructions than a dword-per-lane epilogue -- the
-// epilogue of a short-K GEMM is store-ISSUE bound (17-22 us of a 160 us FFN GEMM before this change; per-block
-// timeline in profiles/r01_gemm_timeline.txt).
+// columns n = tile_col + 8q + 4hf + {0,1,2,3}.
+//
+// gemm_epilogue_at: bias / activation / dropout / residual / stores for FOUR consecutive columns of one output row
+// (av = the accumulator values, gv = the matching gate values of a GLU tile).
+template <int EPI>
+__device__ __forceinline__ void gemm_epilogue_at(const GemmArgs& g, const f32x4 av, const f32x4 gv, int64_t row, int col,
+                                                 bool vec_ok) {
+    const int ncols = EPI == EPI_GLU ? g.n_out : g.N;
+    if (row >= g.M || col >= ncols) return;
+    float v[4];
+    if (vec_ok) {                                                  // col + 3 < ncols because ncols % 4 == 0
+        const f32x4 bb = *reinterpret_cast<const f32x4*>(g.bias + col);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = av[e] + bb[e];
+        const bool drop = g.drop_p > 0.f && EPI != EPI_GLU && EPI != EPI_RELU;
+        const float inv_keep = drop ? 1.0f / (1.0f - g.drop_p) : 1.0f;
+        const unsigned long long e0 = (unsigned long long)row * (unsigned long long)g.N + (unsigned)col;
+        if (drop && EPI != EPI_SWISH) {                        // dropout(y) then alpha*y + R  (or plain y)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] *= dropout_keep(g.drop_seed, e0 + e, g.drop_p, inv_keep);
+        }
+        if (EPI == EPI_GLU) {
+            const f32x4 bg = *reinterpret_cast<const f32x4*>(g.bias + g.n_out + col);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] *= sigmoidf_acc(gv[e] + bg[e]);
+        }
+        if (EPI == EPI_RESID) {
+            const f32x4 rr = *reinterpret_cast<const f32x4*>(g.R + row * g.ldr + col);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = g.alpha * v[e] + rr[e];
+        }
+        if (EPI == EPI_SWISH && g.Zsave)
+            *reinterpret_cast<f32x4*>(g.Zsave + row * g.ldc + col) = f32x4{v[0], v[1], v[2], v[3]};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (EPI == EPI_SWISH) {
+                v[e] = swishf_acc(v[e]);
+                if (drop) v[e] *= dropout_keep(g.drop_seed, e0 + e, g.drop_p, inv_keep);
+            }
+            if (EPI == EPI_RELU) v[e] = fmaxf(v[e], 0.f);
+        }
+        if (g.c_prec == 0) *reinterpret_cast<f32x4*>(g.C + row * g.ldc + col) = f32x4{v[0], v[1], v[2], v[3]};
+        else if (g.c_prec == CFM_PREC_BF16)
+            *reinterpret_cast<Lowp<__bf16>::x4*>(reinterpret_cast<__bf16*>(g.C) + row * g.ldc + col) =
+                Lowp<__bf16>::cvt4(f32x4{v[0], v[1], v[2], v[3]});
+        else
+            *reinterpret_cast<Lowp<_Float16>::x4*>(reinterpret_cast<_Float16*>(g.C) + row * g.ldc + col) =
+                Lowp<_Float16>::cvt4(f32x4{v[0], v[1], v[2], v[3]});
+    } else {                                                       // odd leading dims / widths: scalar path
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (col + e >= ncols) continue;
+            float x = av[e] + g.bias[col + e];
+            const bool drop = g.drop_p > 0.f && EPI != EPI_GLU && EPI != EPI_RELU;
+            const float keep = drop ? dropout_keep(g.drop_seed, (unsigned long long)row * (unsigned long long)g.N +
+                                                   (unsigned)(col + e), g.drop_p, 1.0f / (1.0f - g.drop_p)) : 1.0f;
+            if (EPI != EPI_SWISH) x *= keep;
+            if (EPI == EPI_GLU) x *= sigmoidf_acc(gv[e] + g.bias[g.n_out + col + e]);
+            if (EPI == EPI_RESID) x = g.alpha * x + g.R[row * g.ldr + col + e];
+            if (EPI == EPI_SWISH && g.Zsave) g.Zsave[row * g.ldc + col + e] = x;
+            if (EPI == EPI_SWISH) x = swishf_acc(x) * keep;
+            if (EPI == EPI_RELU) x = fmaxf(x, 0.f);
+            if (g.c_prec == 0) g.C[row * g.ldc + col + e] = x;
+            else if (g.c_prec == CFM_PREC_BF16) reinterpret_cast<__bf16*>(g.C)[row * g.ldc + col + e] = (__bf16)x;
+            else reinterpret_cast<_Float16*>(g.C)[row * g.ldc + col + e] = (_Float16)x;
+        }
+    }
+}
+
+__device__ __forceinline__ bool gemm_epilogue_vec_ok(const GemmArgs& g, int epi) {
+    const int ncols = epi == EPI_GLU ? g.n_out : g.N;
+    return ((g.ldc & 3) == 0) && ((ncols & 3) == 0) && (epi != EPI_RESID || (g.ldr & 3) == 0) &&
+           ((reinterpret_cast<uintptr_t>(g.C) & (g.c_prec ? 7 : 15)) == 0) &&
+           (epi != EPI_RESID || (reinterpret_cast<uintptr_t>(g.R) & 15) == 0);
+}
+
+// Straight from the accumulators: every memory instruction of a wave touches 32 rows x 32 bytes.  Kept for the GLU tile
+// (value and gate tiles of one column range live in one wave) and as the fallback for odd leading dimensions.
 template <int BM, int BN, int EPI, int TM, int TN>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const f32x16 (&acc)[TM][TN], int64_t m0, int n0,
                                               int wr, int wc, int li, int hf) {
-    const int ncols = EPI == EPI_GLU ? g.n_out : g.N;
-    const bool vec_ok = ((g.ldc & 3) == 0) && ((ncols & 3) == 0) && (EPI != EPI_RESID || (g.ldr & 3) == 0) &&
-                        ((reinterpret_cast<uintptr_t>(g.C) & (g.c_prec ? 7 : 15)) == 0) &&
-                        (EPI != EPI_RESID || (reinterpret_cast<uintptr_t>(g.R) & 15) == 0);
+    const bool vec_ok = gemm_epilogue_vec_ok(g, EPI);
 #pragma unroll
-    for (int mt = 0; mt < TM; ++mt) {
-        const int64_t row = m0 + wr * (BM / 2) + mt * 32 + li;
-        if (row >= g.M) continue;
+    for (int mt = 0; mt < TM; ++mt)
 #pragma unroll
         for (int nt = 0; nt < (EPI == EPI_GLU ? 1 : TN); ++nt)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int col = n0 + (EPI == EPI_GLU ? wc * 32 : wc * (BN / 2) + nt * 32) + 8 * q + 4 * hf;
-                if (col >= ncols) continue;
-                float v[4];
-                if (vec_ok) {                                                  // col + 3 < ncols because ncols % 4 == 0
-                    const f32x4 bb = *reinterpret_cast<const f32x4*>(g.bias + col);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = acc[mt][nt][4 * q + e] + bb[e];
-                    const bool drop = g.drop_p > 0.f && EPI != EPI_GLU && EPI != EPI_RELU;
-                    const float inv_keep = drop ? 1.0f / (1.0f - g.drop_p) : 1.0f;
-                    const unsigned long long e0 = (unsigned long long)row * (unsigned long long)g.N + (unsigned)col;
-                    if (drop && EPI != EPI_SWISH) {                        // dropout(y) then alpha*y + R  (or plain y)
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] *= dropout_keep(g.drop_seed, e0 + e, g.drop_p, inv_keep);
-                    }
-                    if (EPI == EPI_GLU) {
-                        const f32x4 bg = *reinterpret_cast<const f32x4*>(g.bias + g.n_out + col);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] *= sigmoidf_acc(acc[mt][TN - 1][4 * q + e] + bg[e]);
-                    }
-                    if (EPI == EPI_RESID) {
-                        const f32x4 rr = *reinterpret_cast<const f32x4*>(g.R + row * g.ldr + col);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = g.alpha * v[e] + rr[e];
-                    }
-                    if (EPI == EPI_SWISH && g.Zsave)
-                        *reinterpret_cast<f32x4*>(g.Zsave + row * g.ldc + col) = f32x4{v[0], v[1], v[2], v[3]};
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        if (EPI == EPI_SWISH) {
-                            v[e] = swishf_acc(v[e]);
-                            if (drop) v[e] *= dropout_keep(g.drop_seed, e0 + e, g.drop_p, inv_keep);
-                        }
-                        if (EPI == EPI_RELU) v[e] = fmaxf(v[e], 0.f);
-                    }
-                    if (g.c_prec == 0) *reinterpret_cast<f32x4*>(g.C + row * g.ldc + col) = f32x4{v[0], v[1], v[2], v[3]};
-                    else if (g.c_prec == CFM_PREC_BF16)
-                        *reinterpret_cast<Lowp<__bf16>::x4*>(reinterpret_cast<__bf16*>(g.C) + row * g.ldc + col) =
-                            Lowp<__bf16>::cvt4(f32x4{v[0], v[1], v[2], v[3]});
-                    else
-                        *reinterpret_cast<Lowp<_Float16>::x4*>(reinterpret_cast<_Float16*>(g.C) + row * g.ldc + col) =
-                            Lowp<_Float16>::cvt4(f32x4{v[0], v[1], v[2], v[3]});
-                } else {                                                       // odd leading dims / widths: scalar path
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        if (col + e >= ncols) continue;
-                        float x = acc[mt][nt][4 * q + e] + g.bias[col + e];
-                        const bool drop = g.drop_p > 0.f && EPI != EPI_GLU && EPI != EPI_RELU;
-                        const float keep = drop ? dropout_keep(g.drop_seed, (unsigned long long)row * (unsigned long long)g.N +
-                                                               (unsigned)(col + e), g.drop_p, 1.0f / (1.0f - g.drop_p)) : 1.0f;
-                        if (EPI != EPI_SWISH) x *= keep;
-                        if (EPI == EPI_GLU) x *= sigmoidf_acc(acc[mt][TN - 1][4 * q + e] + g.bias[g.n_out + col + e]);
-                        if (EPI == EPI_RESID) x = g.alpha * x + g.R[row * g.ldr + col + e];
-                        if (EPI == EPI_SWISH && g.Zsave) g.Zsave[row * g.ldc + col + e] = x;
-                        if (EPI == EPI_SWISH) x = swishf_acc(x) * keep;
-                        if (EPI == EPI_RELU) x = fmaxf(x, 0.f);
-                        if (g.c_prec == 0) g.C[row * g.ldc + col + e] = x;
-                        else if (g.c_prec == CFM_PREC_BF16) reinterpret_cast<__bf16*>(g.C)[row * g.ldc + col + e] = (__bf16)x;
-                        else reinterpret_cast<_Float16*>(g.C)[row * g.ldc + col + e] = (_Float16)x;
-                    }
-                }
+                const f32x4 av = {acc[mt][nt][4 * q], acc[mt][nt][4 * q + 1], acc[mt][nt][4 * q + 2], acc[mt][nt][4 * q + 3]};
+                const f32x4 gv = {acc[mt][TN - 1][4 * q], acc[mt][TN - 1][4 * q + 1], acc[mt][TN - 1][4 * q + 2], acc[mt][TN - 1][4 * q + 3]};
+                gemm_epilogue_at<EPI>(g, av, gv, m0 + wr * (BM / 2) + mt * 32 + li,
+                                      n0 + (EPI == EPI_GLU ? wc * 32 : wc * (BN / 2) + nt * 32) + 8 * q + 4 * hf, vec_ok);
             }
+}
+
+// ROW-MAJOR epilogue: each 32-row slab of the wave's accumulators goes through a per-wave LDS tile (the K-loop's staging
+// buffers are dead by then) and comes back with 8*TN consecutive lanes on one output row, so every bias / residual load
+// and every C / Z store of a wave covers whole 128- or 256-byte row segments.  Why: the per-K-tile timeline of the FFN-hidden
+// GEMM of the training step (128x128 tiles, Z saved) showed 1.2-1.6 us per K-tile, 10 us for the whole K-loop -- and 17-30 us
+// for the epilogue: all co-resident workgroups reach it together and their 32-byte write fragments (96 KB per tile) run at a
+// fraction of the HBM write rate.  scratch: per-wave, 32 * (32*TN + 4) floats, 16-byte aligned.
+template <int BM, int BN, int EPI, int TM, int TN, int WM = 2>
+__device__ __forceinline__ void gemm_epilogue_rows(const GemmArgs& g, const f32x16 (&acc)[TM][TN], int64_t m0, int n0,
+                                                   int wr, int wc, int lane, float* scratch) {
+    static_assert(EPI != EPI_GLU, "GLU pairs value and gate tiles: use gemm_epilogue");
+    constexpr int P = 32 * TN + 4, LPR = 8 * TN, RPI = 64 / LPR;      // row pitch, lanes per row, rows per wave-instruction
+    const int li = lane & 31, hf = lane >> 5;
+    if constexpr (WM == 2) {                                          // (8-wave tiles: the launcher guarantees vec_ok)
+        if (!gemm_epilogue_vec_ok(g, EPI)) {                          // (kernel-uniform)
+            gemm_epilogue<BM, BN, EPI, TM, TN>(g, acc, m0, n0, wr, wc, li, hf);
+            return;
+        }
+    }
+    const int rsub = lane / LPR, c4 = (lane % LPR) * 4;
+    const int col = n0 + wc * (BN / 2) + c4;
+#pragma unroll
+    for (int mt = 0; mt < TM; ++mt) {
+#pragma unroll
+        for (int nt = 0; nt < TN; ++nt)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                *reinterpret_cast<f32x4*>(scratch + li * P + 32 * nt + 8 * q + 4 * hf) =
+                    f32x4{acc[mt][nt][4 * q], acc[mt][nt][4 * q + 1], acc[mt][nt][4 * q + 2], acc[mt][nt][4 * q + 3]};
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int it = 0; it < 32 / RPI; ++it) {
+            const int rl = it * RPI + rsub;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(scratch + rl * P + c4);
+            gemm_epilogue_at<EPI>(g, v, v, m0 + wr * (BM / WM) + mt * 32 + rl, col, true);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
 }
 

@@ -273,6 +273,8 @@ int cfm_relpos_attention_bwd_mfma16_f32(int prec, const float* q, const float* k
 /* diagnostics: per-phase s_memrealtime stamps of one wave of the fused attention backward (see the .hip file) */
 int cfm_debug_attention_bwd_trace_f32(void* trace_or_null);
 int cfm_debug_attention_bwd_trace_mfma16(void* trace_or_null);
+int cfm_debug_gemm_mfma16_force_tile(int tile);           /* tuning: 0 auto, 1 128x128 family, 2 256x128, 3 256x256 */
+int cfm_debug_gemm_mfma16_trace(void* trace_or_null);     /* per-K-tile stamps of two workgroups of cfm_gemm_mfma16_f32 */
 
 /* ---- tuning / diagnostics: the residual-epilogue GEMM with a forced block-tile shape
  *      (cfg 0..3 = 128x128, 128x64, 64x128, 64x64; -1 = built-in heuristic).  Same results for every cfg.
