@@ -82,6 +82,69 @@ __device__ __forceinline__ void bwd_epilogue_rows(const BwdArgs& g, float* Cb, f
     }
 }
 
+// The same through a per-wave LDS tile (cf. gemm_epilogue_rows in gemm_shared.h): each 32-row slab of the wave's accumulators
+// is written to `scratch` (32 * (32*TN + 4) floats per wave; the K-loop's staging buffers, dead after its last barrier) and
+// read back with 8*TN consecutive lanes on one output row, so the Z loads (swish'), the accumulate loads and the C stores of
+// a wave cover whole 128 / 256-byte row segments instead of 32 rows x 32 bytes.  Requires J % 4 == 0, ldc % 4 == 0 (and
+// ldz % 4 == 0) and 16-byte aligned bases -- bwd_rows_lds_ok(); otherwise the caller uses bwd_epilogue_rows.
+__device__ __forceinline__ bool bwd_rows_lds_ok(const BwdArgs& g, const float* Cb, int epi) {
+    return (g.J & 3) == 0 && (g.ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(Cb) & 15) == 0 &&
+           (epi != BEPI_DSWISH || ((g.ldz & 3) == 0 && (reinterpret_cast<uintptr_t>(g.Z) & 15) == 0));
+}
+
+template <int BM, int BN, int EPI, int GATHER, int TM, int TN>
+__device__ __forceinline__ void bwd_epilogue_rows_lds(const BwdArgs& g, float* Cb, f32x16 (&acc)[TM][TN], int i0, int j0, int wr,
+                                                      int wc, int lane, float* scratch) {
+    constexpr int P = 32 * TN + 4, LPR = 8 * TN, RPI = 64 / LPR;
+    const int li = lane & 31, hf = lane >> 5;
+    const int rsub = lane / LPR, c4 = (lane % LPR) * 4;
+    const int col = j0 + wc * (BN / 2) + c4;
+#pragma unroll
+    for (int mt = 0; mt < TM; ++mt) {
+#pragma unroll
+        for (int nt = 0; nt < TN; ++nt)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                *reinterpret_cast<f32x4*>(scratch + li * P + 32 * nt + 8 * q + 4 * hf) =
+                    f32x4{acc[mt][nt][4 * q], acc[mt][nt][4 * q + 1], acc[mt][nt][4 * q + 2], acc[mt][nt][4 * q + 3]};
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int it = 0; it < 32 / RPI; ++it) {
+            const int rl = it * RPI + rsub;
+            const int row = i0 + wr * (BM / 2) + mt * 32 + rl;
+            f32x4 v = *reinterpret_cast<const f32x4*>(scratch + rl * P + c4);
+            if (row >= g.I || col >= g.J) continue;
+            v = v * g.alpha;
+            if (EPI == BEPI_DSWISH) {
+                const f32x4 z4 = *reinterpret_cast<const f32x4*>(g.Z + (int64_t)row * g.ldz + col);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float sg = sigmoidf_acc(z4[e]);
+                    v[e] *= sg * (1.0f + z4[e] * (1.0f - sg));
+                    if (g.drop_p > 0.f)
+                        v[e] *= dropout_keep(g.drop_seed, (unsigned long long)row * (unsigned long long)g.J + (unsigned)(col + e),
+                                             g.drop_p, 1.0f / (1.0f - g.drop_p));
+                }
+            }
+            int64_t crow = row;
+            if (GATHER == 2) {                                             // class row -> position (b, 2a+pt, 2c+pf) of dh1
+                const int per = g.pA * g.pC;
+                const int b = row / per, r = row - b * per;
+                const int a = r / g.pC, c = r - a * g.pC;
+                crow = ((int64_t)b * g.cT1 + 2 * a + g.pt) * g.cF1 + 2 * c + g.pf;
+            }
+            float* dst = Cb + crow * g.ldc + col;
+            if (g.accumulate) v = v + *reinterpret_cast<const f32x4*>(dst);
+            *reinterpret_cast<f32x4*>(dst) = v;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+}
+
 // Split-K epilogue for accumulators in the NATURAL MFMA orientation (lane li = column, register r = row
 // (r&3) + 8*(r>>2) + 4*hf): one atomic instruction adds two contiguous 128-byte row segments.
 template <int BM, int BN, int TM, int TN>

@@ -431,8 +431,15 @@ __global__ __launch_bounds__(256, 2) void gemm_bwd_mfma16_kernel(const BwdArgs g
         if (more) store_tile(cur ^ 1);
         __syncthreads();
     }
-    if (SPLITK) bwd_epilogue_atomic<BM, BN, TM, TN>(g, Cb, acc, i0, j0, wr, wc, li, hf);
-    else bwd_epilogue_rows<BM, BN, EPI, GATHER, TM, TN>(g, Cb, acc, i0, j0, wr, wc, li, hf);
+    if (SPLITK) {
+        bwd_epilogue_atomic<BM, BN, TM, TN>(g, Cb, acc, i0, j0, wr, wc, li, hf);
+    } else if (bwd_rows_lds_ok(g, Cb, EPI)) {                 // (kernel-uniform; the loop ended on a barrier: the staging LDS is free)
+        static_assert(4 * 32 * (32 * TN + 4) * 4 <= 2 * (AF + BF) * 2, "row-major epilogue scratch must fit the staging LDS");
+        bwd_epilogue_rows_lds<BM, BN, EPI, GATHER, TM, TN>(g, Cb, acc, i0, j0, wr, wc, lane,
+                                                           reinterpret_cast<float*>(lds) + wave * 32 * (32 * TN + 4));
+    } else {
+        bwd_epilogue_rows<BM, BN, EPI, GATHER, TM, TN>(g, Cb, acc, i0, j0, wr, wc, li, hf);
+    }
 }
 
 template <typename T16, int BM, int BN, bool AROW, bool BROW, int EPI, int GATHER = 0, bool B16 = false>

@@ -102,7 +102,9 @@ def module_rows(case, dev, dtype=torch.bfloat16):
 
 
 def model_rows(case, dev, dtype=torch.bfloat16):
-    """Eval-mode encoder / logits under autocast, and one training step as train.py:225,232-240 writes it."""
+    """Eval-mode encoder / logits under autocast, and one training step as train.py:225,232-240 writes it.
+    ``dtype=None`` runs the fp32 path instead (``ours`` is then the fp32 kernels' distance to the reference's fp32 results)."""
+    ac = lambda: torch.autocast("cuda", dtype=dtype or torch.bfloat16, enabled=dtype is not None)
     from conformer_amd.evaluation import ConformerCriterion
     from model.conformer import Conformer
     meta, g = load_golden(case)
@@ -117,7 +119,7 @@ def model_rows(case, dev, dtype=torch.bfloat16):
     x, L = x.to(dev), g["lengths"].to(dev)
     rows = []
     m = mk(); m.load_state_dict(P, strict=True); m = m.to(dev).eval()
-    with torch.no_grad(), torch.autocast("cuda", dtype=dtype):
+    with torch.no_grad(), ac():
         enc, L2 = m.encoder(x, L)
         logits, _ = m(x, L)
     _entry(rows, "eval.enc", enc, g, "eval.{p}.enc")
@@ -129,7 +131,7 @@ def model_rows(case, dev, dtype=torch.bfloat16):
                      cross=float((am != g["eval.bf16.argmax"]).float().mean())))
     m = mk(); m.load_state_dict(P, strict=True); m = m.to(dev).train()
     crit = ConformerCriterion(blank_id=0)
-    with torch.autocast("cuda", dtype=dtype):
+    with ac():
         out, xl = m(x, L)
         with torch.autocast("cuda", enabled=False):
             loss = crit.ctc_loss(out, g["targets"].to(dev), xl, g["target_lengths"].to(dev))
