@@ -49,6 +49,8 @@ SIGNATURES = {
     "cfm_dropout_f32": (c_int, [_P, _P, _L, _F, _U, _P]),
     "cfm_layernorm_bwd_dx_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, _L, _I, _P]),
     "cfm_layernorm_bwd_params_f32": (c_int, [_P, _P, _P, _P, _P, _P, _L, _I, _P]),
+    "cfm_layernorm_bwd_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _P, ctypes.c_size_t, _P]),
+    "cfm_layernorm_bwd_workspace_bytes": (ctypes.c_size_t, [_L, _I]),
     "cfm_colsum_f32": (c_int, [_P, _L, _L, _I, _F, _P, _P]),
     "cfm_glu_fwd_f32": (c_int, [_P, _P, _L, _I, _P]),
     "cfm_glu_bwd_f32": (c_int, [_P, _P, _P, _L, _I, _P]),
@@ -72,6 +74,8 @@ SIGNATURES = {
     "cfm_adam_step_f32": (c_int, [_P, _I, _F, _F, _F, _F, _F, _F, _P]),
     "cfm_greedy_ctc_decode_f32": (c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "cfm_lstm_fwd_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "cfm_debug_lstm_trace": (c_int, [_P]),
+    "cfm_linear_bwd_weight_mfma16_f32": (c_int, [_I, _P, _I, _L, _P, _I, _L, _P, _L, _P, _I, _I, _L, _F, _P]),
     "cfm_lstm_bwd_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "cfm_swish_bn_eval_f32": (c_int, [_P, _P, _P, _P, _P, _F, _P, _L, _I, _P]),
     "cfm_swish_bn_stats_f32": (c_int, [_P, _P, _P, _P, _P, _F, _L, _I, _P]),

@@ -48,6 +48,115 @@ __global__ __launch_bounds__(256) void layernorm_bwd_dx_kernel(
     }
 }
 
+// ---- LayerNorm backward, input AND parameter gradients in one pass (training path) --------------------------------------
+// The two-kernel form reads x and dy twice (dx kernel, then the dgamma/dbeta column reduction).  Here a wave walks
+// `rows_per_wave` rows (4-row stride inside the workgroup), keeps sum_r dy*xhat and sum_r dy for its columns in registers,
+// the four waves combine through LDS and the workgroup issues one atomic per column per output.  The next row's operands
+// are requested before the current row is reduced (a wave has two rows in flight).
+template <int VPL>
+__global__ __launch_bounds__(256) void layernorm_bwd_fused_kernel(
+    const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ dy,
+    const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ dres,
+    float* __restrict__ dx, float* __restrict__ partials, int64_t rows, int d, int rows_per_wave) {
+    __shared__ f32x4 red[2][3][VPL][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nvec = d >> 2;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_wave * 4 + wave;
+    const int64_t rend = min(rows, (int64_t)(blockIdx.x + 1) * rows_per_wave * 4);
+    const f32x4* g4 = reinterpret_cast<const f32x4*>(gamma);
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 gam[VPL], dgs[VPL], dbs[VPL];
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        const int c = lane + i * 64;
+        gam[i] = c < nvec ? g4[c] : z4;
+        dgs[i] = z4; dbs[i] = z4;
+    }
+    f32x4 xn[VPL], dn[VPL], rn[VPL];
+    float mun = 0.f, rsn = 0.f;
+    auto fetch = [&](int64_t row) {
+        const int64_t rc = min(row, rows - 1);
+        const f32x4* xr = reinterpret_cast<const f32x4*>(x + rc * d);
+        const f32x4* dyr = reinterpret_cast<const f32x4*>(dy + rc * d);
+        const f32x4* rr = reinterpret_cast<const f32x4*>((dres ? dres : dy) + rc * d);
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            const int c = min(lane + i * 64, nvec - 1);
+            xn[i] = xr[c]; dn[i] = dyr[c];
+            if (dres) rn[i] = rr[c];
+        }
+        mun = mean[rc]; rsn = rstd[rc];
+    };
+    if (r0 < rend) fetch(r0);
+    for (int64_t row = r0; row < rend; row += 4) {
+        f32x4 xh[VPL], dyv[VPL], res[VPL];
+        const float rs = rsn;
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) { xh[i] = (xn[i] - mun) * rsn; dyv[i] = dn[i]; res[i] = dres ? rn[i] : z4; }
+        if (row + 4 < rend) fetch(row + 4);
+        float s1 = 0.f, s2 = 0.f;
+        f32x4 gg[VPL];
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            const bool ok = lane + i * 64 < nvec;
+            gg[i] = ok ? dyv[i] * gam[i] : z4;
+            if (!ok) { xh[i] = z4; dyv[i] = z4; }
+            s1 += (gg[i].x + gg[i].y) + (gg[i].z + gg[i].w);
+            s2 += (gg[i].x * xh[i].x + gg[i].y * xh[i].y) + (gg[i].z * xh[i].z + gg[i].w * xh[i].w);
+            dgs[i] = dgs[i] + dyv[i] * xh[i];
+            dbs[i] = dbs[i] + dyv[i];
+        }
+        s1 = wave_sum(s1) / (float)d;
+        s2 = wave_sum(s2) / (float)d;
+        f32x4* dxr = reinterpret_cast<f32x4*>(dx + row * d);
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            const int c = lane + i * 64;
+            if (c < nvec) dxr[c] = (gg[i] - s1 - xh[i] * s2) * rs + res[i];
+        }
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) { red[0][wave - 1][i][lane] = dgs[i]; red[1][wave - 1][i][lane] = dbs[i]; }
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            const int c = lane + i * 64;
+            if (c >= nvec) continue;
+            const f32x4 a = (dgs[i] + red[0][0][i][lane]) + (red[0][1][i][lane] + red[0][2][i][lane]);
+            const f32x4 b = (dbs[i] + red[1][0][i][lane]) + (red[1][1][i][lane] + red[1][2][i][lane]);
+            f32x4* prow = reinterpret_cast<f32x4*>(partials + (int64_t)blockIdx.x * 2 * d);      // [workgroup][dgamma | dbeta]
+            prow[c] = a;
+            prow[nvec + c] = b;
+        }
+    }
+}
+
+// Second stage: out[c] += sum over the workgroups' partial rows (fixed order: the result does not depend on scheduling).
+// grid.x = 2d/64 column blocks (16 lanes x float4) x 16 row lanes; columns [0,d) -> dgamma, [d,2d) -> dbeta.
+__global__ __launch_bounds__(256) void layernorm_bwd_partials_kernel(const float* __restrict__ partials, int nrows, int d,
+                                                                    float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    __shared__ f32x4 red[16][16];
+    const int cq = threadIdx.x & 15, ry = threadIdx.x >> 4;
+    const int c = blockIdx.x * 64 + cq * 4;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (c < 2 * d) {
+#pragma unroll 4
+        for (int r = ry; r < nrows; r += 16) acc = acc + *reinterpret_cast<const f32x4*>(partials + (int64_t)r * 2 * d + c);
+    }
+    red[ry][cq] = acc;
+    __syncthreads();
+    if (ry == 0 && c < 2 * d) {
+#pragma unroll
+        for (int j = 1; j < 16; ++j) acc = acc + red[j][cq];
+        float* out = c < d ? dgamma + c : dbeta + (c - d);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) out[e] += acc[e];
+    }
+}
+
 // ---- LayerNorm backward, parameter gradients; also the generic column-sum (MODE 0) --------------------------------
 //   MODE 0: out0[c] += alpha * sum_r X[r][c]
 //   MODE 1: out0[c] (dgamma) += sum_r dy*xhat ; out1[c] (dbeta) += sum_r dy       (X = x, Y = dy)
@@ -401,6 +510,43 @@ extern "C" int cfm_layernorm_bwd_dx_f32(const float* x, const float* gamma, cons
     else if (d <= 2048) LNB(8);
     else LNB(32);
 #undef LNB
+    return cfm_launch_status();
+}
+
+// Both of the above in one pass over x and dy (d <= 2048; wider rows: call the two functions).  dgamma / dbeta are
+// accumulated.  The per-workgroup partial sums go through `workspace` (cfm_layernorm_bwd_workspace_bytes(rows, d) bytes,
+// 16-byte aligned) and are combined in a fixed order: the parameter gradients are reproducible bit for bit.
+static int ln_bwd_rows_per_wave(int64_t rows) {
+    // rows per wave: as many as keep >= ~512 workgroups in the grid (two per CU), at most 8
+    return (int)std::max<int64_t>(1, std::min<int64_t>(8, rows / 2048));
+}
+extern "C" size_t cfm_layernorm_bwd_workspace_bytes(int64_t rows, int d) {
+    if (rows <= 0 || d <= 0) return 0;
+    const int rpw = ln_bwd_rows_per_wave(rows);
+    return (size_t)((rows + 4 * rpw - 1) / (4 * rpw)) * 2 * (size_t)d * sizeof(float);
+}
+extern "C" int cfm_layernorm_bwd_f32(const float* x, const float* gamma, const float* dy, const float* mean, const float* rstd,
+                                     const float* dres_or_null, float* dx, float* dgamma, float* dbeta, int64_t rows, int d,
+                                     void* workspace, size_t workspace_bytes, cfm_stream_t stream) {
+    CFM_REQUIRE(x && gamma && dy && mean && rstd && dx && dgamma && dbeta && workspace, CFM_ERR_NULL);
+    CFM_REQUIRE(workspace_bytes >= cfm_layernorm_bwd_workspace_bytes(rows, d) && CFM_ALIGNED16(workspace), CFM_ERR_BAD_SHAPE);
+    CFM_REQUIRE(rows > 0 && d > 0 && (d & 3) == 0, CFM_ERR_BAD_SHAPE);
+    CFM_REQUIRE(d <= 2048, CFM_ERR_UNSUPPORTED);
+    CFM_REQUIRE(CFM_ALIGNED16(x) && CFM_ALIGNED16(dy) && CFM_ALIGNED16(dx) && CFM_ALIGNED16(gamma) &&
+                (!dres_or_null || CFM_ALIGNED16(dres_or_null)), CFM_ERR_ALIGN);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int rpw = ln_bwd_rows_per_wave(rows);
+    const dim3 grid((unsigned)((rows + 4 * rpw - 1) / (4 * rpw))), block(256);
+    float* partials = static_cast<float*>(workspace);
+#define LNF(V) hipLaunchKernelGGL(layernorm_bwd_fused_kernel<V>, grid, block, 0, s, x, gamma, dy, mean, rstd, dres_or_null, dx, \
+                                  partials, rows, d, rpw)
+    if (d <= 256) LNF(1);
+    else if (d <= 512) LNF(2);
+    else if (d <= 1024) LNF(4);
+    else LNF(8);
+#undef LNF
+    hipLaunchKernelGGL(layernorm_bwd_partials_kernel, dim3((unsigned)((2 * d + 63) / 64)), block, 0, s, partials, (int)grid.x, d,
+                       dgamma, dbeta);
     return cfm_launch_status();
 }
 

@@ -19,6 +19,11 @@ int cfm_bwd16_conv2_weight_bf16(BwdArgs g, hipStream_t s);
 int cfm_bwd16_conv2_weight_f16(BwdArgs g, hipStream_t s);
 int cfm_bwd16_conv2_input_bf16(const float* dz2, const float* w2c, float* dh1, int B, int F1, int T1, int C, hipStream_t s);
 int cfm_bwd16_conv2_input_f16(const float* dz2, const float* w2c, float* dh1, int B, int F1, int T1, int C, hipStream_t s);
+// gemm_dw16_{bf16,f16}.hip
+int cfm_dw16_bf16(const void* dy, int dy16, int64_t ldy, const void* x, int x16, int64_t ldx, float* dw, int64_t ldw, float* db, int N,
+                  int K, int64_t M, float alpha, hipStream_t s);
+int cfm_dw16_f16(const void* dy, int dy16, int64_t ldy, const void* x, int x16, int64_t ldx, float* dw, int64_t ldw, float* db, int N,
+                 int K, int64_t M, float alpha, hipStream_t s);
 
 
 // Argument rules of cfm_gemm_bwd_batched_f32; prec = CFM_PREC_BF16 | CFM_PREC_FP16.
@@ -74,5 +79,24 @@ extern "C" int cfm_subsample_conv2_bwd_input_mfma16_f32(int prec, const float* d
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (prec == CFM_PREC_BF16) return cfm_bwd16_conv2_input_bf16(dz2, w2c, dh1, B, F1, T1, C, s);
     if (prec == CFM_PREC_FP16) return cfm_bwd16_conv2_input_f16(dz2, w2c, dh1, B, F1, T1, C, s);
+    return CFM_ERR_UNSUPPORTED;
+}
+
+// Weight (and bias) gradient of y = x.W^T + b on the 16-bit matrix pipe (gemm_dw16_impl.h):
+//   dw (N,K) += alpha * dy^T.x ;  db (N) += alpha * column sums of dy   (db_or_null = NULL: skipped).  Both ACCUMULATE with
+// atomics: the caller zero-fills.  dy (M,N) and x (M,K) are row-major; *_is_16bit: stored in the 16-bit type of `prec`
+// (leading dimensions in elements of the stored type).  N % 8 == 0, K % 8 == 0, 16-byte aligned rows; CFM_ERR_UNSUPPORTED
+// otherwise (use cfm_gemm_bwd_batched_mfma16_f32 + cfm_colsum_f32).
+extern "C" int cfm_linear_bwd_weight_mfma16_f32(int prec, const void* dy, int dy_is_16bit, int64_t ldy, const void* x,
+                                                int x_is_16bit, int64_t ldx, float* dw, int64_t ldw, float* db_or_null, int N,
+                                                int K, int64_t M, float alpha, cfm_stream_t stream) {
+    CFM_REQUIRE(dy && x && dw, CFM_ERR_NULL);
+    CFM_REQUIRE(N > 0 && K > 0 && M > 0 && ldy >= N && ldx >= K && ldw >= K, CFM_ERR_BAD_SHAPE);
+    CFM_REQUIRE((N & 7) == 0 && (K & 7) == 0, CFM_ERR_UNSUPPORTED);
+    CFM_REQUIRE((ldy & (dy_is_16bit ? 7 : 3)) == 0 && (ldx & (x_is_16bit ? 7 : 3)) == 0, CFM_ERR_UNSUPPORTED);
+    CFM_REQUIRE(CFM_ALIGNED16(dy) && CFM_ALIGNED16(x) && CFM_ALIGNED16(dw), CFM_ERR_ALIGN);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (prec == CFM_PREC_BF16) return cfm_dw16_bf16(dy, dy_is_16bit, ldy, x, x_is_16bit, ldx, dw, ldw, db_or_null, N, K, M, alpha, s);
+    if (prec == CFM_PREC_FP16) return cfm_dw16_f16(dy, dy_is_16bit, ldy, x, x_is_16bit, ldx, dw, ldw, db_or_null, N, K, M, alpha, s);
     return CFM_ERR_UNSUPPORTED;
 }

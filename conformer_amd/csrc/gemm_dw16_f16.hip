@@ -1,0 +1,4 @@
+// f16 half of the 16-bit weight-gradient GEMM (see gemm_dw16_impl.h)
+#define CFM_T16 _Float16
+#define CFM_T16_FN f16
+#include "gemm_dw16_impl.h"

@@ -24,6 +24,7 @@ struct LstmArgs {
     float* save_gates;            // (B, T, 4H) post-activation i|f|g|o, or null
     float* save_c;                // (B, T, H)  c_t, or null
     int B, T, H;
+    unsigned long long* trace;    // diagnostics: s_memrealtime stamps (8 per step) of thread 0 of workgroups (0,0) and (last,last)
 };
 
 __device__ __forceinline__ float sigmoid_precise(float x) { return 1.0f / (1.0f + __expf(-x)); }
@@ -37,66 +38,83 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(const LstmArgs a, const 
     const int u0 = blockIdx.x * 4;                        // hidden units u0..u0+3
     const int b0 = blockIdx.y * (RB * 16);
     const int H = a.H;
+    const bool first = blockIdx.x == 0 && blockIdx.y == 0, lastwg = blockIdx.x == gridDim.x - 1 && blockIdx.y == gridDim.y - 1;
+    unsigned long long* tr = (a.trace && tid == 0 && (first || lastwg)) ? a.trace + ((int64_t)t * 2 + (lastwg ? 1 : 0)) * 8 : nullptr;
+#define LSTM_STAMP(i) do { if (tr) tr[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+    LSTM_STAMP(0);
+
+    // Gate-stage operands of this thread (one thread per (utterance, unit)): requested BEFORE the contraction so that their
+    // latency overlaps it -- the step is a chain of dependent memory round trips, not arithmetic.
+    const int bl = tid >> 2, u = tid & 3;
+    const int b = b0 + bl, unit = u0 + u;
+    const bool mine = bl < RB * 16 && b < a.B && unit < H;
+    const int bc = min(b, a.B - 1), uc = min(unit, H - 1);
+    const float* gxr = a.gx + ((int64_t)bc * a.T + t) * 4 * H + uc;
+    float gxv[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) gxv[q] = gxr[(int64_t)q * H];
+    const float cprev = t > 0 ? a.c[(int64_t)bc * H + uc] : 0.f;
+    const bool live = !a.lengths || t < a.lengths[bc];
 
     f32x4 acc[RB];
 #pragma unroll
     for (int r = 0; r < RB; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (t > 0) {
         // B operand: column l16 = gate q (l16 >> 2), unit u0 + (l16 & 3)  ->  W_hh row q*H + unit
-        const int unit = u0 + (l16 & 3);
-        const float* wrow = a.whh + ((int64_t)(l16 >> 2) * H + min(unit, H - 1)) * H;
+        // (columns of units >= H and rows of utterances >= B are computed on clamped addresses and never read back)
+        const float* wrow = a.whh + ((int64_t)(l16 >> 2) * H + min(u0 + (l16 & 3), H - 1)) * H;
         const float* hrow[RB];
-        bool hok[RB];
 #pragma unroll
-        for (int r = 0; r < RB; ++r) {
-            const int b = b0 + 16 * r + l16;
-            hok[r] = b < a.B;
-            hrow[r] = a.y + ((int64_t)min(b, a.B - 1) * a.T + (t - 1)) * H;
-        }
+        for (int r = 0; r < RB; ++r) hrow[r] = a.y + ((int64_t)min(b0 + 16 * r + l16, a.B - 1) * a.T + (t - 1)) * H;
         const int nchunk = (H + 15) / 16;
-        for (int ch = wave; ch < nchunk; ch += 4) {
-            const int k = 16 * ch + 4 * kq;
-            const bool kok = k < H;                           // H % 4 == 0: a 16-byte chunk is all in or all out
-            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-            const f32x4 wv = (kok && unit < H) ? *reinterpret_cast<const f32x4*>(wrow + k) : z;
-            f32x4 hv[RB];
+        constexpr int NBAT = 5;                               // chunks in flight per wave: ALL loads of a batch are issued first
+        for (int c0 = wave; c0 < nchunk; c0 += 4 * NBAT) {
+            f32x4 wv[NBAT], hv[NBAT][RB];
 #pragma unroll
-            for (int r = 0; r < RB; ++r) hv[r] = (kok && hok[r]) ? *reinterpret_cast<const f32x4*>(hrow[r] + k) : z;
+            for (int j = 0; j < NBAT; ++j) {
+                const int k = 16 * (c0 + 4 * j) + 4 * kq;     // H % 4 == 0: a 16-byte chunk is all in or all out
+                const int kc = min(k, H - 4);
+                wv[j] = *reinterpret_cast<const f32x4*>(wrow + kc);
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
+                for (int r = 0; r < RB; ++r) hv[j][r] = *reinterpret_cast<const f32x4*>(hrow[r] + kc);
+            }
 #pragma unroll
-                for (int r = 0; r < RB; ++r) acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(hv[r][e], wv[e], acc[r], 0, 0, 0);
+            for (int j = 0; j < NBAT; ++j) {
+                const int k = 16 * (c0 + 4 * j) + 4 * kq;
+                const f32x4 w = k < H ? wv[j] : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int r = 0; r < RB; ++r) acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(hv[j][r][e], w[e], acc[r], 0, 0, 0);
+            }
         }
     }
     // D layout: lane holds column l16, rows 4*kq + {0..3} of each 16-row block
+    LSTM_STAMP(1);
 #pragma unroll
     for (int r = 0; r < RB; ++r)
 #pragma unroll
         for (int i = 0; i < 4; ++i) part[wave][16 * r + 4 * kq + i][l16] = acc[r][i];
+    LSTM_STAMP(2);
     __syncthreads();
-    const int bl = tid >> 2, u = tid & 3;                  // one thread per (utterance, unit)
-    const int b = b0 + bl, unit = u0 + u;
-    if (bl >= RB * 16 || b >= a.B || unit >= H) return;
-    const bool live = !a.lengths || t < a.lengths[b];
+    LSTM_STAMP(3);
+    if (!mine) return;
     float* yo = a.y + ((int64_t)b * a.T + t) * H + unit;
     if (!live) {                                           // beyond the utterance: zero output, state frozen
         *yo = 0.f;
-        if (a.save_c) a.save_c[((int64_t)b * a.T + t) * H + unit] = a.c[(int64_t)b * H + unit];
+        if (a.save_c) a.save_c[((int64_t)b * a.T + t) * H + unit] = cprev;
         if (a.save_gates) {
             float* sg = a.save_gates + ((int64_t)b * a.T + t) * 4 * H + unit;
             sg[0] = 0.f; sg[H] = 0.f; sg[2 * H] = 0.f; sg[3 * H] = 0.f;
         }
         return;
     }
-    const float* gxr = a.gx + ((int64_t)b * a.T + t) * 4 * H + unit;
     float pre[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q)
-        pre[q] = gxr[(int64_t)q * H] + ((part[0][bl][4 * q + u] + part[1][bl][4 * q + u]) +
-                                        (part[2][bl][4 * q + u] + part[3][bl][4 * q + u]));
+        pre[q] = gxv[q] + ((part[0][bl][4 * q + u] + part[1][bl][4 * q + u]) + (part[2][bl][4 * q + u] + part[3][bl][4 * q + u]));
     const float ig = sigmoid_precise(pre[0]), fg = sigmoid_precise(pre[1]), gg = tanh_precise(pre[2]),
                 og = sigmoid_precise(pre[3]);
-    const float cprev = t > 0 ? a.c[(int64_t)b * H + unit] : 0.f;
     const float cn = fg * cprev + ig * gg;
     a.c[(int64_t)b * H + unit] = cn;
     *yo = og * tanh_precise(cn);
@@ -105,6 +123,9 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(const LstmArgs a, const 
         float* sg = a.save_gates + ((int64_t)b * a.T + t) * 4 * H + unit;
         sg[0] = ig; sg[H] = fg; sg[2 * H] = gg; sg[3 * H] = og;
     }
+    LSTM_STAMP(4);
+    if (tr) { __builtin_amdgcn_s_waitcnt(0); tr[5] = __builtin_amdgcn_s_memrealtime(); }
+#undef LSTM_STAMP
 }
 
 // ---- backward through time ---------------------------------------------------------------------------------------------
@@ -133,32 +154,49 @@ __global__ __launch_bounds__(512) void lstm_bwd_step_kernel(const LstmBwdArgs a,
     const int b0 = blockIdx.y * (RB * 16);
     const int H = a.H, H4 = 4 * a.H;
 
+    // gate-stage operands of this thread (one (utterance, unit) per thread), requested before the contraction (see the forward)
+    static_assert(RB * 256 <= 512, "one (utterance, unit) per thread");
+    const int bl = tid >> 4, u = tid & 15;
+    const int b = b0 + bl, unit = u0 + u;
+    const bool mine = tid < RB * 256 && b < a.B && unit < H;
+    const int bc = min(b, a.B - 1), uc = min(unit, H - 1);
+    const int64_t bt = (int64_t)bc * a.T + t;
+    const bool live = !a.lengths || t < a.lengths[bc];
+    const float dy = a.dy[bt * H + uc];
+    const float* sg = a.gates + bt * H4 + uc;
+    const float ig = sg[0], fg = sg[H], gg = sg[2 * H], og = sg[3 * H];
+    const float ct = a.cells[bt * H + uc];
+    const float cprev = t > 0 ? a.cells[(bt - 1) * H + uc] : 0.f;
+    const float dcn = t + 1 < a.T ? a.dc[(int64_t)bc * H + uc] : 0.f;
+
     f32x4 acc[RB];
 #pragma unroll
     for (int r = 0; r < RB; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (t + 1 < a.T) {
-        const int unit = u0 + l16;
-        const float* wrow = a.whh_t + (int64_t)min(unit, H - 1) * H4;
+        // (columns of units >= H and rows of utterances >= B are computed on clamped addresses and never read back)
+        const float* wrow = a.whh_t + (int64_t)min(u0 + l16, H - 1) * H4;
         const float* grow[RB];
-        bool gok[RB];
 #pragma unroll
-        for (int r = 0; r < RB; ++r) {
-            const int b = b0 + 16 * r + l16;
-            gok[r] = b < a.B;
-            grow[r] = a.dgates + ((int64_t)min(b, a.B - 1) * a.T + (t + 1)) * H4;
-        }
+        for (int r = 0; r < RB; ++r) grow[r] = a.dgates + ((int64_t)min(b0 + 16 * r + l16, a.B - 1) * a.T + (t + 1)) * H4;
         const int nchunk = H4 / 16;                              // H % 4 == 0 -> 4H % 16 == 0
-        for (int ch = wave; ch < nchunk; ch += 8) {
-            const int k = 16 * ch + 4 * kq;
-            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-            const f32x4 wv = unit < H ? *reinterpret_cast<const f32x4*>(wrow + k) : z;
-            f32x4 gv[RB];
+        constexpr int NBAT = 5;                                  // chunks in flight per wave: all loads of a batch are issued first
+        for (int c0 = wave; c0 < nchunk; c0 += 8 * NBAT) {
+            f32x4 wv[NBAT], gv[NBAT][RB];
 #pragma unroll
-            for (int r = 0; r < RB; ++r) gv[r] = gok[r] ? *reinterpret_cast<const f32x4*>(grow[r] + k) : z;
+            for (int j = 0; j < NBAT; ++j) {
+                const int k = 16 * min(c0 + 8 * j, nchunk - 1) + 4 * kq;
+                wv[j] = *reinterpret_cast<const f32x4*>(wrow + k);
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
+                for (int r = 0; r < RB; ++r) gv[j][r] = *reinterpret_cast<const f32x4*>(grow[r] + k);
+            }
 #pragma unroll
-                for (int r = 0; r < RB; ++r) acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(gv[r][e], wv[e], acc[r], 0, 0, 0);
+            for (int j = 0; j < NBAT; ++j) {
+                const f32x4 w = c0 + 8 * j < nchunk ? wv[j] : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int r = 0; r < RB; ++r) acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(gv[j][r][e], w[e], acc[r], 0, 0, 0);
+            }
         }
     }
 #pragma unroll
@@ -166,33 +204,23 @@ __global__ __launch_bounds__(512) void lstm_bwd_step_kernel(const LstmBwdArgs a,
 #pragma unroll
         for (int i = 0; i < 4; ++i) part[wave][16 * r + 4 * kq + i][l16] = acc[r][i];
     __syncthreads();
-    for (int e = tid; e < RB * 16 * 16; e += 512) {              // one (utterance, unit) per thread
-        const int bl = e >> 4, u = e & 15;
-        const int b = b0 + bl, unit = u0 + u;
-        if (b >= a.B || unit >= H) continue;
-        float* dg = a.dgates + ((int64_t)b * a.T + t) * H4 + unit;
-        const bool live = !a.lengths || t < a.lengths[b];
-        if (!live) {
-            dg[0] = 0.f; dg[H] = 0.f; dg[2 * H] = 0.f; dg[3 * H] = 0.f;
-            a.dc[(int64_t)b * H + unit] = 0.f;
-            continue;
-        }
-        float dh = a.dy[((int64_t)b * a.T + t) * H + unit];
-#pragma unroll
-        for (int w = 0; w < 8; ++w) dh += part[w][bl][u];
-        const float* sg = a.gates + ((int64_t)b * a.T + t) * H4 + unit;
-        const float ig = sg[0], fg = sg[H], gg = sg[2 * H], og = sg[3 * H];
-        const float ct = a.cells[((int64_t)b * a.T + t) * H + unit];
-        const float cprev = t > 0 ? a.cells[((int64_t)b * a.T + t - 1) * H + unit] : 0.f;
-        const float th = tanh_precise(ct);
-        const float dcn = t + 1 < a.T ? a.dc[(int64_t)b * H + unit] : 0.f;
-        const float dct = dh * og * (1.0f - th * th) + dcn;
-        dg[0] = dct * gg * ig * (1.0f - ig);
-        dg[H] = dct * cprev * fg * (1.0f - fg);
-        dg[2 * H] = dct * ig * (1.0f - gg * gg);
-        dg[3 * H] = dh * th * og * (1.0f - og);
-        a.dc[(int64_t)b * H + unit] = dct * fg;
+    if (!mine) return;
+    float* dg = a.dgates + bt * H4 + unit;
+    if (!live) {
+        dg[0] = 0.f; dg[H] = 0.f; dg[2 * H] = 0.f; dg[3 * H] = 0.f;
+        a.dc[(int64_t)b * H + unit] = 0.f;
+        return;
     }
+    float dh = dy;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) dh += part[w][bl][u];
+    const float th = tanh_precise(ct);
+    const float dct = dh * og * (1.0f - th * th) + dcn;
+    dg[0] = dct * gg * ig * (1.0f - ig);
+    dg[H] = dct * cprev * fg * (1.0f - fg);
+    dg[2 * H] = dct * ig * (1.0f - gg * gg);
+    dg[3 * H] = dh * th * og * (1.0f - og);
+    a.dc[(int64_t)b * H + unit] = dct * fg;
 }
 
 // y = BatchNorm1d(eval)(swish(h)) per channel (decoder.py:23-26 with running statistics)
@@ -300,6 +328,13 @@ __global__ __launch_bounds__(256) void swish_bn_bwd_kernel(const float* __restri
 
 }  // namespace
 
+static unsigned long long* g_lstm_trace = nullptr;
+// diagnostics: T x 2 x 8 uint64 stamps (100 MHz) of the forward steps; NULL switches the trace off
+extern "C" int cfm_debug_lstm_trace(void* trace_or_null) {
+    g_lstm_trace = static_cast<unsigned long long*>(trace_or_null);
+    return CFM_OK;
+}
+
 // gates_x (B,T,4H) = X.W_ih^T + b_ih + b_hh (caller's GEMM); w_hh (4H,H) PyTorch layout (gate order i|f|g|o);
 // lengths_or_null (B) int64: frames per utterance (pack_padded_sequence); y (B,T,H) <- h_t (0 beyond the length);
 // c_state (B,H) scratch for the cell state (need not be initialised); save_gates_or_null (B,T,4H) / save_c_or_null (B,T,H):
@@ -310,7 +345,7 @@ extern "C" int cfm_lstm_fwd_f32(const float* gates_x, const float* w_hh, const i
     CFM_REQUIRE(gates_x && w_hh && y && c_state, CFM_ERR_NULL);
     CFM_REQUIRE(B > 0 && T > 0 && H > 0 && (H & 3) == 0, CFM_ERR_BAD_SHAPE);
     CFM_REQUIRE(CFM_ALIGNED16(w_hh) && CFM_ALIGNED16(y), CFM_ERR_ALIGN);
-    const LstmArgs a{gates_x, w_hh, lengths_or_null, y, c_state, save_gates_or_null, save_c_or_null, B, T, H};
+    const LstmArgs a{gates_x, w_hh, lengths_or_null, y, c_state, save_gates_or_null, save_c_or_null, B, T, H, g_lstm_trace};
     hipStream_t s = static_cast<hipStream_t>(stream);
     const dim3 grid((unsigned)(H / 4), (unsigned)((B + 15) / 16));
     for (int t = 0; t < T; ++t) hipLaunchKernelGGL(lstm_step_kernel<1>, grid, dim3(256), 0, s, a, t);

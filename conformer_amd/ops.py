@@ -473,10 +473,18 @@ def layernorm_bwd(x, weight, dy, mean, rstd, dres=None):
     dx = torch.empty_like(x)
     if dres is not None:
         dres = _req(dres, "dres")
+    dw, db = _zeros_split(x.device, x.dtype, (d,), (d,))
+    if d <= 2048:                                  # one pass over x and dy: input and parameter gradients together
+        nws = int(lib.cfm_layernorm_bwd_workspace_bytes(rows, d))
+        ws = torch.empty(nws // 4, device=x.device, dtype=torch.float32)
+        _lib.check(lib.cfm_layernorm_bwd_f32(x.data_ptr(), weight.data_ptr(), dy.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                             _p(dres), dx.data_ptr(), dw.data_ptr(), db.data_ptr(), rows, d, ws.data_ptr(), nws,
+                                             _stream()),
+                   "cfm_layernorm_bwd_f32")
+        return dx, dw, db
     _lib.check(lib.cfm_layernorm_bwd_dx_f32(x.data_ptr(), weight.data_ptr(), dy.data_ptr(), mean.data_ptr(),
                                             rstd.data_ptr(), _p(dres), dx.data_ptr(), rows, d, _stream()),
                "cfm_layernorm_bwd_dx_f32")
-    dw, db = _zeros_split(x.device, x.dtype, (d,), (d,))
     _lib.check(lib.cfm_layernorm_bwd_params_f32(x.data_ptr(), dy.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
                                                 dw.data_ptr(), db.data_ptr(), rows, d, _stream()),
                "cfm_layernorm_bwd_params_f32")
@@ -639,10 +647,20 @@ def linear_bwd(x2d, w, dy2d, *, alpha: float = 1.0, Z=None, need_dx: bool = True
         w16 = weight16(w2, prec) if prec else None              # the cast the forward made (same parameter version)
         dx = gemm_bwd(dy2d, False, w2 if w16 is None else w16, True, m, k, n, alpha=alpha, Z=Z, drop_p=drop_p,
                       drop_seed=drop_seed, prec=prec, b16=w16 is not None)
-    dw, db = _zeros_split(dy2d.device, dy2d.dtype, (n, k), (n,))
-    gemm_bwd(dy2d, True, x2d, True, n, k, m, alpha=alpha, allow_split=True, out=dw, prec=prec,
-             b16=x2d.dtype != torch.float32)            # x saved in the 16-bit type by its producer (for_gemm)
-    colsum(dy2d, alpha, out=db)
+    dw, db = _zeros_split(dy2d.device, torch.float32, (n, k), (n,))
+    x16, dy16 = x2d.dtype != torch.float32, dy2d.dtype != torch.float32   # stored in the 16-bit type by their producers
+    if (prec and n % 8 == 0 and k % 8 == 0 and x2d.stride(1) == 1 and dy2d.stride(1) == 1
+            and x2d.stride(0) % (8 if x16 else 4) == 0 and dy2d.stride(0) % (8 if dy16 else 4) == 0
+            and x2d.data_ptr() % 16 == 0 and dy2d.data_ptr() % 16 == 0):
+        # weight and bias gradient in one kernel (gemm_dw16_impl.h): dY is read once
+        _lib.check(_lib.load().cfm_linear_bwd_weight_mfma16_f32(prec, dy2d.data_ptr(), int(dy16), dy2d.stride(0), x2d.data_ptr(),
+                                                                int(x16), x2d.stride(0), dw.data_ptr(), k, db.data_ptr(), n, k, m,
+                                                                alpha, _stream()), "cfm_linear_bwd_weight_mfma16_f32")
+    else:
+        if dy16:
+            raise _lib.ConformerHipError("a 16-bit dY needs the aligned 16-bit weight-gradient kernel (N % 8 == 0, K % 8 == 0)")
+        gemm_bwd(dy2d, True, x2d, True, n, k, m, alpha=alpha, allow_split=True, out=dw, prec=prec, b16=x16)
+        colsum(dy2d, alpha, out=db)
     return dx, dw.view_as(w), db
 
 

@@ -154,6 +154,13 @@ int cfm_gemm_bwd_batched_mfma16_f32(int prec, const float* A, int a_col, int64_t
                                     int operands_zero_padded4, cfm_stream_t stream);
 /*      operands_zero_padded4: ragged Kc (index-major operands) / I, J (contraction-major operands) are physically padded
  *      to a multiple of 4 elements with zeros, so partial 16-byte chunks may be loaded whole (the fast load path). */
+/* Weight (and bias) gradient of y = x.W^T + b on the 16-bit matrix pipe: dw (N,K) += alpha * dy^T.x,
+ * db (N) += alpha * colsum(dy) (NULL: skipped); both accumulate with atomics (caller zero-fills).  dy (M,N), x (M,K)
+ * row-major, either may be stored in the 16-bit type of `prec` (ld in elements).  N % 8 == 0, K % 8 == 0.
+ * Replaces the autograd of nn.Linear under autocast (reference model/utils/ffn.py:15-23). */
+int cfm_linear_bwd_weight_mfma16_f32(int prec, const void* dy, int dy_is_16bit, int64_t ldy, const void* x,
+                                     int x_is_16bit, int64_t ldx, float* dw, int64_t ldw, float* db_or_null, int N,
+                                     int K, int64_t M, float alpha, cfm_stream_t stream);
 int cfm_subsample_conv2_bwd_weight_mfma16_f32(int prec, const float* dz2, const float* h1, float* dw2p, int B, int F1,
                                               int T1, int C, cfm_stream_t stream);
 int cfm_subsample_conv2_bwd_input_mfma16_f32(int prec, const float* dz2, const float* w2c, float* dh1, int B, int F1,
@@ -218,6 +225,12 @@ int cfm_layernorm_bwd_dx_f32(const float* x, const float* gamma, const float* dy
                              cfm_stream_t stream);
 int cfm_layernorm_bwd_params_f32(const float* x, const float* dy, const float* mean, const float* rstd,
                                  float* dgamma, float* dbeta, int64_t rows, int d, cfm_stream_t stream);
+/* Both in one pass over x and dy (d <= 2048); per-workgroup partial sums go through `workspace` and are combined
+ * in a fixed order (bit-reproducible parameter gradients). */
+size_t cfm_layernorm_bwd_workspace_bytes(int64_t rows, int d);
+int cfm_layernorm_bwd_f32(const float* x, const float* gamma, const float* dy, const float* mean,
+                          const float* rstd, const float* dres_or_null, float* dx, float* dgamma, float* dbeta,
+                          int64_t rows, int d, void* workspace, size_t workspace_bytes, cfm_stream_t stream);
 
 /* out[c] += alpha * sum_r X[r][c]  (bias gradients; out accumulated). */
 int cfm_colsum_f32(const float* X, int64_t ld, int64_t rows, int cols, float alpha, float* out,
@@ -273,6 +286,7 @@ int cfm_relpos_attention_bwd_mfma16_f32(int prec, const float* q, const float* k
 /* diagnostics: per-phase s_memrealtime stamps of one wave of the fused attention backward (see the .hip file) */
 int cfm_debug_attention_bwd_trace_f32(void* trace_or_null);
 int cfm_debug_attention_bwd_trace_mfma16(void* trace_or_null);
+int cfm_debug_lstm_trace(void* trace_or_null);            /* T x 2 x 8 stamps of cfm_lstm_fwd_f32's steps */
 int cfm_debug_gemm_mfma16_force_tile(int tile);           /* tuning: 0 auto, 1 128x128 family, 2 256x128, 3 256x256 */
 int cfm_debug_gemm_mfma16_trace(void* trace_or_null);     /* per-K-tile stamps of two workgroups of cfm_gemm_mfma16_f32 */
 
