@@ -33,7 +33,7 @@ SIGNATURES = {
     "cfm_relpos_attention_mfma16_f32": (c_int, [_I, _P, _P, _P, _L, _P, _L, _P, _P, _P, _P, _L, _P, _I, _I, _I, _I, _F, _U, _P]),
     "cfm_subsample_conv2_relu_mfma16_f32": (c_int, [_I, _P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P]),
     "cfm_subsample_conv1_relu_out16_f32": (c_int, [_I, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
-    "cfm_gemm_bwd_batched_mfma16_f32": (c_int, [_I, _P, _I, _L, _P, _I, _I, _L, _P, _L, _F, _P, _L, _I, _I, _L, _I, _I, _I, _I,
+    "cfm_gemm_bwd_batched_mfma16_f32": (c_int, [_I, _P, _I, _L, _P, _I, _I, _L, _P, _L, _F, _P, _L, _I, _I, _I, _L, _I, _I, _I, _I,
                                                 _L, _L, _L, _L, _L, _L, _F, _U, _I, _P]),
     "cfm_subsample_conv2_bwd_weight_mfma16_f32": (c_int, [_I, _P, _P, _P, _I, _I, _I, _I, _P]),
     "cfm_subsample_conv2_bwd_input_mfma16_f32": (c_int, [_I, _P, _P, _P, _I, _I, _I, _I, _P]),
@@ -75,6 +75,7 @@ SIGNATURES = {
     "cfm_greedy_ctc_decode_f32": (c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "cfm_lstm_fwd_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "cfm_debug_lstm_trace": (c_int, [_P]),
+    "cfm_debug_dw16_trace": (c_int, [_P]),
     "cfm_linear_bwd_weight_mfma16_f32": (c_int, [_I, _P, _I, _L, _P, _I, _L, _P, _L, _P, _I, _I, _L, _F, _P]),
     "cfm_lstm_bwd_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "cfm_swish_bn_eval_f32": (c_int, [_P, _P, _P, _P, _P, _F, _P, _L, _I, _P]),

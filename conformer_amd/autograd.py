@@ -126,8 +126,9 @@ class FeedForwardFn(Function):
         dout = dout.contiguous()
         d2 = ops.dropout_apply(dout, ctx.drop_p, ctx.seeds[1])       # gradient w.r.t. the out-projection result
         # d(pre-activation) = alpha * (d2 . W2) * mask1 * swish'(z); dW2 = alpha * d2^T . h (h already carries mask1)
+        # (dz only feeds the two GEMMs below: under autocast it is stored in the 16-bit type they would round it to)
         dz, dw2, db2 = ops.linear_bwd(_flat(h), w2, _flat(d2), alpha=ctx.alpha, Z=_flat(z), drop_p=ctx.drop_p,
-                                      drop_seed=ctx.seeds[0])
+                                      drop_seed=ctx.seeds[0], dx16=True)
         dh0, dw1, db1 = ops.linear_bwd(_flat(h0), w1, dz)
         dx, dlw, dlb = ops.layernorm_bwd(x, ln_w, dh0.view_as(x), mean, rstd, dres=dout)
         return dx, dlw, dlb, dw1, db1, dw2, db2, None, None, None

@@ -13,6 +13,7 @@ struct BwdArgs {
     float drop_p; unsigned long long drop_seed;   // DSWISH: the forward dropped swish(Z): re-apply its mask to the incoming gradient
     int accumulate;                      // C += ... (non-atomic read-modify-write; not combined with splits)
     int b16;                             // 16-bit kernels: operand B is already stored in the 16-bit type (ldb/sb* in elements)
+    int c16;                             // 16-bit kernels, DSWISH only: C is stored in the 16-bit type (1 bf16 | 2 fp16; ldc in elements)
     int pad4;                            // 16-bit kernels: ragged Kc / I / J are physically padded to a multiple of 4 with zeros
     int nbatch, nb1;                     // batched: blockIdx.z = b0*nb1 + b1; operand offset = b0*s?0 + b1*s?1
     int64_t sa0, sa1, sb0, sb1, sc0, sc1;
@@ -134,6 +135,14 @@ __device__ __forceinline__ void bwd_epilogue_rows_lds(const BwdArgs& g, float* C
                 const int b = row / per, r = row - b * per;
                 const int a = r / g.pC, c = r - a * g.pC;
                 crow = ((int64_t)b * g.cT1 + 2 * a + g.pt) * g.cF1 + 2 * c + g.pf;
+            }
+            if (g.c16) {                                                   // gradient stored for GEMM consumers only: 8-byte stores
+                typedef __bf16 bf4 __attribute__((ext_vector_type(4)));
+                typedef _Float16 hf4 __attribute__((ext_vector_type(4)));
+                void* d16 = reinterpret_cast<char*>(Cb) + (crow * g.ldc + col) * 2;
+                if (g.c16 == 1) *reinterpret_cast<bf4*>(d16) = bf4{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+                else *reinterpret_cast<hf4*>(d16) = hf4{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+                continue;
             }
             float* dst = Cb + crow * g.ldc + col;
             if (g.accumulate) v = v + *reinterpret_cast<const f32x4*>(dst);

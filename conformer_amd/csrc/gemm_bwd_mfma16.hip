@@ -20,6 +20,8 @@ int cfm_bwd16_conv2_weight_f16(BwdArgs g, hipStream_t s);
 int cfm_bwd16_conv2_input_bf16(const float* dz2, const float* w2c, float* dh1, int B, int F1, int T1, int C, hipStream_t s);
 int cfm_bwd16_conv2_input_f16(const float* dz2, const float* w2c, float* dh1, int B, int F1, int T1, int C, hipStream_t s);
 // gemm_dw16_{bf16,f16}.hip
+void cfm_dw16_trace_bf16(void* p);
+void cfm_dw16_trace_f16(void* p);
 int cfm_dw16_bf16(const void* dy, int dy16, int64_t ldy, const void* x, int x16, int64_t ldx, float* dw, int64_t ldw, float* db, int N,
                   int K, int64_t M, float alpha, hipStream_t s);
 int cfm_dw16_f16(const void* dy, int dy16, int64_t ldy, const void* x, int x16, int64_t ldx, float* dw, int64_t ldw, float* db, int N,
@@ -28,8 +30,8 @@ int cfm_dw16_f16(const void* dy, int dy16, int64_t ldy, const void* x, int x16, 
 
 // Argument rules of cfm_gemm_bwd_batched_f32; prec = CFM_PREC_BF16 | CFM_PREC_FP16.
 extern "C" int cfm_gemm_bwd_batched_mfma16_f32(int prec, const float* A, int a_col, int64_t lda, const void* B, int b_col,
-                                               int b_is_16bit, int64_t ldb, const float* Z_or_null, int64_t ldz, float alpha, float* C,
-                                               int64_t ldc, int I, int J, int64_t Kc, int allow_split, int accumulate,
+                                               int b_is_16bit, int64_t ldb, const float* Z_or_null, int64_t ldz, float alpha, void* C,
+                                               int64_t ldc, int c_is_16bit, int I, int J, int64_t Kc, int allow_split, int accumulate,
                                                int nbatch, int nb1, int64_t sa0, int64_t sa1, int64_t sb0, int64_t sb1,
                                                int64_t sc0, int64_t sc1, float drop_p, uint64_t drop_seed,
                                                int operands_zero_padded4, cfm_stream_t stream) {
@@ -41,10 +43,13 @@ extern "C" int cfm_gemm_bwd_batched_mfma16_f32(int prec, const float* A, int a_c
     CFM_REQUIRE(CFM_ALIGNED16(A) && CFM_ALIGNED16(B) && CFM_ALIGNED16(C), CFM_ERR_ALIGN);
     CFM_REQUIRE(!Z_or_null || (CFM_ALIGNED16(Z_or_null) && (ldz & 3) == 0), CFM_ERR_ALIGN);
     CFM_REQUIRE(!Z_or_null || (!a_col && b_col && nbatch == 1), CFM_ERR_UNSUPPORTED);
+    // a 16-bit C: only the swish'(Z) product (its result feeds GEMM operands), whole 16-byte chunks, plain stores
+    CFM_REQUIRE(!c_is_16bit || (Z_or_null && !accumulate && (J & 7) == 0 && (ldc & 7) == 0), CFM_ERR_UNSUPPORTED);
     BwdArgs g{};
     g.b16 = b_is_16bit != 0;
     g.pad4 = operands_zero_padded4 != 0;
-    g.A = A; g.B = static_cast<const float*>(B); g.Z = Z_or_null; g.C = C; g.I = I; g.J = J; g.Kc = Kc;
+    g.c16 = c_is_16bit ? prec : 0;
+    g.A = A; g.B = static_cast<const float*>(B); g.Z = Z_or_null; g.C = static_cast<float*>(C); g.I = I; g.J = J; g.Kc = Kc;
     g.lda = lda; g.ldb = ldb; g.ldz = ldz; g.ldc = ldc; g.alpha = alpha;
     g.splits = (allow_split && !accumulate) ? 0 : 1;
     g.accumulate = accumulate; g.nbatch = nbatch; g.nb1 = nb1; g.drop_p = drop_p; g.drop_seed = drop_seed;
@@ -99,4 +104,11 @@ extern "C" int cfm_linear_bwd_weight_mfma16_f32(int prec, const void* dy, int dy
     if (prec == CFM_PREC_BF16) return cfm_dw16_bf16(dy, dy_is_16bit, ldy, x, x_is_16bit, ldx, dw, ldw, db_or_null, N, K, M, alpha, s);
     if (prec == CFM_PREC_FP16) return cfm_dw16_f16(dy, dy_is_16bit, ldy, x, x_is_16bit, ldx, dw, ldw, db_or_null, N, K, M, alpha, s);
     return CFM_ERR_UNSUPPORTED;
+}
+
+// diagnostics: 2 x 64 uint64 stamps (100 MHz) of two workgroups of the next cfm_linear_bwd_weight_mfma16_f32 launches
+extern "C" int cfm_debug_dw16_trace(void* trace_or_null) {
+    cfm_dw16_trace_bf16(trace_or_null);
+    cfm_dw16_trace_f16(trace_or_null);
+    return CFM_OK;
 }

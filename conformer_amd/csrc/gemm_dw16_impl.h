@@ -21,6 +21,8 @@
 //     column tile from the dY registers they stage anyway (no separate column-sum pass over dY).
 // Requirements (checked by the launcher; otherwise the caller falls back to the general kernel): I % 8 == 0, J % 8 == 0,
 // 16-byte aligned bases and leading dimensions, (k_per_split + 64) * ld * sizeof(elem) < 2^31.
+#include <stdlib.h>
+
 #include <type_traits>
 
 #include "cfm_common.h"
@@ -33,12 +35,14 @@ struct DwArgs {
     int I, J; int64_t Kc, k_per_split;
     float alpha;
     unsigned tiles_i, tiles_j;
+    unsigned long long* trace;        // diagnostics: s_memrealtime stamps of thread 0 of workgroups 0 and nwg/2 (64 each)
 };
 
 template <typename T16, bool A16, bool B16>
 __global__ __launch_bounds__(256, 2) void gemm_dw16_kernel(const DwArgs g) {
     using x8 = typename Lowp<T16>::x8;
     using x4 = typename Lowp<T16>::x4;
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
     constexpr int BM = 128, BN = 128, BK = 64, RS = BM + 32;          // LDS row stride (elements): see gemm_bwd_mfma16_impl.h
     constexpr int STAGE = BK * RS;
     __shared__ __attribute__((aligned(16))) T16 lds[2 * 2 * STAGE];     // [stage][A | B][k][index]
@@ -62,7 +66,7 @@ __global__ __launch_bounds__(256, 2) void gemm_dw16_kernel(const DwArgs g) {
     constexpr int NLA = A16 ? 4 : 8, NLB = B16 ? 4 : 8;
     using RegA = typename std::conditional<A16, x8, f32x4>::type;
     using RegB = typename std::conditional<B16, x8, f32x4>::type;
-    unsigned offa[NLA], offb[NLB], offa0 = 0, offb0 = 0;                // element offsets from the tile base; *0: row 0 (always valid)
+    unsigned offa[NLA], offb[NLB], offa0 = 0, offb0 = 0;                // byte offsets from the tile base; *0: row 0 (always valid)
     int rowa[NLA], rowb[NLB];
     bool cola_ok = false, colb_ok = false;                              // this thread's column chunk is inside the matrix
     // (a fp32 operand's second slot group q = 1 covers the same columns: (tid + 256) & 31 == tid & 31)
@@ -72,8 +76,8 @@ __global__ __launch_bounds__(256, 2) void gemm_dw16_kernel(const DwArgs g) {
         const int col = A16 ? (tid & 15) * 8 : (tid & 31) * 4;
         const int c = min(i0 + col, g.I - (A16 ? 8 : 4));               // (I % 8 == 0: a chunk is all in or all out)
         rowa[p] = kg * 4 + (p & 3);
-        offa[p] = (unsigned)(rowa[p] * g.lda + c);
-        if (p == 0) { offa0 = (unsigned)c; cola_ok = i0 + col < g.I; }
+        offa[p] = (unsigned)(rowa[p] * g.lda + c) * (A16 ? 2u : 4u);         // BYTE offsets (saddr + 32-bit voffset loads)
+        if (p == 0) { offa0 = (unsigned)c * (A16 ? 2u : 4u); cola_ok = i0 + col < g.I; }
     }
 #pragma unroll
     for (int p = 0; p < NLB; ++p) {
@@ -81,8 +85,8 @@ __global__ __launch_bounds__(256, 2) void gemm_dw16_kernel(const DwArgs g) {
         const int col = B16 ? (tid & 15) * 8 : (tid & 31) * 4;
         const int c = min(j0 + col, g.J - (B16 ? 8 : 4));
         rowb[p] = kg * 4 + (p & 3);
-        offb[p] = (unsigned)(rowb[p] * g.ldb + c);
-        if (p == 0) { offb0 = (unsigned)c; colb_ok = j0 + col < g.J; }
+        offb[p] = (unsigned)(rowb[p] * g.ldb + c) * (B16 ? 2u : 4u);
+        if (p == 0) { offb0 = (unsigned)c * (B16 ? 2u : 4u); colb_ok = j0 + col < g.J; }
     }
     const char* baseA = static_cast<const char*>(g.A) + kbeg * g.lda * (A16 ? 2 : 4);
     const char* baseB = static_cast<const char*>(g.B) + kbeg * g.ldb * (B16 ? 2 : 4);
@@ -90,16 +94,26 @@ __global__ __launch_bounds__(256, 2) void gemm_dw16_kernel(const DwArgs g) {
 
     struct Set { RegA a[NLA]; RegB b[NLB]; };
     Set s0, s1;
-    auto load_set = [&](Set& s, int kt) {                               // unconditional loads: rows past the split read row 0 of the tile
-        const int rmax = klen - 1 - kt * BK;
-        const char* pa = baseA + (int64_t)kt * stepA;
-        const char* pb = baseB + (int64_t)kt * stepB;
+    using Fast = std::integral_constant<bool, true>;
+    using Slow = std::integral_constant<bool, false>;
+    auto load_set = [&](auto fast, Set& s, int kt) {
+        if constexpr (decltype(fast)::value) {                          // tile kt is known to be a full tile of this split
+            const char* pa = baseA + (int64_t)kt * stepA;
+            const char* pb = baseB + (int64_t)kt * stepB;
 #pragma unroll
-        for (int p = 0; p < NLA; ++p)
-            s.a[p] = *reinterpret_cast<const RegA*>(pa + (size_t)(rowa[p] <= rmax ? offa[p] : offa0) * (A16 ? 2 : 4));
+            for (int p = 0; p < NLA; ++p) s.a[p] = *reinterpret_cast<const RegA*>(pa + offa[p]);
 #pragma unroll
-        for (int p = 0; p < NLB; ++p)
-            s.b[p] = *reinterpret_cast<const RegB*>(pb + (size_t)(rowb[p] <= rmax ? offb[p] : offb0) * (B16 ? 2 : 4));
+            for (int p = 0; p < NLB; ++p) s.b[p] = *reinterpret_cast<const RegB*>(pb + offb[p]);
+        } else {                                   // UNCONDITIONAL: tiles past the split re-read its last tile (never staged), rows
+            kt = min(kt, nkt - 1);                 // past the split read row 0 of the tile (zeroed when staged)
+            const int rmax = klen - 1 - kt * BK;
+            const char* pa = baseA + (int64_t)kt * stepA;
+            const char* pb = baseB + (int64_t)kt * stepB;
+#pragma unroll
+            for (int p = 0; p < NLA; ++p) s.a[p] = *reinterpret_cast<const RegA*>(pa + (rowa[p] <= rmax ? offa[p] : offa0));
+#pragma unroll
+            for (int p = 0; p < NLB; ++p) s.b[p] = *reinterpret_cast<const RegB*>(pb + (rowb[p] <= rmax ? offb[p] : offb0));
+        }
     };
     // bias gradient: the workgroups of column tile 0 sum the dY values they stage (per thread: its 8 / 4 fixed columns)
     const bool do_colsum = g.colsum != nullptr && tj == 0;
@@ -107,40 +121,37 @@ __global__ __launch_bounds__(256, 2) void gemm_dw16_kernel(const DwArgs g) {
 #pragma unroll
     for (int e = 0; e < (A16 ? 8 : 4); ++e) csum[e] = 0.f;
 
-    auto store_set = [&](const Set& s, int kt, int stage) {
+    auto store_set = [&](auto fast_c, const Set& s, int kt, int stage) {
+        constexpr bool fast = decltype(fast_c)::value;                  // full tile inside the matrix: nothing to zero
         const int rmax = klen - 1 - kt * BK;
         T16* As = lds + stage * 2 * STAGE;
         T16* Bs = As + STAGE;
 #pragma unroll
         for (int p = 0; p < NLA; ++p) {
-            const bool keep = rowa[p] <= rmax && cola_ok;
+            const bool keep = fast || (rowa[p] <= rmax && cola_ok);
             if constexpr (A16) {
                 x8 v = s.a[p];
-                if (!keep)
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = (T16)0.f;
+                if constexpr (!fast) v = __builtin_bit_cast(x8, keep ? __builtin_bit_cast(i32x4, v) : i32x4{0, 0, 0, 0});
                 *reinterpret_cast<x8*>(As + rowa[p] * RS + (tid & 15) * 8) = v;
                 if (do_colsum)
 #pragma unroll
                     for (int e = 0; e < 8; ++e) csum[e] += (float)v[e];
             } else {
                 const f32x4 v = keep ? s.a[p] : f32x4{0.f, 0.f, 0.f, 0.f};
-                *reinterpret_cast<x4*>(As + rowa[p] * RS + ((tid + 256 * (p >> 2)) & 31) * 4) = Lowp<T16>::cvt4(v);
+                *reinterpret_cast<x4*>(As + rowa[p] * RS + (tid & 31) * 4) = Lowp<T16>::cvt4(v);
                 if (do_colsum) { csum[0] += v.x; csum[1] += v.y; csum[2] += v.z; csum[3] += v.w; }
             }
         }
 #pragma unroll
         for (int p = 0; p < NLB; ++p) {
-            const bool keep = rowb[p] <= rmax && colb_ok;
+            const bool keep = fast || (rowb[p] <= rmax && colb_ok);
             if constexpr (B16) {
                 x8 v = s.b[p];
-                if (!keep)
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = (T16)0.f;
+                if constexpr (!fast) v = __builtin_bit_cast(x8, keep ? __builtin_bit_cast(i32x4, v) : i32x4{0, 0, 0, 0});
                 *reinterpret_cast<x8*>(Bs + rowb[p] * RS + (tid & 15) * 8) = v;
             } else {
                 const f32x4 v = keep ? s.b[p] : f32x4{0.f, 0.f, 0.f, 0.f};
-                *reinterpret_cast<x4*>(Bs + rowb[p] * RS + ((tid + 256 * (p >> 2)) & 31) * 4) = Lowp<T16>::cvt4(v);
+                *reinterpret_cast<x4*>(Bs + rowb[p] * RS + (tid & 31) * 4) = Lowp<T16>::cvt4(v);
             }
         }
     };
@@ -192,24 +203,41 @@ __global__ __launch_bounds__(256, 2) void gemm_dw16_kernel(const DwArgs g) {
         }
     };
 
-    // ---- pipeline: LDS stage (kt & 1) holds tile kt, register set ((kt + 1) & 1) holds tile kt + 1 (in flight), the loads of
-    //      tile kt + 2 are issued into set (kt & 1) before tile kt is multiplied.
-    load_set(s0, 0);
-    if (nkt > 1) load_set(s1, 1);
-    store_set(s0, 0, 0);
+    const bool tracer = g.trace && tid == 0 && blockIdx.y == 0 && (blockIdx.x == 0 || blockIdx.x == nwg / 2);
+    unsigned long long* tr = g.trace + (blockIdx.x == 0 ? 0 : 64);
+    if (tracer) tr[0] = __builtin_amdgcn_s_memrealtime();
+    // ---- pipeline: on entry to step kt, LDS stage (kt & 1) holds tile kt, register set `nxt` holds tile kt + 1 and the other
+    //      set tile kt + 2 (both requested earlier); the step multiplies tile kt, stages `nxt` and refills it with tile kt + 3.
+    load_set(Slow{}, s0, 0);
+    store_set(Slow{}, s0, 0, 0);
+    load_set(Slow{}, s1, 1);
+    load_set(Slow{}, s0, 2);
     lds_barrier();
-    auto step = [&](int kt, Set& mine, Set& next) {                     // `mine` = set (kt & 1): free; `next` = set holding tile kt + 1
-        if (kt + 2 < nkt) load_set(mine, kt + 2);
-        __builtin_amdgcn_sched_barrier(0);
+    if (tracer) tr[1] = __builtin_amdgcn_s_memrealtime();
+    auto step = [&](auto fast, int kt, Set& nxt) {
         multiply(kt & 1);
         __builtin_amdgcn_sched_barrier(0);
-        if (kt + 1 < nkt) store_set(next, kt + 1, (kt + 1) & 1);
+        if (decltype(fast)::value || kt + 1 < nkt) store_set(fast, nxt, kt + 1, (kt + 1) & 1);
+        load_set(fast, nxt, kt + 3);
         lds_barrier();
+        if (tracer && kt < 58) tr[2 + kt] = __builtin_amdgcn_s_memrealtime();
     };
-    for (int kt = 0; kt < nkt; kt += 2) {
-        step(kt, s0, s1);
-        if (kt + 1 < nkt) step(kt + 1, s1, s0);
+    // FAST steps: the tile staged (kt + 1) and the tile requested (kt + 3) are full tiles inside the matrix: no selects, no
+    // zeroing, no clamps.  (The first version spent ~2000 of its ~2500 cycles per K-tile on that bookkeeping around 16 MFMAs.)
+    // (only the all-16-bit instantiation: with a fp32 operand the second copy of the loop costs registers the sets need)
+    const int nfast = (A16 && B16 && i0 + BM <= g.I && j0 + BN <= g.J) ? (klen / BK - 3) & ~1 : 0;       // even: the sets keep their roles
+    int kt = 0;
+    if constexpr (A16 && B16) {
+        for (; kt < nfast; kt += 2) {
+            step(Fast{}, kt, s1);
+            step(Fast{}, kt + 1, s0);
+        }
     }
+    for (; kt + 1 < nkt; kt += 2) {
+        step(Slow{}, kt, s1);
+        step(Slow{}, kt + 1, s0);
+    }
+    if (kt < nkt) step(Slow{}, kt, s1);
 
     // ---- epilogue: natural MFMA orientation (lane li = column, register r = row (r&3) + 8 (r>>2) + 4 hf), atomics
 #pragma unroll
@@ -224,6 +252,7 @@ __global__ __launch_bounds__(256, 2) void gemm_dw16_kernel(const DwArgs g) {
                 if (row < g.I) atomicAdd(g.C + (int64_t)row * g.ldc + col, g.alpha * acc[mt][nt][r]);
             }
         }
+    if (tracer) { tr[60] = __builtin_amdgcn_s_memrealtime(); __builtin_amdgcn_s_waitcnt(0); tr[61] = __builtin_amdgcn_s_memrealtime(); }
     if (do_colsum) {
         // threads with equal column chunk: 16-bit: tid & 15 (lanes l, l+16, l+32, l+48); fp32: tid & 31 (lanes l, l+32)
 #pragma unroll
@@ -242,6 +271,8 @@ __global__ __launch_bounds__(256, 2) void gemm_dw16_kernel(const DwArgs g) {
     }
 }
 
+unsigned long long* g_dw16_trace = nullptr;
+
 template <typename T16>
 int launch_dw16(DwArgs g, int a16, int b16, hipStream_t s) {
     g.tiles_i = (unsigned)((g.I + 127) / 128);
@@ -249,6 +280,8 @@ int launch_dw16(DwArgs g, int a16, int b16, hipStream_t s) {
     const unsigned tiles = g.tiles_i * g.tiles_j;
     int splits = 1;
     while ((int64_t)tiles * splits < 448 && g.Kc / (splits * 2) >= 256 && splits < 64) splits *= 2;   // ~2 workgroups per CU
+    static const int forced = [] { const char* e = getenv("CFM_DW16_SPLITS"); return e ? atoi(e) : 0; }();   // tuning only
+    if (forced > 0) splits = forced;
     const int64_t per = (g.Kc + splits - 1) / splits;
     g.k_per_split = (per + 63) / 64 * 64;
     const int64_t span_a = (g.k_per_split + 64) * g.lda * (a16 ? 2 : 4), span_b = (g.k_per_split + 64) * g.ldb * (b16 ? 2 : 4);
@@ -268,9 +301,12 @@ int launch_dw16(DwArgs g, int a16, int b16, hipStream_t s) {
 #define CFM_CAT2(a, b) a##b
 #define CFM_CAT(a, b) CFM_CAT2(a, b)
 
+void CFM_CAT(cfm_dw16_trace_, CFM_T16_FN)(void* p) { g_dw16_trace = static_cast<unsigned long long*>(p); }
+
 int CFM_CAT(cfm_dw16_, CFM_T16_FN)(const void* dy, int dy16, int64_t ldy, const void* x, int x16, int64_t ldx, float* dw, int64_t ldw,
                                    float* db, int N, int K, int64_t M, float alpha, hipStream_t s) {
     DwArgs g{};
+    g.trace = g_dw16_trace;
     g.A = dy; g.B = x; g.C = dw; g.colsum = db; g.lda = ldy; g.ldb = ldx; g.ldc = ldw; g.I = N; g.J = K; g.Kc = M; g.alpha = alpha;
     return launch_dw16<CFM_T16>(g, dy16, x16, s);
 }

@@ -83,25 +83,40 @@ def _ver(t: torch.Tensor) -> int:
 
 
 _W16_CACHE = {}        # data_ptr -> (weakref(base tensor), version, prec, shape, 16-bit tensor): per-optimizer-step weight casts
-def weight16(w: torch.Tensor, prec: int) -> Optional[torch.Tensor]:
+def weight16(w: torch.Tensor, prec: int, transposed: bool = False) -> Optional[torch.Tensor]:
     """The weight matrix rounded to the 16-bit matrix-pipe type, cached until the parameter changes in place (optimizer
-    step / load_state_dict bump `_version`).  None when the 16-bit operand path does not apply (K % 8 != 0)."""
-    if w.shape[-1] % 8 or w.numel() % 4:
+    step / load_state_dict bump `_version`).  None when the 16-bit operand path does not apply (K % 8 != 0).
+    transposed: the (K, N) transpose of the (N, K) weight (the backward's dX = dY.W as a row-major-A forward GEMM)."""
+    if w.shape[-1] % 8 or w.numel() % 4 or (transposed and w.shape[0] % 8):
         return None
-    key = w.data_ptr()
+    key = (w.data_ptr(), transposed)
     base = w._base if w._base is not None else w     # views are re-created per call; the owning tensor identifies the weight
     hit = _W16_CACHE.get(key)
     # (a freed temporary -- e.g. last step's fused QKV matrix -- can hand its address to a new tensor: the weak reference
     # to the owner tells the two apart; `_version` catches in-place updates of a live parameter)
     if hit is not None and hit[0]() is base and hit[1] == _ver(w) and hit[2] == prec and hit[3] == w.shape:
         return hit[4]
-    out = torch.empty(w.shape, device=w.device, dtype=_DT16[prec])
-    _lib.check(_lib.load().cfm_cast16_f32(prec, w.data_ptr(), out.data_ptr(), w.numel(), _stream()), "cfm_cast16_f32")
+    if transposed:
+        out = w.detach().t().to(_DT16[prec]).contiguous()
+    else:
+        out = torch.empty(w.shape, device=w.device, dtype=_DT16[prec])
+        _lib.check(_lib.load().cfm_cast16_f32(prec, w.data_ptr(), out.data_ptr(), w.numel(), _stream()), "cfm_cast16_f32")
     if len(_W16_CACHE) > 4096:
         for k in [k for k, v in _W16_CACHE.items() if v[0]() is None]:
             del _W16_CACHE[k]
     _W16_CACHE[key] = (weakref.ref(base), _ver(w), prec, w.shape, out)
     return out
+
+
+_ZERO_BIAS = {}
+
+
+def _zero_bias(n: int, device) -> torch.Tensor:
+    """A cached all-zero bias vector (read-only) for GEMM entry points that always add one."""
+    t = _ZERO_BIAS.get((n, device))
+    if t is None:
+        t = _ZERO_BIAS[(n, device)] = torch.zeros(n, device=device, dtype=torch.float32)
+    return t
 
 
 # ---- opt-in fp32 matmul mode: exact bf16 operand splitting on the 16x faster bf16 matrix pipe (csrc/gemm_split.hip) -----------
@@ -606,50 +621,67 @@ def colsum(x2d, alpha: float = 1.0, rows=None, cols=None, ld=None, out=None):
 def gemm_bwd(A, a_col: bool, B, b_col: bool, I: int, J: int, Kc: int, *, alpha: float = 1.0, Z=None, out=None,
              lda=None, ldb=None, ldc=None, ldz=None, allow_split: bool = False, accumulate: bool = False,
              nbatch: int = 1, nb1: int = 1, sa=(0, 0), sb=(0, 0), sc=(0, 0), a_ptr=None, b_ptr=None, c_ptr=None,
-             drop_p: float = 0.0, drop_seed: int = 0, prec: int = 0, b16: bool = False, pad4: bool = False):
+             drop_p: float = 0.0, drop_seed: int = 0, prec: int = 0, b16: bool = False, pad4: bool = False,
+             c16: bool = False):
     """C (I,J) (+)= alpha * sum_k A(i,k) B(j,k) [* swish'(Z)]; *_col selects the contraction-major layout.
     Pointers default to the tensors' data_ptr(); explicit *_ptr / ld* let callers address sub-blocks (head slices).
     prec: PREC_F32 (fp32 MFMA) | PREC_BF16 | PREC_FP16 (operands rounded while staged, fp32 accumulate).
     b16: B is a tensor already stored in the 16-bit type of `prec` (contraction-major only; ldb in elements).
-    pad4 (16-bit kernels): ragged Kc / I / J are physically padded to a multiple of 4 with zeros (fast load path)."""
+    pad4 (16-bit kernels): ragged Kc / I / J are physically padded to a multiple of 4 with zeros (fast load path).
+    c16 (16-bit kernels, with Z): C is written in the 16-bit type of `prec` (a gradient that only feeds GEMM operands)."""
     lda = A.stride(-2) if lda is None else lda
     ldb = B.stride(-2) if ldb is None else ldb
     if out is None:
-        out = (torch.zeros if allow_split else torch.empty)(I, J, device=A.device, dtype=A.dtype)
+        out = (torch.zeros if allow_split else torch.empty)(I, J, device=A.device, dtype=_DT16[prec] if c16 else A.dtype)
     ldc = out.stride(-2) if ldc is None else ldc
     ldz = 0 if Z is None else (Z.stride(-2) if ldz is None else ldz)
     head = (A.data_ptr() if a_ptr is None else a_ptr, int(a_col), lda, B.data_ptr() if b_ptr is None else b_ptr, int(b_col))
-    tail = (ldb, _p(Z), ldz, alpha, out.data_ptr() if c_ptr is None else c_ptr, ldc, I, J, Kc, int(allow_split),
+    tail = (ldb, _p(Z), ldz, alpha, out.data_ptr() if c_ptr is None else c_ptr, ldc, int(c16), I, J, Kc, int(allow_split),
             int(accumulate), nbatch, nb1, sa[0], sa[1], sb[0], sb[1], sc[0], sc[1], float(drop_p), int(drop_seed))
     if prec:
         _lib.check(_lib.load().cfm_gemm_bwd_batched_mfma16_f32(prec, *head, int(b16), *tail, int(pad4), _stream()),
                    "cfm_gemm_bwd_batched_mfma16_f32")
     else:
-        if b16:
-            raise _lib.ConformerHipError("a 16-bit B operand needs a 16-bit precision mode")
-        _lib.check(_lib.load().cfm_gemm_bwd_batched_f32(*head, *tail, _stream()), "cfm_gemm_bwd_batched_f32")
+        if b16 or c16:
+            raise _lib.ConformerHipError("16-bit operands / results need a 16-bit precision mode")
+        _lib.check(_lib.load().cfm_gemm_bwd_batched_f32(*head, *tail[:6], *tail[7:], _stream()), "cfm_gemm_bwd_batched_f32")
     return out
 
 
-def linear_bwd(x2d, w, dy2d, *, alpha: float = 1.0, Z=None, need_dx: bool = True, drop_p: float = 0.0, drop_seed: int = 0):
+def linear_bwd(x2d, w, dy2d, *, alpha: float = 1.0, Z=None, need_dx: bool = True, drop_p: float = 0.0, drop_seed: int = 0,
+               dx16: bool = False):
     """Backward of y = x @ w.T + b for 2-D views: returns (dx or None, dw, db), all scaled by alpha;
-    dx is additionally multiplied by swish'(Z) when Z is given (then it is d/d(pre-activation))."""
+    dx is additionally multiplied by swish'(Z) when Z is given (then it is d/d(pre-activation)).
+    dx16 (with Z, under a 16-bit precision mode): dx only feeds GEMM operands (the next layer's dX / dW products round it to
+    the 16-bit type anyway) and is written in that type -- identical results, half the bytes on three passes over it.
+    dy2d may itself be such a 16-bit gradient."""
     m, k = x2d.shape
     n = w.shape[0]
     w2 = w.reshape(n, -1)
     dx = None
     prec = mfma16_prec()
+    dy16 = dy2d.dtype != torch.float32
+    if dy16 and not (prec and dy2d.dtype == _DT16[prec] and n % 8 == 0 and k % 8 == 0 and alpha == 1.0 and Z is None):
+        raise _lib.ConformerHipError("a 16-bit dY needs the matching precision mode, N % 8 == 0, K % 8 == 0, alpha = 1, no Z")
     if dy2d.stride(0) & 3:                        # e.g. the vocabulary projection (N = 370): rows must start 16-byte aligned
         padded = torch.zeros(m, (n + 3) // 4 * 4, device=dy2d.device, dtype=dy2d.dtype)
         padded[:, :n] = dy2d
         dy2d = padded[:, :n]
-    if need_dx:
+    if need_dx and dy16:
+        # dX = dY.W with a 16-bit dY: the forward kernel (row-major 16-bit A operand) on the cached transposed 16-bit weight
+        wt16 = weight16(w2, prec, transposed=True)
+        dx = torch.empty(m, k, device=dy2d.device, dtype=torch.float32)
+        _lib.check(_lib.load().cfm_gemm_mfma16_f32(prec, 0, dy2d.data_ptr(), 1, wt16.data_ptr(), 1, _zero_bias(k, dy2d.device).data_ptr(),
+                                                   None, 1.0, dx.data_ptr(), 0, None, m, k, n, dy2d.stride(0), k, k, 0.0, 0, _stream()),
+                   "cfm_gemm_mfma16_f32")
+    elif need_dx:
         w16 = weight16(w2, prec) if prec else None              # the cast the forward made (same parameter version)
+        c16 = bool(dx16 and prec and Z is not None and k % 8 == 0)
         dx = gemm_bwd(dy2d, False, w2 if w16 is None else w16, True, m, k, n, alpha=alpha, Z=Z, drop_p=drop_p,
-                      drop_seed=drop_seed, prec=prec, b16=w16 is not None)
+                      drop_seed=drop_seed, prec=prec, b16=w16 is not None, c16=c16)
     dw, db = _zeros_split(dy2d.device, torch.float32, (n, k), (n,))
-    x16, dy16 = x2d.dtype != torch.float32, dy2d.dtype != torch.float32   # stored in the 16-bit type by their producers
-    if (prec and n % 8 == 0 and k % 8 == 0 and x2d.stride(1) == 1 and dy2d.stride(1) == 1
+    x16 = x2d.dtype != torch.float32                  # stored in the 16-bit type by its producer (for_gemm)
+    if (prec and (x16 or dy16) and n % 8 == 0 and k % 8 == 0 and x2d.stride(1) == 1 and dy2d.stride(1) == 1
             and x2d.stride(0) % (8 if x16 else 4) == 0 and dy2d.stride(0) % (8 if dy16 else 4) == 0
             and x2d.data_ptr() % 16 == 0 and dy2d.data_ptr() % 16 == 0):
         # weight and bias gradient in one kernel (gemm_dw16_impl.h): dY is read once

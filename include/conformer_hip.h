@@ -147,12 +147,14 @@ int cfm_subsample_conv2_relu_mfma16_f32(int prec, const void* h1, int h1_is_16bi
 int cfm_subsample_conv1_relu_out16_f32(int prec, const float* x, const float* w1, const float* b1, void* h1, int B, int F,
                                        int T, int C, cfm_stream_t stream);
 int cfm_gemm_bwd_batched_mfma16_f32(int prec, const float* A, int a_col, int64_t lda, const void* B, int b_col,
-                                    int b_is_16bit, int64_t ldb, const float* Z_or_null, int64_t ldz, float alpha, float* C,
-                                    int64_t ldc, int I, int J, int64_t Kc, int allow_split, int accumulate,
+                                    int b_is_16bit, int64_t ldb, const float* Z_or_null, int64_t ldz, float alpha, void* C,
+                                    int64_t ldc, int c_is_16bit, int I, int J, int64_t Kc, int allow_split, int accumulate,
                                     int nbatch, int nb1, int64_t sa0, int64_t sa1, int64_t sb0, int64_t sb1,
                                     int64_t sc0, int64_t sc1, float drop_p, uint64_t drop_seed,
                                     int operands_zero_padded4, cfm_stream_t stream);
-/*      operands_zero_padded4: ragged Kc (index-major operands) / I, J (contraction-major operands) are physically padded
+/*      c_is_16bit (swish'(Z) product only, J % 8 == 0): C is stored in `prec` (ldc in elements) -- a gradient whose only
+ *      consumers are GEMM operands.
+ *      operands_zero_padded4: ragged Kc (index-major operands) / I, J (contraction-major operands) are physically padded
  *      to a multiple of 4 elements with zeros, so partial 16-byte chunks may be loaded whole (the fast load path). */
 /* Weight (and bias) gradient of y = x.W^T + b on the 16-bit matrix pipe: dw (N,K) += alpha * dy^T.x,
  * db (N) += alpha * colsum(dy) (NULL: skipped); both accumulate with atomics (caller zero-fills).  dy (M,N), x (M,K)
@@ -286,6 +288,7 @@ int cfm_relpos_attention_bwd_mfma16_f32(int prec, const float* q, const float* k
 /* diagnostics: per-phase s_memrealtime stamps of one wave of the fused attention backward (see the .hip file) */
 int cfm_debug_attention_bwd_trace_f32(void* trace_or_null);
 int cfm_debug_attention_bwd_trace_mfma16(void* trace_or_null);
+int cfm_debug_dw16_trace(void* trace_or_null);            /* 2 x 64 stamps of cfm_linear_bwd_weight_mfma16_f32 */
 int cfm_debug_lstm_trace(void* trace_or_null);            /* T x 2 x 8 stamps of cfm_lstm_fwd_f32's steps */
 int cfm_debug_gemm_mfma16_force_tile(int tile);           /* tuning: 0 auto, 1 128x128 family, 2 256x128, 3 256x256 */
 int cfm_debug_gemm_mfma16_trace(void* trace_or_null);     /* per-K-tile stamps of two workgroups of cfm_gemm_mfma16_f32 */
