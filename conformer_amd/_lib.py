@@ -27,13 +27,13 @@ SIGNATURES = {
     "cfm_gemm_bias_relu_f32": (c_int, [_P, _P, _P, _P, _L, _I, _I, _L, _L, _P]),
     "cfm_gemm_bias_glu_f32": (c_int, [_P, _P, _P, _P, _L, _I, _I, _L, _L, _P]),
     "cfm_gemm_bias_residual_f32": (c_int, [_P, _P, _P, _P, _F, _P, _L, _I, _I, _L, _L, _L, _P]),
-    "cfm_gemm_mfma16_f32": (c_int, [_I, _I, _P, _I, _P, _I, _P, _P, _F, _P, _I, _P, _L, _I, _I, _L, _L, _L, _F, _U, _P]),
+    "cfm_gemm_mfma16_f32": (c_int, [_I, _I, _P, _I, _P, _I, _P, _P, _F, _P, _I, _P, _I, _L, _I, _I, _L, _L, _L, _F, _U, _P]),
     "cfm_layernorm_fwd_out16_f32": (c_int, [_I, _P, _P, _P, _P, _P, _P, _L, _I, _F, _P]),
     "cfm_cast16_f32": (c_int, [_I, _P, _P, _L, _P]),
     "cfm_relpos_attention_mfma16_f32": (c_int, [_I, _P, _P, _P, _L, _P, _L, _P, _P, _P, _P, _L, _P, _I, _I, _I, _I, _F, _U, _P]),
     "cfm_subsample_conv2_relu_mfma16_f32": (c_int, [_I, _P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P]),
     "cfm_subsample_conv1_relu_out16_f32": (c_int, [_I, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
-    "cfm_gemm_bwd_batched_mfma16_f32": (c_int, [_I, _P, _I, _L, _P, _I, _I, _L, _P, _L, _F, _P, _L, _I, _I, _I, _L, _I, _I, _I, _I,
+    "cfm_gemm_bwd_batched_mfma16_f32": (c_int, [_I, _P, _I, _L, _P, _I, _I, _L, _P, _I, _L, _F, _P, _L, _I, _I, _I, _L, _I, _I, _I, _I,
                                                 _L, _L, _L, _L, _L, _L, _F, _U, _I, _P]),
     "cfm_subsample_conv2_bwd_weight_mfma16_f32": (c_int, [_I, _P, _P, _P, _I, _I, _I, _I, _P]),
     "cfm_subsample_conv2_bwd_input_mfma16_f32": (c_int, [_I, _P, _P, _P, _I, _I, _I, _I, _P]),

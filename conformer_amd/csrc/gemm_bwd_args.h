@@ -13,6 +13,7 @@ struct BwdArgs {
     float drop_p; unsigned long long drop_seed;   // DSWISH: the forward dropped swish(Z): re-apply its mask to the incoming gradient
     int accumulate;                      // C += ... (non-atomic read-modify-write; not combined with splits)
     int b16;                             // 16-bit kernels: operand B is already stored in the 16-bit type (ldb/sb* in elements)
+    int z16;                             // 16-bit kernels: Z is stored in the 16-bit type (1 bf16 | 2 fp16; ldz in elements)
     int c16;                             // 16-bit kernels, DSWISH only: C is stored in the 16-bit type (1 bf16 | 2 fp16; ldc in elements)
     int pad4;                            // 16-bit kernels: ragged Kc / I / J are physically padded to a multiple of 4 with zeros
     int nbatch, nb1;                     // batched: blockIdx.z = b0*nb1 + b1; operand offset = b0*s?0 + b1*s?1
@@ -90,7 +91,7 @@ __device__ __forceinline__ void bwd_epilogue_rows(const BwdArgs& g, float* Cb, f
 // ldz % 4 == 0) and 16-byte aligned bases -- bwd_rows_lds_ok(); otherwise the caller uses bwd_epilogue_rows.
 __device__ __forceinline__ bool bwd_rows_lds_ok(const BwdArgs& g, const float* Cb, int epi) {
     return (g.J & 3) == 0 && (g.ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(Cb) & 15) == 0 &&
-           (epi != BEPI_DSWISH || ((g.ldz & 3) == 0 && (reinterpret_cast<uintptr_t>(g.Z) & 15) == 0));
+           (epi != BEPI_DSWISH || ((g.ldz & 3) == 0 && (reinterpret_cast<uintptr_t>(g.Z) & (g.z16 ? 7 : 15)) == 0));
 }
 
 template <int BM, int BN, int EPI, int GATHER, int TM, int TN>
@@ -119,7 +120,16 @@ __device__ __forceinline__ void bwd_epilogue_rows_lds(const BwdArgs& g, float* C
             if (row >= g.I || col >= g.J) continue;
             v = v * g.alpha;
             if (EPI == BEPI_DSWISH) {
-                const f32x4 z4 = *reinterpret_cast<const f32x4*>(g.Z + (int64_t)row * g.ldz + col);
+                f32x4 z4;
+                if (g.z16 == 0) {
+                    z4 = *reinterpret_cast<const f32x4*>(g.Z + (int64_t)row * g.ldz + col);
+                } else {
+                    typedef __bf16 bf4 __attribute__((ext_vector_type(4)));
+                    typedef _Float16 hf4 __attribute__((ext_vector_type(4)));
+                    const void* zp = reinterpret_cast<const char*>(g.Z) + ((int64_t)row * g.ldz + col) * 2;
+                    if (g.z16 == 1) { const bf4 t = *reinterpret_cast<const bf4*>(zp); z4 = f32x4{(float)t[0], (float)t[1], (float)t[2], (float)t[3]}; }
+                    else { const hf4 t = *reinterpret_cast<const hf4*>(zp); z4 = f32x4{(float)t[0], (float)t[1], (float)t[2], (float)t[3]}; }
+                }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float sg = sigmoidf_acc(z4[e]);

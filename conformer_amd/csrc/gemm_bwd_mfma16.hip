@@ -30,7 +30,7 @@ int cfm_dw16_f16(const void* dy, int dy16, int64_t ldy, const void* x, int x16, 
 
 // Argument rules of cfm_gemm_bwd_batched_f32; prec = CFM_PREC_BF16 | CFM_PREC_FP16.
 extern "C" int cfm_gemm_bwd_batched_mfma16_f32(int prec, const float* A, int a_col, int64_t lda, const void* B, int b_col,
-                                               int b_is_16bit, int64_t ldb, const float* Z_or_null, int64_t ldz, float alpha, void* C,
+                                               int b_is_16bit, int64_t ldb, const void* Z_or_null, int z_is_16bit, int64_t ldz, float alpha, void* C,
                                                int64_t ldc, int c_is_16bit, int I, int J, int64_t Kc, int allow_split, int accumulate,
                                                int nbatch, int nb1, int64_t sa0, int64_t sa1, int64_t sb0, int64_t sb1,
                                                int64_t sc0, int64_t sc1, float drop_p, uint64_t drop_seed,
@@ -43,13 +43,16 @@ extern "C" int cfm_gemm_bwd_batched_mfma16_f32(int prec, const float* A, int a_c
     CFM_REQUIRE(CFM_ALIGNED16(A) && CFM_ALIGNED16(B) && CFM_ALIGNED16(C), CFM_ERR_ALIGN);
     CFM_REQUIRE(!Z_or_null || (CFM_ALIGNED16(Z_or_null) && (ldz & 3) == 0), CFM_ERR_ALIGN);
     CFM_REQUIRE(!Z_or_null || (!a_col && b_col && nbatch == 1), CFM_ERR_UNSUPPORTED);
+    // a 16-bit Z is read by the row-major (vectorised) epilogue only
+    CFM_REQUIRE(!z_is_16bit || (Z_or_null && (J & 7) == 0 && (ldz & 7) == 0 && (ldc & 3) == 0), CFM_ERR_UNSUPPORTED);
     // a 16-bit C: only the swish'(Z) product (its result feeds GEMM operands), whole 16-byte chunks, plain stores
     CFM_REQUIRE(!c_is_16bit || (Z_or_null && !accumulate && (J & 7) == 0 && (ldc & 7) == 0), CFM_ERR_UNSUPPORTED);
     BwdArgs g{};
     g.b16 = b_is_16bit != 0;
     g.pad4 = operands_zero_padded4 != 0;
     g.c16 = c_is_16bit ? prec : 0;
-    g.A = A; g.B = static_cast<const float*>(B); g.Z = Z_or_null; g.C = static_cast<float*>(C); g.I = I; g.J = J; g.Kc = Kc;
+    g.z16 = z_is_16bit ? prec : 0;
+    g.A = A; g.B = static_cast<const float*>(B); g.Z = static_cast<const float*>(Z_or_null); g.C = static_cast<float*>(C); g.I = I; g.J = J; g.Kc = Kc;
     g.lda = lda; g.ldb = ldb; g.ldz = ldz; g.ldc = ldc; g.alpha = alpha;
     g.splits = (allow_split && !accumulate) ? 0 : 1;
     g.accumulate = accumulate; g.nbatch = nbatch; g.nb1 = nb1; g.drop_p = drop_p; g.drop_seed = drop_seed;

@@ -304,9 +304,12 @@ extern "C" int cfm_debug_gemm_mfma16_force_tile(int tile) {
 // Z_or_null / drop_p / drop_seed); results differ from them by the 16-bit rounding of A and W only.
 extern "C" int cfm_gemm_mfma16_f32(int prec, int epi, const void* A, int a_is_16bit, const void* W, int w_is_16bit,
                                    const float* bias, const float* R_or_null, float alpha, void* C, int c_is_16bit,
-                                   float* Z_or_null, int64_t M, int N, int K, int64_t lda, int64_t ldr, int64_t ldc,
-                                   float drop_p, uint64_t drop_seed, cfm_stream_t stream) {
+                                   void* Z_or_null, int z_is_16bit, int64_t M, int N, int K, int64_t lda, int64_t ldr,
+                                   int64_t ldc, float drop_p, uint64_t drop_seed, cfm_stream_t stream) {
     CFM_REQUIRE(A && W && bias && C, CFM_ERR_NULL);
+    // a 16-bit Z takes the vectorised epilogue only: whole 8-byte groups of four columns
+    CFM_REQUIRE(!z_is_16bit || (Z_or_null && epi == 1 && (N & 7) == 0 && (ldc & 7) == 0 && CFM_ALIGNED16(C) && CFM_ALIGNED16(Z_or_null)),
+                CFM_ERR_UNSUPPORTED);
     CFM_REQUIRE(!w_is_16bit || (K & 7) == 0, CFM_ERR_BAD_SHAPE);
     CFM_REQUIRE(!a_is_16bit || (w_is_16bit && (lda & 7) == 0), CFM_ERR_BAD_SHAPE);
     const int src16 = a_is_16bit ? 2 : (w_is_16bit ? 1 : 0);
@@ -316,7 +319,7 @@ extern "C" int cfm_gemm_mfma16_f32(int prec, int epi, const void* A, int a_is_16
     GemmArgs g{};
     g.A = static_cast<const float*>(A); g.W = static_cast<const float*>(W); g.bias = bias; g.R = R_or_null;
     g.C = static_cast<float*>(C); g.c_prec = c_is_16bit ? prec : 0; g.M = M; g.K = K; g.lda = lda;
-    g.ldr = ldr; g.ldc = ldc; g.alpha = alpha; g.Zsave = Z_or_null; g.drop_p = drop_p; g.drop_seed = drop_seed;
+    g.ldr = ldr; g.ldc = ldc; g.alpha = alpha; g.Zsave = static_cast<float*>(Z_or_null); g.z_prec = z_is_16bit ? prec : 0; g.drop_p = drop_p; g.drop_seed = drop_seed;
     g.trace = g_gemm16_trace;
     g.occ_cap = g_gemm16_force_tile;
     hipStream_t s = static_cast<hipStream_t>(stream);

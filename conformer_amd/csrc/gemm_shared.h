@@ -10,6 +10,7 @@ enum Epi { EPI_BIAS = 0, EPI_SWISH = 1, EPI_RELU = 2, EPI_GLU = 3, EPI_RESID = 4
 struct GemmArgs {
     const float* A; const float* W; const float* bias; const float* R; float* C;
     float* Zsave;                   // swish epilogue, training: also store the pre-activation (same ldc), or NULL
+    int z_prec;                     // 0: Zsave is fp32; CFM_PREC_BF16 / CFM_PREC_FP16: stored in that type (vectorised path only)
     float drop_p; unsigned long long drop_seed;   // training: dropout on the GEMM result (after Swish; before alpha*y+R)
     int64_t M; int N; int K; int64_t lda, ldr, ldc; float alpha;
     int n_out;                      // GLU: output columns (N = 2*n_out)
@@ -97,8 +98,15 @@ __device__ __forceinline__ void gemm_epilogue_at(const GemmArgs& g, const f32x4 
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = g.alpha * v[e] + rr[e];
         }
-        if (EPI == EPI_SWISH && g.Zsave)
-            *reinterpret_cast<f32x4*>(g.Zsave + row * g.ldc + col) = f32x4{v[0], v[1], v[2], v[3]};
+        if (EPI == EPI_SWISH && g.Zsave) {
+            if (g.z_prec == 0) *reinterpret_cast<f32x4*>(g.Zsave + row * g.ldc + col) = f32x4{v[0], v[1], v[2], v[3]};
+            else if (g.z_prec == CFM_PREC_BF16)
+                *reinterpret_cast<Lowp<__bf16>::x4*>(reinterpret_cast<__bf16*>(g.Zsave) + row * g.ldc + col) =
+                    Lowp<__bf16>::cvt4(f32x4{v[0], v[1], v[2], v[3]});
+            else
+                *reinterpret_cast<Lowp<_Float16>::x4*>(reinterpret_cast<_Float16*>(g.Zsave) + row * g.ldc + col) =
+                    Lowp<_Float16>::cvt4(f32x4{v[0], v[1], v[2], v[3]});
+        }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             if (EPI == EPI_SWISH) {

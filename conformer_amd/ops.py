@@ -199,8 +199,8 @@ def _mfma16_gemm(prec: int, epi: int, a, w2, b, c, m, n, k, res=None, alpha: flo
         raise _lib.ConformerHipError(f"16-bit A operand ({a.dtype}) does not match the precision mode / weight shape")
     st = _lib.load().cfm_gemm_mfma16_f32(prec, epi, a.data_ptr(), int(a16), (w2 if w16 is None else w16).data_ptr(),
                                          int(w16 is not None), b.data_ptr(), _p(res), alpha, c.data_ptr(),
-                                         int(c.dtype != torch.float32), _p(z), m, n, k, k, n, n, float(drop_p), int(seed),
-                                         _stream())
+                                         int(c.dtype != torch.float32), _p(z), int(z is not None and z.dtype != torch.float32),
+                                         m, n, k, k, n, n, float(drop_p), int(seed), _stream())
     _lib.check(st, "cfm_gemm_mfma16_f32")
     return c
 
@@ -562,7 +562,8 @@ def linear_train(epi: str, a, w, b, *, residual=None, alpha: float = 1.0, drop_p
     a, w2, b, m, n, k = _gemm_common(a, w, b)
     p16 = out16_ok(n) if for_gemm else 0
     c = torch.empty(*a.shape[:-1], n, device=a.device, dtype=_DT16[p16] if p16 else torch.float32)
-    z = torch.empty(*a.shape[:-1], n, device=a.device, dtype=torch.float32) if save_z else None
+    # (the saved pre-activation is kept in the 16-bit type together with the activation: what autocast keeps for silu's backward)
+    z = torch.empty(*a.shape[:-1], n, device=a.device, dtype=_DT16[p16] if p16 and epi == "swish" else torch.float32) if save_z else None
     code = {"bias": 0, "swish": 1, "residual": 4}[epi]
     if residual is not None:
         residual = _req(residual, "residual")
@@ -636,15 +637,16 @@ def gemm_bwd(A, a_col: bool, B, b_col: bool, I: int, J: int, Kc: int, *, alpha: 
     ldc = out.stride(-2) if ldc is None else ldc
     ldz = 0 if Z is None else (Z.stride(-2) if ldz is None else ldz)
     head = (A.data_ptr() if a_ptr is None else a_ptr, int(a_col), lda, B.data_ptr() if b_ptr is None else b_ptr, int(b_col))
-    tail = (ldb, _p(Z), ldz, alpha, out.data_ptr() if c_ptr is None else c_ptr, ldc, int(c16), I, J, Kc, int(allow_split),
+    z16 = Z is not None and Z.dtype != torch.float32
+    tail = (ldb, _p(Z), int(z16), ldz, alpha, out.data_ptr() if c_ptr is None else c_ptr, ldc, int(c16), I, J, Kc, int(allow_split),
             int(accumulate), nbatch, nb1, sa[0], sa[1], sb[0], sb[1], sc[0], sc[1], float(drop_p), int(drop_seed))
     if prec:
         _lib.check(_lib.load().cfm_gemm_bwd_batched_mfma16_f32(prec, *head, int(b16), *tail, int(pad4), _stream()),
                    "cfm_gemm_bwd_batched_mfma16_f32")
     else:
-        if b16 or c16:
+        if b16 or c16 or z16:
             raise _lib.ConformerHipError("16-bit operands / results need a 16-bit precision mode")
-        _lib.check(_lib.load().cfm_gemm_bwd_batched_f32(*head, *tail[:6], *tail[7:], _stream()), "cfm_gemm_bwd_batched_f32")
+        _lib.check(_lib.load().cfm_gemm_bwd_batched_f32(*head, *tail[:2], *tail[3:7], *tail[8:], _stream()), "cfm_gemm_bwd_batched_f32")
     return out
 
 
@@ -672,7 +674,7 @@ def linear_bwd(x2d, w, dy2d, *, alpha: float = 1.0, Z=None, need_dx: bool = True
         wt16 = weight16(w2, prec, transposed=True)
         dx = torch.empty(m, k, device=dy2d.device, dtype=torch.float32)
         _lib.check(_lib.load().cfm_gemm_mfma16_f32(prec, 0, dy2d.data_ptr(), 1, wt16.data_ptr(), 1, _zero_bias(k, dy2d.device).data_ptr(),
-                                                   None, 1.0, dx.data_ptr(), 0, None, m, k, n, dy2d.stride(0), k, k, 0.0, 0, _stream()),
+                                                   None, 1.0, dx.data_ptr(), 0, None, 0, m, k, n, dy2d.stride(0), k, k, 0.0, 0, _stream()),
                    "cfm_gemm_mfma16_f32")
     elif need_dx:
         w16 = weight16(w2, prec) if prec else None              # the cast the forward made (same parameter version)

@@ -127,12 +127,14 @@ int cfm_pack_linear_weight_f32(const float* wl, float* wlp, int d_out, int C, in
 #define CFM_PREC_FP16 2
 int cfm_gemm_mfma16_f32(int prec, int epi, const void* A, int a_is_16bit, const void* W, int w_is_16bit,
                         const float* bias, const float* R_or_null, float alpha, void* C, int c_is_16bit,
-                        float* Z_or_null, int64_t M, int N, int K, int64_t lda, int64_t ldr, int64_t ldc,
-                        float drop_p, uint64_t drop_seed, cfm_stream_t stream);
+                        void* Z_or_null, int z_is_16bit, int64_t M, int N, int K, int64_t lda, int64_t ldr,
+                        int64_t ldc, float drop_p, uint64_t drop_seed, cfm_stream_t stream);
 /*      w_is_16bit / b_is_16bit: that operand is already stored in `prec` (cfm_cast16_f32 of the fp32 master weights, once
  *      per optimizer step): half the bytes of the operand every row tile re-reads; results are bit-identical. K % 8 == 0.
  *      a_is_16bit (needs w_is_16bit; lda % 8 == 0, in elements): A is a 16-bit tensor written by its producer
- *      (cfm_layernorm_fwd_out16_f32, or a GEMM with c_is_16bit).  c_is_16bit: C is stored in `prec` (ldc in elements). */
+ *      (cfm_layernorm_fwd_out16_f32, or a GEMM with c_is_16bit).  c_is_16bit: C is stored in `prec` (ldc in elements).
+ *      z_is_16bit (epi 1, N % 8 == 0): the saved pre-activation Z is stored in `prec` too (what autocast keeps for the
+ *      backward of silu: reference model/utils/activation.py). */
 int cfm_layernorm_fwd_out16_f32(int prec, const float* x, const float* gamma, const float* beta, void* y16,
                                 float* mean_or_null, float* rstd_or_null, int64_t rows, int d, float eps,
                                 cfm_stream_t stream);
@@ -147,7 +149,7 @@ int cfm_subsample_conv2_relu_mfma16_f32(int prec, const void* h1, int h1_is_16bi
 int cfm_subsample_conv1_relu_out16_f32(int prec, const float* x, const float* w1, const float* b1, void* h1, int B, int F,
                                        int T, int C, cfm_stream_t stream);
 int cfm_gemm_bwd_batched_mfma16_f32(int prec, const float* A, int a_col, int64_t lda, const void* B, int b_col,
-                                    int b_is_16bit, int64_t ldb, const float* Z_or_null, int64_t ldz, float alpha, void* C,
+                                    int b_is_16bit, int64_t ldb, const void* Z_or_null, int z_is_16bit, int64_t ldz, float alpha, void* C,
                                     int64_t ldc, int c_is_16bit, int I, int J, int64_t Kc, int allow_split, int accumulate,
                                     int nbatch, int nb1, int64_t sa0, int64_t sa1, int64_t sb0, int64_t sb1,
                                     int64_t sc0, int64_t sc1, float drop_p, uint64_t drop_seed,
