@@ -306,9 +306,9 @@ extern "C" int cfm_gemm_mfma16_f32(int prec, int epi, const void* A, int a_is_16
                                    const float* bias, const float* R_or_null, float alpha, void* C, int c_is_16bit,
                                    void* Z_or_null, int z_is_16bit, int64_t M, int N, int K, int64_t lda, int64_t ldr,
                                    int64_t ldc, float drop_p, uint64_t drop_seed, cfm_stream_t stream) {
-    CFM_REQUIRE(A && W && bias && C, CFM_ERR_NULL);
+    CFM_REQUIRE(A && W && C && (bias || epi == EPI_DSWISH), CFM_ERR_NULL);
     // a 16-bit Z takes the vectorised epilogue only: whole 8-byte groups of four columns
-    CFM_REQUIRE(!z_is_16bit || (Z_or_null && epi == 1 && (N & 7) == 0 && (ldc & 7) == 0 && CFM_ALIGNED16(C) && CFM_ALIGNED16(Z_or_null)),
+    CFM_REQUIRE(!z_is_16bit || (Z_or_null && (epi == EPI_SWISH || epi == EPI_DSWISH) && (N & 7) == 0 && (ldc & 7) == 0 && CFM_ALIGNED16(C) && CFM_ALIGNED16(Z_or_null)),
                 CFM_ERR_UNSUPPORTED);
     CFM_REQUIRE(!w_is_16bit || (K & 7) == 0, CFM_ERR_BAD_SHAPE);
     CFM_REQUIRE(!a_is_16bit || (w_is_16bit && (lda & 7) == 0), CFM_ERR_BAD_SHAPE);
@@ -336,6 +336,11 @@ extern "C" int cfm_gemm_mfma16_f32(int prec, int epi, const void* A, int a_is_16
             CFM_REQUIRE(R_or_null != nullptr, CFM_ERR_NULL);
             CFM_REQUIRE(ldr >= N, CFM_ERR_BAD_SHAPE);
             return launch<EPI_RESID, false>(prec, g, src16, s);
+        case EPI_DSWISH:                                        // backward: C = alpha * (A.W^T) * swish'(Z); Z is READ, ldr = its leading dim
+            CFM_REQUIRE(Z_or_null != nullptr, CFM_ERR_NULL);
+            CFM_REQUIRE((N & 7) == 0 && (ldc & 7) == 0 && (ldr & 7) == 0 && ldr >= N && CFM_ALIGNED16(C) && CFM_ALIGNED16(Z_or_null),
+                        CFM_ERR_UNSUPPORTED);
+            return launch<EPI_DSWISH, false>(prec, g, src16, s);
         default: return CFM_ERR_UNSUPPORTED;
     }
 }

@@ -5,7 +5,9 @@
 
 namespace {
 
-enum Epi { EPI_BIAS = 0, EPI_SWISH = 1, EPI_RELU = 2, EPI_GLU = 3, EPI_RESID = 4 };
+enum Epi { EPI_BIAS = 0, EPI_SWISH = 1, EPI_RELU = 2, EPI_GLU = 3, EPI_RESID = 4, EPI_DSWISH = 5 };
+// EPI_DSWISH (16-bit kernels, backward): C = alpha * acc * swish'(Z) [* the forward's dropout mask]; Z = g.Zsave (READ, leading
+// dimension g.ldr, type g.z_prec), no bias.  Vectorised epilogue only (the entry point checks the alignment conditions).
 
 struct GemmArgs {
     const float* A; const float* W; const float* bias; const float* R; float* C;
@@ -76,6 +78,33 @@ __device__ __forceinline__ void gemm_epilogue_at(const GemmArgs& g, const f32x4 
                                                  bool vec_ok) {
     const int ncols = EPI == EPI_GLU ? g.n_out : g.N;
     if (row >= g.M || col >= ncols) return;
+    if constexpr (EPI == EPI_DSWISH) {
+        if (!vec_ok) return;                                           // (excluded by the entry point)
+        f32x4 z4;
+        if (g.z_prec == 0) z4 = *reinterpret_cast<const f32x4*>(g.Zsave + row * g.ldr + col);
+        else if (g.z_prec == CFM_PREC_BF16) {
+            const Lowp<__bf16>::x4 t = *reinterpret_cast<const Lowp<__bf16>::x4*>(reinterpret_cast<const __bf16*>(g.Zsave) + row * g.ldr + col);
+            z4 = f32x4{(float)t[0], (float)t[1], (float)t[2], (float)t[3]};
+        } else {
+            const Lowp<_Float16>::x4 t = *reinterpret_cast<const Lowp<_Float16>::x4*>(reinterpret_cast<const _Float16*>(g.Zsave) + row * g.ldr + col);
+            z4 = f32x4{(float)t[0], (float)t[1], (float)t[2], (float)t[3]};
+        }
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float sg = sigmoidf_acc(z4[e]);
+            o[e] = g.alpha * av[e] * (sg * (1.0f + z4[e] * (1.0f - sg)));
+            if (g.drop_p > 0.f)
+                o[e] *= dropout_keep(g.drop_seed, (unsigned long long)row * (unsigned long long)g.N + (unsigned)(col + e), g.drop_p,
+                                     1.0f / (1.0f - g.drop_p));
+        }
+        if (g.c_prec == 0) *reinterpret_cast<f32x4*>(g.C + row * g.ldc + col) = o;
+        else if (g.c_prec == CFM_PREC_BF16)
+            *reinterpret_cast<Lowp<__bf16>::x4*>(reinterpret_cast<__bf16*>(g.C) + row * g.ldc + col) = Lowp<__bf16>::cvt4(o);
+        else
+            *reinterpret_cast<Lowp<_Float16>::x4*>(reinterpret_cast<_Float16*>(g.C) + row * g.ldc + col) = Lowp<_Float16>::cvt4(o);
+        return;
+    }
     float v[4];
     if (vec_ok) {                                                  // col + 3 < ncols because ncols % 4 == 0
         const f32x4 bb = *reinterpret_cast<const f32x4*>(g.bias + col);

@@ -676,6 +676,14 @@ def linear_bwd(x2d, w, dy2d, *, alpha: float = 1.0, Z=None, need_dx: bool = True
         _lib.check(_lib.load().cfm_gemm_mfma16_f32(prec, 0, dy2d.data_ptr(), 1, wt16.data_ptr(), 1, _zero_bias(k, dy2d.device).data_ptr(),
                                                    None, 1.0, dx.data_ptr(), 0, None, 0, m, k, n, dy2d.stride(0), k, k, 0.0, 0, _stream()),
                    "cfm_gemm_mfma16_f32")
+    elif need_dx and prec and Z is not None and n % 8 == 0 and k % 8 == 0 and Z.stride(0) % 8 == 0:
+        # d(pre-activation) = alpha * (dY.W) * swish'(Z) [* dropout mask]: forward kernel (big tiles, deep prefetch) on the
+        # cached transposed 16-bit weight, swish' fused in its row-major epilogue
+        wt16 = weight16(w2, prec, transposed=True)
+        dx = torch.empty(m, k, device=dy2d.device, dtype=_DT16[prec] if dx16 else torch.float32)
+        _lib.check(_lib.load().cfm_gemm_mfma16_f32(prec, 5, dy2d.data_ptr(), 0, wt16.data_ptr(), 1, None, None, alpha, dx.data_ptr(),
+                                                   int(dx16), Z.data_ptr(), int(Z.dtype != torch.float32), m, k, n, dy2d.stride(0),
+                                                   Z.stride(0), k, float(drop_p), int(drop_seed), _stream()), "cfm_gemm_mfma16_f32")
     elif need_dx:
         w16 = weight16(w2, prec) if prec else None              # the cast the forward made (same parameter version)
         c16 = bool(dx16 and prec and Z is not None and k % 8 == 0)

@@ -118,7 +118,8 @@ int cfm_pack_linear_weight_f32(const float* wl, float* wlp, int d_out, int C, in
 /* ---- 16-bit-MFMA GEMMs with fp32 storage: the arithmetic torch.autocast gives nn.Linear / Conv (train.py:6,232 runs the
  *      model under torch.cuda.amp.autocast = fp16; bf16 is the MI355X-preferred variant).  Operands
  *      are rounded to `prec` on their way into LDS, accumulation and epilogues are fp32, tensors in HBM stay fp32.
- *      epi: 0 bias | 1 +swish | 2 +relu | 3 +GLU | 4 alpha*y+R; argument rules as the fp32 entry points
+ *      epi: 0 bias | 1 +swish | 2 +relu | 3 +GLU | 4 alpha*y+R | 5 backward of swish: C = alpha * (A.W^T) * swish'(Z)
+ *      (Z_or_null is READ, ldr is its leading dimension, bias may be NULL, N % 8 == 0); argument rules as the fp32 entry points
  *      (cfm_gemm_train_f32 for Z_or_null / drop_p / drop_seed; for GLU, N = n_out and W has 2*n_out rows).
  *      The *_bwd_* entries mirror cfm_gemm_bwd_batched_f32 / cfm_subsample_conv2_bwd_{weight,input}_f32 (the stem
  *      forms need C % 64 == 0). */
