@@ -152,56 +152,63 @@ __global__ __launch_bounds__(256, 2) void relpos_attn_fwd_kernel(const AttnArgs 
 
     const bool tracer = a.trace && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0;
 #define ATT_STAMP(i) do { if (tracer) a.trace[16 * kt + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+    // ---- positional band G^T[jj][query], jj = 32*mt + row <-> table row j = jbase - jj (jbase = T-1-i0+k0+31), and the
+    // "relative shift": lane (query li) needs G^T[li - kk + 31][li] for its 16 keys kk -- a per-lane column skew through the
+    // per-wave LDS tile (each lane only touches its own bank).  The 64-row band of a key tile is two 32-row MFMA tiles, and
+    // band tile 1 of key tile kt+1 covers exactly the table rows of band tile 0 of key tile kt (jbase moves by 32): only band
+    // tile 0 is computed per key tile.  Better: the skew reads address row (jj & 31) of the tile for ALL 16 keys and a
+    // select picks the band tile that owns key kk (jj >> 5) -- a per-key `if` compiles to 16 serialized branch + ds_read +
+    // wait sequences, measured 3 us per band -- so the 16 values read from band tile 0 of key tile kt already ARE the 16
+    // values key tile kt+1 needs from its band tile 1.  They are carried in registers (skp): per key tile one band product
+    // (4*NC MFMAs instead of 8*NC), one spill and 16 skew reads instead of two of each.
+    auto band = [&](int jbase, int mt) {
+        const int slot = (jbase - (32 * mt + li) + ring_bias) % RING;
+        const float* prow = Pr + slot * KROW + 4 * hf;
+        f32x16 ga;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ga[r] = 0.f;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const f32x4 pf = *reinterpret_cast<const f32x4*>(prow + 8 * c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ga = __builtin_amdgcn_mfma_f32_32x32x2f32(pf[e], qv[4 * c + e], ga, 0, 0, 0);
+        }
+        return ga;
+    };
+    auto spill_band = [&](const f32x16& ga) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) gs[((r & 3) + 8 * (r >> 2) + 4 * hf) * 32 + li] = ga[r];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    auto skew_reads = [&](float (&dst)[16]) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int jj = li - ((r & 3) + 8 * (r >> 2) + 4 * hf) + 31;     // 0..62
+            dst[r] = gs[(jj & 31) * 32 + li];
+        }
+    };
+    float skp[16];                                                   // band tile 1 of the current key tile, skewed (carried)
+    if (active) {                                                    // first key tile: its band tile 1 is computed explicitly
+        const f32x16 g1 = band(T - 1 - i0 + 32 * kt_begin + 31, 1);
+        spill_band(g1);
+        skew_reads(skp);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // the reads have landed before the tile is rewritten
+        __builtin_amdgcn_wave_barrier();
+    }
     for (int kt = kt_begin; kt < ntiles; ++kt) {
         const int k0 = kt * 32;
         ATT_STAMP(0);
         if (active) {
-            // ---- positional band G^T[jj][query], jj = 32*mt + row <-> table row j = jbase - jj, then the "relative shift":
-            // lane (query li) needs G^T[li - kk + 31][li] for its 16 keys kk -- a per-lane column skew through the per-wave
-            // LDS tile (each lane only touches its own bank).  Order: band 0 -> tile; band 1 MFMAs are issued while the skewed
-            // reads of band 0 return; band 1 -> tile; the content MFMAs are issued while the reads of band 1 return.  All 16
-            // skew reads of a band are unconditional and issued back to back (a per-key `if` compiles to 16 serialized
-            // branch + ds_read + wait sequences: measured 3 us per band), the band that owns key kk is picked by a select.
             const int jbase = T - 1 - i0 + k0 + 31;
-            auto band = [&](int mt) {
-                const int slot = (jbase - (32 * mt + li) + ring_bias) % RING;
-                const float* prow = Pr + slot * KROW + 4 * hf;
-                f32x16 ga;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) ga[r] = 0.f;
-#pragma unroll
-                for (int c = 0; c < NC; ++c) {
-                    const f32x4 pf = *reinterpret_cast<const f32x4*>(prow + 8 * c);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) ga = __builtin_amdgcn_mfma_f32_32x32x2f32(pf[e], qv[4 * c + e], ga, 0, 0, 0);
-                }
-                return ga;
-            };
-            auto spill_band = [&](const f32x16& ga) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) gs[((r & 3) + 8 * (r >> 2) + 4 * hf) * 32 + li] = ga[r];
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            };
-            float sk[16];                                            // skewed positional scores of this lane's 16 keys
             {
-                const f32x16 g0 = band(0);
+                const f32x16 g0 = band(jbase, 0);
                 ATT_STAMP(1);
                 spill_band(g0);
             }
-            const f32x16 g1 = band(1);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int jj = li - ((r & 3) + 8 * (r >> 2) + 4 * hf) + 31;     // 0..62
-                sk[r] = gs[(jj & 31) * 32 + li];
-            }
             ATT_STAMP(2);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // band-0 reads have landed before the tile is rewritten
-            __builtin_amdgcn_wave_barrier();
-            spill_band(g1);
-            ATT_STAMP(3);
-            // ---- content scores S^T[key][query]
+            // ---- content scores S^T[key][query] (issued while the skew reads return)
             f32x16 sc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) sc[r] = 0.f;
@@ -211,17 +218,18 @@ __global__ __launch_bounds__(256, 2) void relpos_attn_fwd_kernel(const AttnArgs 
 #pragma unroll
                 for (int e = 0; e < 4; ++e) sc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[e], qu[4 * c + e], sc, 0, 0, 0);
             }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int jj = li - ((r & 3) + 8 * (r >> 2) + 4 * hf) + 31;
-                const float g1v = gs[(jj & 31) * 32 + li];
-                sk[r] = (jj >> 5) ? g1v : sk[r];
-            }
+            ATT_STAMP(3);
+            float skn[16];
+            skew_reads(skn);
             ATT_STAMP(4);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();                        // the tile is rewritten by the next key tile
 #pragma unroll
-            for (int r = 0; r < 16; ++r) sc[r] += sk[r];
+            for (int r = 0; r < 16; ++r) {
+                const int jj = li - ((r & 3) + 8 * (r >> 2) + 4 * hf) + 31;
+                sc[r] += (jj >> 5) ? skp[r] : skn[r];
+                skp[r] = skn[r];
+            }
             ATT_STAMP(5);
             // ---- scale + mask, online softmax (query = lane column; keys = registers x 2 halves)
             float p[16];
