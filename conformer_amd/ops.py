@@ -848,7 +848,7 @@ def subsample_stem_bwd(x, w1, b1, w2, h1, h2, dh2):
 def lstm_forward(x, w_ih, w_hh, bias, lengths=None, save: bool = False):
     """nn.LSTM(batch_first) forward of one layer: x (B,T,D) -> y (B,T,H); bias = b_ih + b_hh (4H).  `lengths` (B) int64 on
     the device gives pack_padded_sequence semantics (outputs beyond an utterance's length are 0).  The input projection is
-    one GEMM (16-bit MFMA under autocast), the recurrence runs in fp32.  save=True also returns (gates, cells)."""
+    one GEMM; under autocast both it and the recurrent product run on the 16-bit matrix pipe.  save=True also returns (gates, cells)."""
     x = _req(x, "x"); w_hh = _req(w_hh, "weight_hh")
     B, T, _ = x.shape
     H = w_hh.shape[1]
@@ -859,6 +859,16 @@ def lstm_forward(x, w_ih, w_hh, bias, lengths=None, save: bool = False):
     cells = torch.empty(B, T, H, device=x.device, dtype=x.dtype) if save else None
     if lengths is not None:
         lengths = _req(lengths, "lengths", torch.int64)
+    prec = mfma16_prec()
+    w16 = weight16(w_hh, prec) if prec and H % 16 == 0 else None
+    if w16 is not None:
+        # under autocast the recurrent product runs on the 16-bit matrix pipe too (what autocast does to nn.LSTM on a GPU);
+        # gate math, cell state and all stored tensors stay fp32
+        h16 = torch.empty(2, B, H, device=x.device, dtype=_DT16[prec])
+        _lib.check(_lib.load().cfm_lstm_fwd_mfma16_f32(prec, gx.data_ptr(), w16.data_ptr(), _p(lengths), y.data_ptr(), c.data_ptr(),
+                                                       h16.data_ptr(), _p(gates), _p(cells), B, T, H, _stream()),
+                   "cfm_lstm_fwd_mfma16_f32")
+        return (y, gates, cells) if save else y
     _lib.check(_lib.load().cfm_lstm_fwd_f32(gx.data_ptr(), w_hh.data_ptr(), _p(lengths), y.data_ptr(), c.data_ptr(), _p(gates),
                                             _p(cells), B, T, H, _stream()), "cfm_lstm_fwd_f32")
     return (y, gates, cells) if save else y
@@ -882,15 +892,22 @@ def lstm_backward(x, w_ih, w_hh, y, gates, cells, dy, lengths=None, need_dx: boo
     B, T, D = x.shape
     H = w_hh.shape[1]
     dy = _req(dy, "dy")
-    whh_t = w_hh.t().contiguous()                                     # (H,4H): 6.5 MB of glue per step
     dG = torch.empty(B, T, 4 * H, device=x.device, dtype=x.dtype)
     dc = torch.empty(B, H, device=x.device, dtype=x.dtype)
-    _lib.check(lib.cfm_lstm_bwd_f32(dy.data_ptr(), gates.data_ptr(), cells.data_ptr(), whh_t.data_ptr(), _p(lengths),
-                                    dG.data_ptr(), dc.data_ptr(), B, T, H, _stream()), "cfm_lstm_bwd_f32")
+    prec = mfma16_prec()
+    whh_t16 = weight16(w_hh, prec, transposed=True) if prec and H % 16 == 0 else None
+    if whh_t16 is not None:
+        dg16 = torch.empty(2, B, 4 * H, device=x.device, dtype=_DT16[prec])
+        _lib.check(lib.cfm_lstm_bwd_mfma16_f32(prec, dy.data_ptr(), gates.data_ptr(), cells.data_ptr(), whh_t16.data_ptr(),
+                                               _p(lengths), dG.data_ptr(), dc.data_ptr(), dg16.data_ptr(), B, T, H, _stream()),
+                   "cfm_lstm_bwd_mfma16_f32")
+    else:
+        whh_t = w_hh.t().contiguous()                                 # (H,4H): 6.5 MB of glue per step
+        _lib.check(lib.cfm_lstm_bwd_f32(dy.data_ptr(), gates.data_ptr(), cells.data_ptr(), whh_t.data_ptr(), _p(lengths),
+                                        dG.data_ptr(), dc.data_ptr(), B, T, H, _stream()), "cfm_lstm_bwd_f32")
     dG2, x2 = dG.view(B * T, 4 * H), x.reshape(B * T, D)
     h_prev = torch.zeros_like(y)                                      # h_{t-1}: y shifted by one frame per utterance
     h_prev[:, 1:] = y[:, :-1]
-    prec = mfma16_prec()
     dx = gemm_bwd(dG2, False, w_ih, True, B * T, D, 4 * H, prec=prec).view(B, T, D) if need_dx else None
     dw_ih, dw_hh, db = _zeros_split(x.device, x.dtype, (4 * H, D), (4 * H, H), (4 * H,))
     gemm_bwd(dG2, True, x2, True, 4 * H, D, B * T, allow_split=True, out=dw_ih, prec=prec)

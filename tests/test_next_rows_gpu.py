@@ -146,6 +146,39 @@ def test_lstm_backward_vs_oracle_autograd(dev, B, T, D, H, ragged):
         assert rel_l2(a.grad, b.grad) < 2e-5, name
 
 
+@pytest.mark.parametrize("B,T,D,H,ragged", [(3, 25, 32, 16, True), (2, 49, 144, 320, True), (64, 30, 64, 640, True), (40, 12, 64, 48, True)])
+def test_lstm_bf16_recurrence_and_bptt_vs_oracle(dev, B, T, D, H, ragged):
+    """Under autocast the recurrent product runs on the 16-bit matrix pipe (lstm_mfma16.hip: 32-utterance x 8-unit workgroups,
+    16-bit W_hh and h exchange): forward and every gradient within the north_star's 1e-2 of the float64 oracle."""
+    from conformer_amd.autograd import LstmFn
+    g = torch.Generator().manual_seed(B * 100 + T + 7)
+    x = torch.randn(B, T, D, generator=g)
+    k = 1.0 / H ** 0.5
+    ps = [(torch.rand(4 * H, D, generator=g) * 2 - 1) * k, (torch.rand(4 * H, H, generator=g) * 2 - 1) * k,
+          (torch.rand(4 * H, generator=g) * 2 - 1) * k, (torch.rand(4 * H, generator=g) * 2 - 1) * k]
+    L = None
+    if ragged:
+        L = torch.sort(torch.randint(1, T + 1, (B,), generator=g), descending=True).values
+        L[0] = T
+    w = torch.randn(B, T, H, generator=g)
+    xr = x.double().requires_grad_(True)
+    pr = [p.double().requires_grad_(True) for p in ps]
+    ref = O.lstm_layer(xr, L, *pr)
+    (ref * w.double()).sum().backward()
+    xd = x.to(dev).requires_grad_(True)
+    pd = [p.to(dev).requires_grad_(True) for p in ps]
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y = LstmFn.apply(xd, *pd, None if L is None else L.to(dev))
+    (y.float() * w.to(dev)).sum().backward()
+    assert y.dtype == torch.float32 and rel_l2(y, ref.detach()) < 1e-2
+    if L is not None:
+        for b in range(B):
+            assert (y[b, int(L[b]):] == 0).all()
+    assert rel_l2(xd.grad, xr.grad) < 1e-2
+    for a, b, name in zip(pd, pr, ("w_ih", "w_hh", "b_ih", "b_hh")):
+        assert rel_l2(a.grad, b.grad) < 1e-2, name
+
+
 @pytest.mark.parametrize("train_bn", [False, True])
 def test_decoder_training_grads_vs_oracle_autograd(dev, train_bn):
     """N1 training: the whole decoder (LSTM -> Swish -> BatchNorm -> Linear(370)) forward + backward on the gfx950 kernels
