@@ -5,15 +5,24 @@
 // Why a second pair of kernels: the fp32 step (lstm.hip) is bound by re-streaming W_hh from L2 every frame -- 52 MB per
 // step at B = 64, H = 640 (26 MB of W_hh: a workgroup owns 16 utterances, so the matrix is read B/16 times; 26 MB of h: it is
 // broadcast to H/4 workgroups), ~8.5 TB/s of L2 -> CU traffic = 6 of the step's 11-12 us (tools/lstm_probe.py).  Here:
-//   * W_hh (and W_hh^T for the backward) is the per-optimizer-step 16-bit weight copy, h_{t-1} (dG_{t+1}) is exchanged between
-//     steps through a small 16-bit double buffer: half the bytes;
-//   * a workgroup owns 32 utterances x 8 hidden units (32 gate columns) forward, 32 utterances x 16 units backward: W_hh is
-//     read B/32 times, h is broadcast to H/8 workgroups: 13 MB per forward step instead of 52;
+//   * W_hh is the per-optimizer-step 16-bit weight copy, h_{t-1} is exchanged between steps through a small 16-bit double
+//     buffer: half the bytes;
+//   * a workgroup owns 32 utterances x 8 hidden units (32 gate columns): W_hh is read B/32 times, h is broadcast to H/8
+//     workgroups: 13 MB per step instead of 52;
 //   * operands go straight from global memory into the MFMA register layout (v_mfma_f32_32x32x16: lane (row li, k-half hf)
 //     holds 8 consecutive k = one 16-byte load of a row-major 16-bit row), ALL loads of a wave are issued before its first
 //     MFMA, and the thread's gate-stage operands before that: one memory round trip per step, no LDS staging;
 //   * the waves split the contraction; partial 32x32 tiles are summed through LDS.
 // One launch per frame (the kernel boundary is the grid-wide barrier of the recurrence), issued back to back from one C call.
+// 5.9 us per step at B = 64, H = 640 against 11.0 for the fp32 kernel (tools/lstm_probe.py).
+//
+// The BACKWARD stays on lstm.hip's fp32 kernel also under autocast.  Its contraction is over the 4H gate rows -- four times
+// the forward's -- and its A operand (dG_{t+1}, 4H wide) has to reach every workgroup.  Two 16-bit forms were built and
+// measured at B = 64, H = 640 (fp32 kernel: 12.0 us per step): (a) 32-utterance x 16-unit tiles owning the whole contraction:
+// 80 workgroups pulling 246 KB each through one CU, 13.4 us; (b) the contraction split over 8 workgroups per tile (40 KB each),
+// partial sums added with fp32 atomics, the workgroup drawing the last ticket of a tile doing the gate math: correct, but the
+// device-scope release/acquire it needs between workgroups (on this part: an L2 write-back per workgroup, the XCDs' L2s are
+// not coherent with each other) made it 31.9 us.  Neither beats the fp32 kernel, which is also the more accurate one.
 #include "cfm_common.h"
 
 namespace {
@@ -116,104 +125,10 @@ __global__ __launch_bounds__(256) void lstm_step16_kernel(const Lstm16Args a, co
     }
 }
 
-struct Lstm16BwdArgs {
-    const float* dy;              // (B, T, H)
-    const float* gates;           // (B, T, 4H) saved i|f|g|o
-    const float* cells;           // (B, T, H)
-    const void* whh_t16;          // (H, 4H) = W_hh^T, 16-bit
-    const int64_t* lengths;
-    float* dgates;                // (B, T, 4H) out
-    float* dc;                    // (B, H) running dc_next
-    void* dg16;                   // (2, B, 4H) 16-bit copy of dG_t, double buffered by t & 1
-    int B, T, H;
-};
-
-// Backward step t.  grid = (H/16, ceil(B/32)), 512 threads: 8 waves split the contraction over the 4H gate rows.
-// Columns 16..31 of the MFMA tile repeat columns 0..15 (same addresses: cache hits) and are not read back.
-template <typename T16>
-__global__ __launch_bounds__(512) void lstm_bwd_step16_kernel(const Lstm16BwdArgs a, const int t) {
-    using x8 = typename Lowp<T16>::x8;
-    __shared__ float part[8][32][17];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int li = lane & 31, hf = lane >> 5;
-    const int u0 = blockIdx.x * 16, b0 = blockIdx.y * 32;
-    const int H = a.H, H4 = 4 * a.H;
-    const T16* dg_next = static_cast<const T16*>(a.dg16) + (int64_t)((t + 1) & 1) * a.B * H4;
-    T16* dg_cur = static_cast<T16*>(a.dg16) + (int64_t)(t & 1) * a.B * H4;
-
-    // gate-stage operands of this thread (utterance tid >> 4, unit tid & 15)
-    const int bl = tid >> 4, u = tid & 15;
-    const int b = b0 + bl, unit = u0 + u;
-    const bool mine = b < a.B && unit < H;
-    const int bc = min(b, a.B - 1), uc = min(unit, H - 1);
-    const int64_t bt = (int64_t)bc * a.T + t;
-    const bool live = !a.lengths || t < a.lengths[bc];
-    const float dyv = a.dy[bt * H + uc];
-    const float* sg = a.gates + bt * H4 + uc;
-    const float ig = sg[0], fg = sg[H], gg = sg[2 * H], og = sg[3 * H];
-    const float ct = a.cells[bt * H + uc];
-    const float cprev = t > 0 ? a.cells[(bt - 1) * H + uc] : 0.f;
-    const float dcn = t + 1 < a.T ? a.dc[(int64_t)bc * H + uc] : 0.f;
-
-    f32x16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    if (t + 1 < a.T) {
-        const T16* arow = dg_next + (int64_t)min(b0 + li, a.B - 1) * H4 + 8 * hf;
-        const T16* brow = static_cast<const T16*>(a.whh_t16) + (int64_t)min(u0 + (li & 15), H - 1) * H4 + 8 * hf;
-        const int nstep = H4 / 16;                                // wave w takes steps w, w+8, ...
-        constexpr int NBAT = 10;
-        for (int s0 = wave; s0 < nstep; s0 += 8 * NBAT) {
-            x8 av[NBAT], bv[NBAT];
-#pragma unroll
-            for (int j = 0; j < NBAT; ++j) {
-                const int s = min(s0 + 8 * j, nstep - 1);
-                av[j] = *reinterpret_cast<const x8*>(arow + 16 * s);
-                bv[j] = *reinterpret_cast<const x8*>(brow + 16 * s);
-            }
-#pragma unroll
-            for (int j = 0; j < NBAT; ++j) {
-                if (s0 + 8 * j < nstep) acc = Lowp<T16>::mfma(av[j], bv[j], acc);
-            }
-        }
-    }
-    if (li < 16) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) part[wave][(r & 3) + 8 * (r >> 2) + 4 * hf][li] = acc[r];
-    }
-    __syncthreads();
-    if (!mine) return;
-    float* dg = a.dgates + bt * H4 + unit;
-    T16* dgh = dg_cur + (int64_t)b * H4 + unit;
-    if (!live) {
-        dg[0] = 0.f; dg[H] = 0.f; dg[2 * H] = 0.f; dg[3 * H] = 0.f;
-        dgh[0] = (T16)0.f; dgh[H] = (T16)0.f; dgh[2 * H] = (T16)0.f; dgh[3 * H] = (T16)0.f;
-        a.dc[(int64_t)b * H + unit] = 0.f;
-        return;
-    }
-    float dh = dyv;
-#pragma unroll
-    for (int w = 0; w < 8; ++w) dh += part[w][bl][u];
-    const float th = tanh_p(ct);
-    const float dct = dh * og * (1.0f - th * th) + dcn;
-    const float di = dct * gg * ig * (1.0f - ig), df = dct * cprev * fg * (1.0f - fg);
-    const float dgg = dct * ig * (1.0f - gg * gg), dog = dh * th * og * (1.0f - og);
-    dg[0] = di; dg[H] = df; dg[2 * H] = dgg; dg[3 * H] = dog;
-    dgh[0] = (T16)di; dgh[H] = (T16)df; dgh[2 * H] = (T16)dgg; dgh[3 * H] = (T16)dog;
-    a.dc[(int64_t)b * H + unit] = dct * fg;
-}
-
 template <typename T16>
 int lstm_fwd16(const Lstm16Args& a, hipStream_t s) {
     const dim3 grid((unsigned)(a.H / 8), (unsigned)((a.B + 31) / 32));
     for (int t = 0; t < a.T; ++t) hipLaunchKernelGGL(lstm_step16_kernel<T16>, grid, dim3(256), 0, s, a, t);
-    return cfm_launch_status();
-}
-
-template <typename T16>
-int lstm_bwd16(const Lstm16BwdArgs& a, hipStream_t s) {
-    const dim3 grid((unsigned)(a.H / 16), (unsigned)((a.B + 31) / 32));
-    for (int t = a.T - 1; t >= 0; --t) hipLaunchKernelGGL(lstm_bwd_step16_kernel<T16>, grid, dim3(512), 0, s, a, t);
     return cfm_launch_status();
 }
 
@@ -231,20 +146,5 @@ extern "C" int cfm_lstm_fwd_mfma16_f32(int prec, const float* gates_x, const voi
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (prec == CFM_PREC_BF16) return lstm_fwd16<__bf16>(a, s);
     if (prec == CFM_PREC_FP16) return lstm_fwd16<_Float16>(a, s);
-    return CFM_ERR_UNSUPPORTED;
-}
-
-// cfm_lstm_bwd_f32 with the recurrent product on the 16-bit matrix pipe: whh_t16 (H,4H) = 16-bit W_hh^T, dg16_scratch holds
-// 2*B*4H 16-bit elements.  H % 16 == 0.
-extern "C" int cfm_lstm_bwd_mfma16_f32(int prec, const float* dy, const float* gates, const float* cells, const void* whh_t16,
-                                       const int64_t* lengths_or_null, float* dgates, float* dc_state, void* dg16_scratch, int B,
-                                       int T, int H, cfm_stream_t stream) {
-    CFM_REQUIRE(dy && gates && cells && whh_t16 && dgates && dc_state && dg16_scratch, CFM_ERR_NULL);
-    CFM_REQUIRE(B > 0 && T > 0 && H > 0 && (H & 15) == 0, CFM_ERR_BAD_SHAPE);
-    CFM_REQUIRE(CFM_ALIGNED16(whh_t16) && CFM_ALIGNED16(dg16_scratch), CFM_ERR_ALIGN);
-    const Lstm16BwdArgs a{dy, gates, cells, whh_t16, lengths_or_null, dgates, dc_state, dg16_scratch, B, T, H};
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    if (prec == CFM_PREC_BF16) return lstm_bwd16<__bf16>(a, s);
-    if (prec == CFM_PREC_FP16) return lstm_bwd16<_Float16>(a, s);
     return CFM_ERR_UNSUPPORTED;
 }

@@ -895,16 +895,10 @@ def lstm_backward(x, w_ih, w_hh, y, gates, cells, dy, lengths=None, need_dx: boo
     dG = torch.empty(B, T, 4 * H, device=x.device, dtype=x.dtype)
     dc = torch.empty(B, H, device=x.device, dtype=x.dtype)
     prec = mfma16_prec()
-    whh_t16 = weight16(w_hh, prec, transposed=True) if prec and H % 16 == 0 else None
-    if whh_t16 is not None:
-        dg16 = torch.empty(2, B, 4 * H, device=x.device, dtype=_DT16[prec])
-        _lib.check(lib.cfm_lstm_bwd_mfma16_f32(prec, dy.data_ptr(), gates.data_ptr(), cells.data_ptr(), whh_t16.data_ptr(),
-                                               _p(lengths), dG.data_ptr(), dc.data_ptr(), dg16.data_ptr(), B, T, H, _stream()),
-                   "cfm_lstm_bwd_mfma16_f32")
-    else:
-        whh_t = w_hh.t().contiguous()                                 # (H,4H): 6.5 MB of glue per step
-        _lib.check(lib.cfm_lstm_bwd_f32(dy.data_ptr(), gates.data_ptr(), cells.data_ptr(), whh_t.data_ptr(), _p(lengths),
-                                        dG.data_ptr(), dc.data_ptr(), B, T, H, _stream()), "cfm_lstm_bwd_f32")
+    # (fp32 recurrence also under autocast: the 16-bit forms of this step measured slower, see csrc/lstm_mfma16.hip)
+    whh_t = w_hh.t().contiguous()                                     # (H,4H): 6.5 MB of glue per step
+    _lib.check(lib.cfm_lstm_bwd_f32(dy.data_ptr(), gates.data_ptr(), cells.data_ptr(), whh_t.data_ptr(), _p(lengths),
+                                    dG.data_ptr(), dc.data_ptr(), B, T, H, _stream()), "cfm_lstm_bwd_f32")
     dG2, x2 = dG.view(B * T, 4 * H), x.reshape(B * T, D)
     h_prev = torch.zeros_like(y)                                      # h_{t-1}: y shifted by one frame per utterance
     h_prev[:, 1:] = y[:, :-1]

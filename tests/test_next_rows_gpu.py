@@ -148,8 +148,9 @@ def test_lstm_backward_vs_oracle_autograd(dev, B, T, D, H, ragged):
 
 @pytest.mark.parametrize("B,T,D,H,ragged", [(3, 25, 32, 16, True), (2, 49, 144, 320, True), (64, 30, 64, 640, True), (40, 12, 64, 48, True)])
 def test_lstm_bf16_recurrence_and_bptt_vs_oracle(dev, B, T, D, H, ragged):
-    """Under autocast the recurrent product runs on the 16-bit matrix pipe (lstm_mfma16.hip: 32-utterance x 8-unit workgroups,
-    16-bit W_hh and h exchange): forward and every gradient within the north_star's 1e-2 of the float64 oracle."""
+    """Under autocast the forward recurrent product runs on the 16-bit matrix pipe (lstm_mfma16.hip: 32-utterance x 8-unit
+    workgroups, 16-bit W_hh and h exchange; BPTT on the fp32 kernel): forward and every gradient within the north_star's
+    1e-2 of the float64 oracle."""
     from conformer_amd.autograd import LstmFn
     g = torch.Generator().manual_seed(B * 100 + T + 7)
     x = torch.randn(B, T, D, generator=g)

@@ -33,6 +33,29 @@ def main():
             run()
         e1.record(); torch.cuda.synchronize()
         print(f"B={B} H={H} T={T}: {e0.elapsed_time(e1) / 5 / T * 1e3:.2f} us per step (forward recurrence only)")
+    # the 16-bit recurrence (lstm_mfma16.hip): forward and backward per-step time
+    for B, H, T in [(64, 640, 249), (32, 640, 249)]:
+        gx = torch.randn(B, T, 4 * H, device=dev); w_hh = (torch.randn(4 * H, H, device=dev) * 0.05)
+        w16, wt16 = w_hh.to(torch.bfloat16), w_hh.t().contiguous().to(torch.bfloat16)
+        y = torch.empty(B, T, H, device=dev); c = torch.empty(B, H, device=dev)
+        h16 = torch.empty(2, B, H, device=dev, dtype=torch.bfloat16)
+        gates = torch.rand(B, T, 4 * H, device=dev); cells = torch.randn(B, T, H, device=dev); dy = torch.randn(B, T, H, device=dev)
+        dG = torch.empty(B, T, 4 * H, device=dev); dc = torch.empty(B, H, device=dev)
+        wt32 = w_hh.t().contiguous()
+        st = torch.cuda.current_stream().cuda_stream
+        fns = {"fwd 16-bit": lambda: lib.cfm_lstm_fwd_mfma16_f32(1, gx.data_ptr(), w16.data_ptr(), None, y.data_ptr(), c.data_ptr(), h16.data_ptr(), None, None, B, T, H, st),
+               "fwd fp32": lambda: lib.cfm_lstm_fwd_f32(gx.data_ptr(), w_hh.data_ptr(), None, y.data_ptr(), c.data_ptr(), None, None, B, T, H, st),
+               "bwd fp32": lambda: lib.cfm_lstm_bwd_f32(dy.data_ptr(), gates.data_ptr(), cells.data_ptr(), wt32.data_ptr(), None, dG.data_ptr(), dc.data_ptr(), B, T, H, st)}
+        for name, fn in fns.items():
+            for _ in range(2):
+                assert fn() == 0
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                fn()
+            e1.record(); torch.cuda.synchronize()
+            print(f"B={B} H={H}: {name}: {e0.elapsed_time(e1) / 5 / T * 1e3:.2f} us per step")
     B, H, T = 64, 640, 249
     gx = torch.randn(B, T, 4 * H, device=dev); w_hh = torch.randn(4 * H, H, device=dev) * 0.05
     y = torch.empty(B, T, H, device=dev); c = torch.empty(B, H, device=dev)
