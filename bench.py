@@ -166,10 +166,11 @@ def pmc_traffic_bytes(kernel_substr: str):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE
     collected in separate --pmc runs of this same command, corrected as MI355X_MICROARCH.md prescribes: KiB units,
     FETCH_SIZE doubled on gfx950) -- tools/pmc_traffic.py writes the file; None when it is absent."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    import glob
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_traffic.json")))   # the latest round's passes
     try:
-        table = json.load(open(path))
-    except (OSError, ValueError):
+        table = json.load(open(paths[-1]))
+    except (OSError, ValueError, IndexError):
         return None
     for name, v in table.items():
         if kernel_substr in name:
@@ -414,7 +415,7 @@ def main():
             "achieved": dom["tflops"], "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s",
             "frac": dom["tflops"] / PEAK_MFMA_F32_TFLOPS,
             "traffic": pmc_traffic_bytes(dom["pmc_name"]) if dom.get("pmc_name") else None,
-            "traffic_unit": "HBM bytes per launch (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_pmc_traffic.json)",
+            "traffic_unit": "HBM bytes per launch (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE, latest profiles/rNN_pmc_traffic.json)",
             "algorithmic_bytes": dom.get("alg_bytes"),
             "avg_launch_ms": dom["avg_ms"], "launches_per_step": dom["launches_per_step"],
             "gemm_ms_per_step": tot, "gemm_share_of_step": tot / ms,
