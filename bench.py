@@ -367,10 +367,10 @@ def main():
     log(f"[bench] rank {rank}/{world}: model on {dev}, warm-up {args.warmup} steps")
     last = {}
     runner, graphed = enc, False
-    if not args.no_graph and args.dtype != "bf16":
+    if not args.no_graph:
         try:
             from conformer_amd.graph import GraphedEncoder
-            runner, graphed = GraphedEncoder(enc, x, lengths), True
+            runner, graphed = GraphedEncoder(enc, x, lengths, autocast_dtype=torch.bfloat16 if args.dtype == "bf16" else None), True
         except Exception as e:                               # capture is an optimisation: fall back to eager launches
             log(f"[bench] hipGraph capture unavailable ({type(e).__name__}: {e}); eager launches")
 
@@ -430,9 +430,9 @@ def main():
             try:
                 ops.set_fp32_matmul(mode)
                 run2 = enc
-                if not autocast and not args.no_graph:
+                if not args.no_graph:
                     from conformer_amd.graph import GraphedEncoder
-                    run2 = GraphedEncoder(enc, x, lengths)
+                    run2 = GraphedEncoder(enc, x, lengths, autocast_dtype=torch.bfloat16 if autocast else None)
                 amp2 = (lambda: torch.autocast("cuda", dtype=torch.bfloat16)) if autocast else contextlib.nullcontext
                 res = {}
 

@@ -28,13 +28,14 @@ class GraphedEncoder:
     need `conformer_amd.model.utils._guard.invalidate_weight_caches()`, which this check also sees."""
 
     def __init__(self, encoder: torch.nn.Module, example_x: torch.Tensor, example_lengths: Optional[torch.Tensor],
-                 warmup: int = 2) -> None:
+                 warmup: int = 2, autocast_dtype: Optional[torch.dtype] = None) -> None:
         if encoder.training:
             raise ValueError("GraphedEncoder captures the inference path: call encoder.eval() first")
         self.encoder = encoder
         self.static_x = example_x.clone()
         self.static_len = None if example_lengths is None else example_lengths.clone()
         self.warmup = warmup
+        self.autocast_dtype = autocast_dtype             # bfloat16 / float16: capture the 16-bit matrix-pipe path
         self.captures = 0
         self._capture()
 
@@ -44,13 +45,14 @@ class GraphedEncoder:
         self.static_y = self.static_out_len = None
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side), torch.no_grad():
-            for _ in range(warmup):                      # builds every cached pack / table outside the capture
+        amp = lambda: torch.autocast("cuda", dtype=self.autocast_dtype or torch.bfloat16, enabled=self.autocast_dtype is not None)
+        with torch.cuda.stream(side), torch.no_grad(), amp():
+            for _ in range(warmup):                      # builds every cached pack / table / 16-bit weight copy outside the capture
                 encoder(self.static_x, self.static_len)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.no_grad(), torch.cuda.graph(self.graph):
+        with torch.no_grad(), torch.cuda.graph(self.graph), amp():
             self.static_y, self.static_out_len = encoder(self.static_x, self.static_len)
         self._fingerprint = _weights_fingerprint(encoder)
         self.captures += 1

@@ -31,7 +31,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "trace":
                                                  torch.cuda.current_stream().cuda_stream), "trace")
     torch.cuda.synchronize()
     s = tr.cpu().view(ntiles, 16)[:, :9]
-    names = ["band mfma", "spill", "content mfma", "skew reads", "select+add", "softmax", "PV", "rotate"]
+    names = ["stage next K/V", "content mfma", "band mfma+spill", "skew reads", "select+add", "softmax", "PV", "barrier"]
     print("tile | " + " | ".join(names) + " | total   (ns, 100 MHz clock)")
     for kt in range(ntiles):
         dts = [(int(s[kt, i + 1]) - int(s[kt, i])) * 10 for i in range(8)]
