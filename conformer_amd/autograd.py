@@ -134,6 +134,30 @@ class FeedForwardFn(Function):
         return dx, dlw, dlb, dw1, db1, dw2, db2, None, None, None
 
 
+class RelPosAttentionFn(Function):
+    """ctx = RelPosAttention(qkv, pos): the attention core alone (attention.py:47-72,94-102) -- what RelativeMultiHeadAttention's
+    own forward needs between its projection Linears when it is called directly in training."""
+
+    @staticmethod
+    @_fwd_prec
+    def forward(ctx, qkv, pos, u, vb, lengths, n_heads, drop_p=0.0):
+        ctx.drop_p = float(drop_p)
+        ctx.seed = ops.new_seeds(1)[0] if ctx.drop_p > 0.0 else 0
+        att, lse = ops.relpos_attention_train(qkv, pos, u, vb, lengths, n_heads, ctx.drop_p, ctx.seed)
+        ctx.save_for_backward(qkv, pos, u, vb, att, lse, lengths if lengths is not None else torch.empty(0))
+        ctx.has_len = lengths is not None
+        ctx.n_heads = n_heads
+        return att
+
+    @staticmethod
+    @_bwd_prec
+    def backward(ctx, datt):
+        qkv, pos, u, vb, att, lse, lengths = ctx.saved_tensors
+        dqkv, dpos, du, dvb = ops.relpos_attention_bwd(qkv, pos, u, vb, lengths if ctx.has_len else None, ctx.n_heads, att, lse,
+                                                       datt.contiguous(), ctx.drop_p, ctx.seed)
+        return dqkv, dpos, du, dvb, None, None, None
+
+
 class SelfAttentionFn(Function):
     """out = Wo . RelPosAttention(LN(x)) + bo + x                  (attention.py:14-18,47-102 + block.py:21)
     `pos` is this layer's (2T-1, d) slice of the projected position table (it has its own graph through LinearFn)."""

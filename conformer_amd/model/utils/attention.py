@@ -72,15 +72,23 @@ class RelativeMultiHeadAttention(nn.Module):
     # ---- reference-compatible entry (attention.py:74) ------------------------------------------
     def forward(self, q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, pos_embedding: torch.Tensor,
                 mask: Optional[torch.Tensor] = None) -> torch.Tensor:
-        refuse_dropout(self, "RelativeMultiHeadAttention")
-        if ag.needs_grad(self, q):
-            raise NotImplementedError("RelativeMultiHeadAttention.forward: the differentiable path lives one level up "
-                                      "(MultiHeadSelfAttentionModule folds the LayerNorm and the residual)")
         if not (k is q and v is q):
             raise NotImplementedError("the fused gfx950 kernel implements SELF-attention (q is k is v), which is "
                                       "the only way the reference calls it (attention.py:16)")
         table = pos_embedding[0] if pos_embedding.dim() == 3 else pos_embedding
         lengths = None if mask is None else lengths_from_key_padding_mask(mask)
+        if ag.needs_grad(self, q, table):
+            # differentiable path of the bare module (the blocks go through MultiHeadSelfAttentionModule, which folds the
+            # LayerNorm and the residual into SelfAttentionFn): projections -> attention core -> out_proj, each an autograd
+            # Function on the gfx950 kernels; the weight concatenation is ordinary autograd
+            wqkv = torch.cat([self.query_proj.weight, self.key_proj.weight, self.value_proj.weight], dim=0)
+            bqkv = torch.cat([self.query_proj.bias, self.key_proj.bias, self.value_proj.bias], dim=0)
+            qkv = ag.LinearFn.apply(q, wqkv, bqkv)
+            pos = ag.LinearFn.apply(table, self.pos_proj.weight, self.pos_proj.bias)
+            att = ag.RelPosAttentionFn.apply(qkv, pos, self.content_bias, self.position_bias, lengths, self.n_heads,
+                                             active_dropout(self.dropout))
+            return ag.LinearFn.apply(att, self.out_proj.weight, self.out_proj.bias)
+        refuse_dropout(self, "RelativeMultiHeadAttention")
         return self.fused(q, table, lengths)
 
 

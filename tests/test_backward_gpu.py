@@ -214,3 +214,42 @@ def test_block_forward_backward_other_geometries_vs_oracle_autograd(dev, d, H, K
             assert p.grad is None or float(p.grad.abs().max()) < 1e-3, n      # mathematically-zero gradients
         else:
             assert rel_l2(p.grad, r) < 2e-4, n
+
+
+def test_bare_relative_attention_module_is_differentiable(dev):
+    """RelativeMultiHeadAttention.forward(q, k, v, pos, mask) called directly in training (attention.py:74-92: projections,
+    attention core, out_proj; the blocks use the fused MultiHeadSelfAttentionModule path instead): output and every gradient
+    vs torch autograd through the float64 restatement of the same lines."""
+    from model.utils.attention import RelativeMultiHeadAttention
+    d, H, B, T = 64, 4, 3, 37
+    g = torch.Generator().manual_seed(11)
+    mod = RelativeMultiHeadAttention(d, H)
+    with torch.no_grad():
+        for p in mod.parameters():
+            p.copy_(torch.randn(p.shape, generator=g) * (0.2 if p.dim() > 1 else 0.1))
+    x = torch.randn(B, T, d, generator=g)
+    pe = torch.randn(2 * T - 1, d, generator=g)
+    L = torch.tensor([T, 20, 5])
+    w = torch.randn(B, T, d, generator=g)
+    # float64 restatement (attention.py:76-91)
+    P = {n: p.detach().double().requires_grad_(True) for n, p in mod.named_parameters()}
+    xr, per = x.double().requires_grad_(True), pe.double().requires_grad_(True)
+    dh = d // H
+    lin = lambda t, n: t @ P[n + ".weight"].t() + P[n + ".bias"]
+    ctx = O.relpos_attention_core(lin(xr, "query_proj").view(B, T, H, dh), lin(xr, "key_proj").view(B, T, H, dh),
+                                  lin(xr, "value_proj").view(B, T, H, dh), lin(per, "pos_proj").view(2 * T - 1, H, dh),
+                                  P["content_bias"], P["position_bias"], L)
+    ref = lin(ctx, "out_proj")
+    (ref * w.double()).sum().backward()
+    mod = mod.to(dev).train()
+    xd, ped = x.to(dev).requires_grad_(True), pe.to(dev).requires_grad_(True)
+    mask = (torch.arange(T)[None, :] >= L[:, None])[:, None, None, :].to(dev)
+    y = mod(xd, xd, xd, ped, mask)
+    (y * w.to(dev)).sum().backward()
+    assert rel_l2(y, ref.detach()) < 2e-5
+    assert rel_l2(xd.grad, xr.grad) < 5e-5 and rel_l2(ped.grad, per.grad) < 5e-5
+    for n, p in mod.named_parameters():
+        if float(P[n].grad.norm()) < 1e-9:                     # key / position-projection biases: zero by construction
+            assert float(p.grad.abs().max()) < 1e-4, n
+        else:
+            assert rel_l2(p.grad, P[n].grad) < 5e-5, n
