@@ -429,28 +429,38 @@ __global__ __launch_bounds__(256) void dwconv_stats_kernel(const float* __restri
     }
 }
 
-// mean / biased variance of a channel = the ordered merge of its workgroup partials (workgroup = 64 channels; wave v folds
-// the v-th quarter of the partials in index order, wave 0 then folds the four results in wave order: a fixed tree);
-// running <- (1-mom)*running + mom*{mean, var*n/(n-1)}   (convolution.py:16 defaults)
-__global__ __launch_bounds__(256) void bn_merge_update_kernel(const float* __restrict__ part, int nblk,
-                                                              float* __restrict__ batch_mean, float* __restrict__ batch_var,
-                                                              float* __restrict__ run_mean, float* __restrict__ run_var,
-                                                              float momentum, int C) {
-    __shared__ float red[4][3][64];
+// mean / biased variance of a channel = the ordered merge of its workgroup partials (workgroup = 64 channels x 16 waves; wave v
+// folds the v-th sixteenth of the partials in index order, wave 0 then folds the sixteen results in wave order: a fixed tree);
+// running <- (1-mom)*running + mom*{mean, var*n/(n-1)}   (convolution.py:16 defaults).
+// The partial triples of a wave are requested in batches of 8 before they are merged: the first version (4 waves, one
+// dependent load + merge per partial) took as long as the statistics pass itself (20 us at 128 partials).
+__global__ __launch_bounds__(1024) void bn_merge_update_kernel(const float* __restrict__ part, int nblk,
+                                                               float* __restrict__ batch_mean, float* __restrict__ batch_var,
+                                                               float* __restrict__ run_mean, float* __restrict__ run_var,
+                                                               float momentum, int C) {
+    constexpr int NW = 16, NBAT = 8;
+    __shared__ float red[NW][3][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + lane;
     const int cc = c < C ? c : C - 1;
-    const int per = (nblk + 3) / 4, i0 = wave * per, i1 = min(nblk, i0 + per);
+    const int per = (nblk + NW - 1) / NW, i0 = wave * per, i1 = min(nblk, i0 + per);
     float n = 0.f, mean = 0.f, m2 = 0.f;
-    for (int i = i0; i < i1; ++i) {
-        const float* p = part + (int64_t)i * 3 * C;
-        chan_merge(n, mean, m2, p[cc], p[C + cc], p[2 * C + cc]);
+    for (int ib = i0; ib < i1; ib += NBAT) {
+        float pn[NBAT], pm[NBAT], pq[NBAT];
+#pragma unroll
+        for (int j = 0; j < NBAT; ++j) {
+            const float* p = part + (int64_t)min(ib + j, nblk - 1) * 3 * C;
+            pn[j] = p[cc]; pm[j] = p[C + cc]; pq[j] = p[2 * C + cc];
+        }
+#pragma unroll
+        for (int j = 0; j < NBAT; ++j)
+            if (ib + j < i1) chan_merge(n, mean, m2, pn[j], pm[j], pq[j]);           // (wave-uniform)
     }
     red[wave][0][lane] = n; red[wave][1][lane] = mean; red[wave][2][lane] = m2;
     __syncthreads();
     if (wave != 0 || c >= C) return;
 #pragma unroll
-    for (int v = 1; v < 4; ++v) chan_merge(n, mean, m2, red[v][0][lane], red[v][1][lane], red[v][2][lane]);
+    for (int v = 1; v < NW; ++v) chan_merge(n, mean, m2, red[v][0][lane], red[v][1][lane], red[v][2][lane]);
     const float var = m2 / n;
     batch_mean[c] = mean;
     batch_var[c] = var;
@@ -673,7 +683,7 @@ extern "C" int cfm_dwconv_bn_stats_f32(const float* g, const float* w, const flo
         default: return CFM_ERR_UNSUPPORTED;
     }
 #undef DWS
-    hipLaunchKernelGGL(bn_merge_update_kernel, dim3((unsigned)cblocks), dim3(256), 0, s, part, B * nseg, batch_mean,
+    hipLaunchKernelGGL(bn_merge_update_kernel, dim3((unsigned)cblocks), dim3(1024), 0, s, part, B * nseg, batch_mean,
                        batch_var, running_mean_or_null, running_var_or_null, momentum, C);
     return cfm_launch_status();
 }
