@@ -174,3 +174,57 @@ def test_forward_gemms_dwconv_layernorm_next_to_poison(dev):
     x, lw, lb = rnd(77, 144, seed=13), rnd(144, seed=14), rnd(144, seed=15)
     assert rel_l2(ops.layernorm(G(x), G(lw), G(lb)), torch.nn.functional.layer_norm(x.double(), (144,), lw.double(), lb.double())) < 2e-5
     assert P.intact()
+
+
+def test_round2_training_kernels_next_to_poison(dev):
+    """The kernels added in round 2 load with clamped addresses + selects instead of branches: the weight(+bias)-gradient kernel
+    (ragged contraction length: the last K-tile of the last split is partial), the fused Swish-backward epilogue with 16-bit Z
+    and output, the one-pass LayerNorm backward (ragged row count per wave) and the 16-bit LSTM recurrence."""
+    from conformer_amd import ops
+    P = Poisoned(dev)
+    G = lambda t: t.to(dev)
+    m, n, k = 7968 // 8 + 3 * 8, 256, 128                 # m = 1020: not a multiple of 64 (contraction tile) nor of the split
+    x, w, dy, z = rnd(m, k, seed=1), rnd(n, k, seed=2) * 0.1, rnd(m, n, seed=3), rnd(m, n, seed=4)
+    w2 = rnd(k, n, seed=5) * 0.1
+
+    def run(place):
+        out = []
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            xs = place(G(x).to(torch.bfloat16))                                   # activation stored by its producer in bf16
+            dx, dw, db = ops.linear_bwd(xs, place(G(w)), place(G(dy)))             # dX (general kernel), dW+db (gemm_dw16: A fp32, B bf16)
+            out += [dx, dw, db]
+            zs = place(G(z).to(torch.bfloat16))
+            dz, dw2, db2 = ops.linear_bwd(place(G(rnd(m, n, seed=6)).to(torch.bfloat16)), place(G(w2)), place(G(rnd(m, k, seed=7))),
+                                          alpha=0.5, Z=zs, dx16=True)              # EPI 5: swish'(Z) epilogue, 16-bit Z and result
+            out += [dz.float(), dw2, db2]
+            dx3, dw3, db3 = ops.linear_bwd(xs, place(G(w)), place(G(dy).to(torch.bfloat16)))   # 16-bit dY: forward-kernel dX + all-16-bit dW
+            out += [dx3, dw3, db3]
+        return out
+
+    plain = run(lambda t: t.clone())
+    guarded = run(P.place)
+    assert P.intact()
+    for a, b in zip(guarded, plain):
+        assert torch.isfinite(a).all()
+        assert rel_l2(a, b) < 1e-3                      # (split-K atomics: not bit-identical)
+    # LayerNorm backward, fused: 1003 rows (ragged rows per wave), d = 144
+    rows, d = 1003, 144
+    xl, gl, dyl, dr = rnd(rows, d, seed=8), rnd(d, seed=9), rnd(rows, d, seed=10), rnd(rows, d, seed=11)
+    mean, rstd = xl.mean(-1), 1.0 / torch.sqrt(xl.var(-1, unbiased=False) + 1e-5)
+    P2 = Poisoned(dev)
+    ref = ops.layernorm_bwd(G(xl), G(gl), G(dyl), G(mean), G(rstd), dres=G(dr))
+    got = ops.layernorm_bwd(P2.place(G(xl)), P2.place(G(gl)), P2.place(G(dyl)), P2.place(G(mean)), P2.place(G(rstd)), dres=P2.place(G(dr)))
+    assert P2.intact()
+    for a, b in zip(got, ref):
+        assert torch.isfinite(a).all() and torch.equal(a, b)     # deterministic by construction
+    # 16-bit LSTM forward: B = 37 (ragged utterance block), H = 48 (three MFMA steps: waves 3 of 4 idle), ragged lengths
+    B, T, D, H = 37, 9, 32, 48
+    xx, wih, whh, bias = rnd(B, T, D, seed=12), rnd(4 * H, D, seed=13) * 0.2, rnd(4 * H, H, seed=14) * 0.2, rnd(4 * H, seed=15) * 0.1
+    L = torch.sort(torch.randint(1, T + 1, (B,), generator=torch.Generator().manual_seed(3)), descending=True).values
+    P3 = Poisoned(dev)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        ref = ops.lstm_forward(G(xx), G(wih), G(whh), G(bias), G(L), save=True)
+        got = ops.lstm_forward(P3.place(G(xx)), P3.place(G(wih)), P3.place(G(whh)), P3.place(G(bias)), G(L), save=True)
+    assert P3.intact()
+    for a, b in zip(got, ref):
+        assert torch.isfinite(a).all() and torch.equal(a, b)
