@@ -30,6 +30,7 @@ SIGNATURES = {
     "cfm_gemm_mfma16_f32": (c_int, [_I, _I, _P, _I, _P, _I, _P, _P, _F, _P, _I, _P, _I, _L, _I, _I, _L, _L, _L, _F, _U, _P]),
     "cfm_layernorm_fwd_out16_f32": (c_int, [_I, _P, _P, _P, _P, _P, _P, _L, _I, _F, _P]),
     "cfm_cast16_f32": (c_int, [_I, _P, _P, _L, _P]),
+    "cfm_cast16_multi_f32": (c_int, [_I, _P, _I, _P]),
     "cfm_relpos_attention_mfma16_f32": (c_int, [_I, _P, _P, _P, _L, _P, _L, _P, _P, _P, _P, _L, _P, _I, _I, _I, _I, _F, _U, _P]),
     "cfm_subsample_conv2_relu_mfma16_f32": (c_int, [_I, _P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P]),
     "cfm_subsample_conv1_relu_out16_f32": (c_int, [_I, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
@@ -127,6 +128,12 @@ def load() -> ctypes.CDLL:
         fn.argtypes = args
     _lib = lib
     return lib
+
+
+class CastItem(ctypes.Structure):
+    """cfm_cast_item of include/conformer_hip.h"""
+    _fields_ = [("src", ctypes.c_void_p), ("dst", ctypes.c_void_p), ("rows", ctypes.c_int64), ("cols", ctypes.c_int64),
+                ("transpose", ctypes.c_int)]
 
 
 def check(status: int, what: str) -> None:

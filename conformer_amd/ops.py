@@ -6,6 +6,7 @@ kernels on torch's current stream.  Inputs on the wrong device/dtype raise; ther
 from __future__ import annotations
 
 import threading
+import ctypes
 import weakref
 from typing import Optional, Tuple
 
@@ -97,7 +98,10 @@ def weight16(w: torch.Tensor, prec: int, transposed: bool = False) -> Optional[t
     if hit is not None and hit[0]() is base and hit[1] == _ver(w) and hit[2] == prec and hit[3] == w.shape:
         return hit[4]
     if transposed:
-        out = w.detach().t().to(_DT16[prec]).contiguous()
+        out = torch.empty(w.shape[1], w.shape[0], device=w.device, dtype=_DT16[prec])
+        item = (_lib.CastItem * 1)()
+        item[0].src, item[0].dst, item[0].rows, item[0].cols, item[0].transpose = w.data_ptr(), out.data_ptr(), w.shape[0], w.shape[1], 1
+        _lib.check(_lib.load().cfm_cast16_multi_f32(prec, ctypes.addressof(item), 1, _stream()), "cfm_cast16_multi_f32")
     else:
         out = torch.empty(w.shape, device=w.device, dtype=_DT16[prec])
         _lib.check(_lib.load().cfm_cast16_f32(prec, w.data_ptr(), out.data_ptr(), w.numel(), _stream()), "cfm_cast16_f32")
@@ -106,6 +110,36 @@ def weight16(w: torch.Tensor, prec: int, transposed: bool = False) -> Optional[t
             del _W16_CACHE[k]
     _W16_CACHE[key] = (weakref.ref(base), _ver(w), prec, w.shape, out)
     return out
+
+
+def refresh_weight16(params) -> int:
+    """Re-cast, in ONE batched launch per 48 weights, every cached 16-bit copy (plain and transposed) of the given parameters
+    that went stale -- called by FusedAdam right after its update, so the next forward finds every copy current instead of
+    issuing ~130 five-microsecond cast launches (+ ~130 ATen kernels for the transposed copies) one by one.  The copies are
+    rewritten IN PLACE (same addresses: graph-friendly; the previous step's kernels that read them precede the optimizer
+    step on the stream).  Returns the number of copies refreshed."""
+    by_prec = {}
+    for p in params:
+        for transposed in (False, True):
+            key = (p.data_ptr(), transposed)
+            hit = _W16_CACHE.get(key)
+            if hit is None or hit[0]() is not (p._base if p._base is not None else p) or hit[1] == _ver(p):
+                continue
+            shape2 = tuple(hit[3])                     # the 2-D view the copy was made from (conv weights arrive reshaped)
+            if len(shape2) != 2 or shape2[0] * shape2[1] != p.numel() or not p.is_contiguous():
+                continue
+            w2 = p.detach().reshape(shape2)
+            by_prec.setdefault(hit[2], []).append((w2, hit[4], transposed))
+            _W16_CACHE[key] = (hit[0], _ver(p), hit[2], hit[3], hit[4])
+    n = 0
+    for prec, items in by_prec.items():
+        arr = (_lib.CastItem * len(items))()
+        for i, (w2, out, transposed) in enumerate(items):
+            arr[i].src, arr[i].dst = w2.data_ptr(), out.data_ptr()
+            arr[i].rows, arr[i].cols, arr[i].transpose = w2.shape[0], w2.shape[1], int(transposed)
+        _lib.check(_lib.load().cfm_cast16_multi_f32(prec, ctypes.addressof(arr), len(items), _stream()), "cfm_cast16_multi_f32")
+        n += len(items)
+    return n
 
 
 _ZERO_BIAS = {}

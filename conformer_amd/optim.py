@@ -75,6 +75,7 @@ class FusedAdam(torch.optim.Optimizer):
             # the kernel wrote through raw pointers: tell autograd (and every cache keyed on `_version`: the packed / fused /
             # 16-bit weight copies of the modules and of ops.weight16) that the parameters changed in place
             torch.autograd.graph.increment_version(plist)
+            ops.refresh_weight16(plist)                  # the cached 16-bit weight copies of the autocast path, in one batched launch
         return loss
 
     def _sync_steps(self) -> None:

@@ -136,6 +136,15 @@ int cfm_gemm_mfma16_f32(int prec, int epi, const void* A, int a_is_16bit, const 
  *      (cfm_layernorm_fwd_out16_f32, or a GEMM with c_is_16bit).  c_is_16bit: C is stored in `prec` (ldc in elements).
  *      z_is_16bit (epi 1, N % 8 == 0): the saved pre-activation Z is stored in `prec` too (what autocast keeps for the
  *      backward of silu: reference model/utils/activation.py). */
+/* Multi-tensor cast of fp32 master weights to `prec` (optionally transposed): one launch per CFM_CAST_BATCH items. */
+#define CFM_CAST_BATCH 48
+typedef struct cfm_cast_item {
+    const float* src;   /* (rows, cols) fp32, contiguous */
+    void* dst;          /* 16-bit: (rows, cols), or (cols, rows) when transpose != 0 */
+    int64_t rows, cols;
+    int transpose;
+} cfm_cast_item;
+int cfm_cast16_multi_f32(int prec, const cfm_cast_item* items, int count, cfm_stream_t stream);
 int cfm_layernorm_fwd_out16_f32(int prec, const float* x, const float* gamma, const float* beta, void* y16,
                                 float* mean_or_null, float* rstd_or_null, int64_t rows, int d, float eps,
                                 cfm_stream_t stream);

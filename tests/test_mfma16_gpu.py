@@ -240,3 +240,29 @@ def test_mfma16_stem_inference_keeps_16bit_activations(dev, dt16):
     assert h2.dtype == dt16 and y.dtype == torch.float32
     tol = 1e-2 if dt16 == torch.bfloat16 else 2e-3
     assert rel_l2(h2.float(), ref_h2) < tol and rel_l2(y, ref) < tol
+
+
+def test_weight16_refresh_after_fused_adam(dev):
+    """FusedAdam re-casts the cached 16-bit weight copies (plain and transposed) in one batched launch, in place: the next
+    forward / backward must see exactly the copies a fresh cast of the updated weights gives."""
+    from conformer_amd import ops
+    from conformer_amd.optim import FusedAdam
+    g = torch.Generator().manual_seed(5)
+    ws = [torch.nn.Parameter(torch.randn(n, k, generator=g).to(dev)) for n, k in ((64, 32), (128, 96), (40, 72))]
+    conv = torch.nn.Parameter(torch.randn(48, 24, 1, generator=g).to(dev))            # pointwise-conv weight: cached through a 2-D view
+    opt = FusedAdam(ws + [conv], lr=1e-2)
+    prec = ops.PREC_BF16
+    before = [ops.weight16(w, prec) for w in ws] + [ops.weight16(w, prec, transposed=True) for w in ws[:2]]
+    before.append(ops.weight16(conv.reshape(48, -1), prec))
+    ptrs = [t.data_ptr() for t in before]
+    for p in ws + [conv]:
+        p.grad = torch.randn(p.shape, generator=g).to(dev)
+    opt.step()
+    after = [ops.weight16(w, prec) for w in ws] + [ops.weight16(w, prec, transposed=True) for w in ws[:2]]
+    after.append(ops.weight16(conv.reshape(48, -1), prec))
+    assert [t.data_ptr() for t in after] == ptrs                                      # refreshed in place, no new cast
+    for t, w in zip(after[:3], ws):
+        assert torch.equal(t, w.detach().to(torch.bfloat16))
+    for t, w in zip(after[3:5], ws[:2]):
+        assert torch.equal(t, w.detach().t().to(torch.bfloat16))
+    assert torch.equal(after[5], conv.detach().reshape(48, -1).to(torch.bfloat16))
