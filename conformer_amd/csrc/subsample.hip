@@ -6,6 +6,9 @@
 
 namespace {
 
+// A workgroup owns one (utterance, output frame t1) row of h1 -- F1 x C contiguous outputs -- and walks f1: no index
+// arithmetic per position.  (The first version flattened (b, t1, f1) into one 64-bit position index and paid two 64-bit
+// divisions per position and thread: it ran at 1.9 TB/s of stores, ALU-bound on the divisions, not write-bound.)
 template <typename TOUT>     // float, or the 16-bit matrix-pipe type when h1 only feeds the 16-bit conv2 GEMM (inference under autocast)
 __global__ __launch_bounds__(256) void conv1_relu_kernel(const float* __restrict__ x, const float* __restrict__ w1,
                                                          const float* __restrict__ b1, TOUT* __restrict__ h1,
@@ -20,18 +23,16 @@ __global__ __launch_bounds__(256) void conv1_relu_kernel(const float* __restrict
 #pragma unroll
         for (int j = 0; j < 9; ++j) w[i][j] = w1[(c4 * 4 + i) * 9 + j];
     const f32x4 bb = *reinterpret_cast<const f32x4*>(b1 + c4 * 4);
-    const int64_t npos = (int64_t)B * T1 * F1;
-    for (int64_t pos = (int64_t)blockIdx.x * ppb + pl; pos < npos; pos += (int64_t)gridDim.x * ppb) {
-        const int f1 = (int)(pos % F1);
-        const int64_t bt = pos / F1;
-        const int t1 = (int)(bt % T1);
-        const int64_t b = bt / T1;
-        const float* xp = x + (b * F + 2 * f1) * (int64_t)T + 2 * t1;
+    const int t1 = blockIdx.x, b = blockIdx.y;
+    const float* xb = x + (int64_t)b * F * T + 2 * t1;
+    TOUT* hrow = h1 + ((int64_t)b * T1 + t1) * F1 * C + c4 * 4;
+    for (int f1 = pl; f1 < F1; f1 += ppb) {
+        const float* xp = xb + (int64_t)(2 * f1) * T;
         float xv[9];
 #pragma unroll
         for (int kf = 0; kf < 3; ++kf)
 #pragma unroll
-            for (int kt = 0; kt < 3; ++kt) xv[kf * 3 + kt] = xp[(int64_t)kf * T + kt];
+            for (int kt = 0; kt < 3; ++kt) xv[kf * 3 + kt] = xp[kf * T + kt];
         f32x4 o = bb;
 #pragma unroll
         for (int j = 0; j < 9; ++j) {
@@ -41,8 +42,8 @@ __global__ __launch_bounds__(256) void conv1_relu_kernel(const float* __restrict
             o.w = fmaf(w[3][j], xv[j], o.w);
         }
         o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
-        if constexpr (sizeof(TOUT) == 4) *reinterpret_cast<f32x4*>(h1 + pos * C + c4 * 4) = o;
-        else *reinterpret_cast<typename Lowp<TOUT>::x4*>(h1 + pos * C + c4 * 4) = Lowp<TOUT>::cvt4(o);
+        if constexpr (sizeof(TOUT) == 4) *reinterpret_cast<f32x4*>(hrow + (int64_t)f1 * C) = o;
+        else *reinterpret_cast<typename Lowp<TOUT>::x4*>(hrow + (int64_t)f1 * C) = Lowp<TOUT>::cvt4(o);
     }
 }
 
@@ -119,20 +120,20 @@ __global__ __launch_bounds__(256) void conv1_bwd_kernel(const float* __restrict_
         acc[i][9] = 0.f;
     }
     const f32x4 bb = act ? *reinterpret_cast<const f32x4*>(b1 + c4 * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
-    const int64_t npos = (int64_t)B * T1 * F1;
+    // grid = (frame groups, utterances): a workgroup walks the frames t1 = blockIdx.x, blockIdx.x + gridDim.x, ... of one
+    // utterance and all f1 of each -- no per-position index arithmetic (the flattened 64-bit position index of the first
+    // version cost two 64-bit divisions per position and thread)
+    const int b = blockIdx.y;
     if (act)
-        for (int64_t pos = (int64_t)blockIdx.x * ppb + pl; pos < npos; pos += (int64_t)gridDim.x * ppb) {
-            const int f1 = (int)(pos % F1);
-            const int64_t bt = pos / F1;
-            const int t1 = (int)(bt % T1);
-            const int64_t b = bt / T1;
-            const float* xp = x + (b * F + 2 * f1) * (int64_t)T + 2 * t1;
+        for (int t1 = blockIdx.x; t1 < T1; t1 += gridDim.x)
+        for (int f1 = pl; f1 < F1; f1 += ppb) {
+            const float* xp = x + ((int64_t)b * F + 2 * f1) * T + 2 * t1;
             float xv[9];
 #pragma unroll
             for (int kf = 0; kf < 3; ++kf)
 #pragma unroll
-                for (int kt = 0; kt < 3; ++kt) xv[kf * 3 + kt] = xp[(int64_t)kf * T + kt];
-            const f32x4 d = *reinterpret_cast<const f32x4*>(dh1 + pos * C + c4 * 4);
+                for (int kt = 0; kt < 3; ++kt) xv[kf * 3 + kt] = xp[kf * T + kt];
+            const f32x4 d = *reinterpret_cast<const f32x4*>(dh1 + (((int64_t)b * T1 + t1) * F1 + f1) * C + c4 * 4);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 float pre = bb[i];
@@ -184,11 +185,11 @@ extern "C" int cfm_subsample_conv1_bwd_f32(const float* x, const float* w1, cons
     CFM_REQUIRE(C <= 1024, CFM_ERR_UNSUPPORTED);
     const int F1 = (F - 1) / 2, T1 = (T - 1) / 2;
     const int ppb = 256 / (C / 4);
-    const int64_t npos = (int64_t)B * T1 * F1;
-    int64_t blocks = (npos + ppb - 1) / ppb;
-    if (blocks > 512) blocks = 512;                     // few blocks: 40 atomics per thread at the end
-    hipLaunchKernelGGL(conv1_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), x, w1, b1,
-                       dh1, dw1, db1, B, F, T, C, F1, T1, ppb);
+    CFM_REQUIRE(B <= 65535, CFM_ERR_UNSUPPORTED);
+    int groups = (768 + B - 1) / B;                     // ~768 workgroups in all: 40 atomics per thread at the end
+    groups = groups < 1 ? 1 : (groups > T1 ? T1 : groups);
+    hipLaunchKernelGGL(conv1_bwd_kernel, dim3((unsigned)groups, (unsigned)B), dim3(256), 0, static_cast<hipStream_t>(stream), x, w1,
+                       b1, dh1, dw1, db1, B, F, T, C, F1, T1, ppb);
     return cfm_launch_status();
 }
 
@@ -200,10 +201,8 @@ extern "C" int cfm_subsample_conv1_relu_f32(const float* x, const float* w1, con
     CFM_REQUIRE(CFM_ALIGNED16(h1) && CFM_ALIGNED16(b1), CFM_ERR_ALIGN);
     const int F1 = (F - 1) / 2, T1 = (T - 1) / 2;
     const int ppb = 256 / (C / 4);
-    const int64_t npos = (int64_t)B * T1 * F1;
-    int64_t blocks = (npos + ppb - 1) / ppb;
-    if (blocks > 256 * 32) blocks = 256 * 32;
-    hipLaunchKernelGGL(conv1_relu_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), x, w1,
+    CFM_REQUIRE(B <= 65535, CFM_ERR_UNSUPPORTED);
+    hipLaunchKernelGGL(conv1_relu_kernel<float>, dim3((unsigned)T1, (unsigned)B), dim3(256), 0, static_cast<hipStream_t>(stream), x, w1,
                        b1, h1, B, F, T, C, F1, T1, ppb);
     return cfm_launch_status();
 }
@@ -217,15 +216,14 @@ extern "C" int cfm_subsample_conv1_relu_out16_f32(int prec, const float* x, cons
     const int F1 = (F - 1) / 2, T1 = (T - 1) / 2;
     const int ppb = 256 / (C / 4) > 0 ? 256 / (C / 4) : 0;
     CFM_REQUIRE(ppb > 0, CFM_ERR_UNSUPPORTED);
-    const int64_t npos = (int64_t)B * T1 * F1;
-    int64_t blocks = (npos + ppb - 1) / ppb;
-    if (blocks > 256 * 32) blocks = 256 * 32;
+    CFM_REQUIRE(B <= 65535, CFM_ERR_UNSUPPORTED);
+    const dim3 grid((unsigned)T1, (unsigned)B);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (prec == CFM_PREC_BF16)
-        hipLaunchKernelGGL(conv1_relu_kernel<__bf16>, dim3((unsigned)blocks), dim3(256), 0, s, x, w1, b1, static_cast<__bf16*>(h1),
+        hipLaunchKernelGGL(conv1_relu_kernel<__bf16>, grid, dim3(256), 0, s, x, w1, b1, static_cast<__bf16*>(h1),
                            B, F, T, C, F1, T1, ppb);
     else if (prec == CFM_PREC_FP16)
-        hipLaunchKernelGGL(conv1_relu_kernel<_Float16>, dim3((unsigned)blocks), dim3(256), 0, s, x, w1, b1,
+        hipLaunchKernelGGL(conv1_relu_kernel<_Float16>, grid, dim3(256), 0, s, x, w1, b1,
                            static_cast<_Float16*>(h1), B, F, T, C, F1, T1, ppb);
     else return CFM_ERR_UNSUPPORTED;
     return cfm_launch_status();
