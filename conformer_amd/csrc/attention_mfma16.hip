@@ -11,7 +11,9 @@
 //     e = 0..7, for step s.  V is staged as loaded ([key][dim], 16-bit) and its V^T fragment is fetched with two
 //     ds_read_b64_tr_b16 (gfx950's transposing LDS read) over key rows 16s+4hf+{0..3} and +8 -- exactly that key order,
 //     so P goes from the softmax registers to the MFMA without any shuffle and V is never transposed by hand;
-//   * (Q+u), (Q+v) live in 16 VGPRs each (64 in the fp32 kernel): 48 KB LDS + ~130 VGPRs -> 3 workgroups per CU.
+//   * (Q+u), (Q+v) live in 16 VGPRs each (64 in the fp32 kernel);
+//   * round 2, as in the fp32 kernel: one band product per key tile (the skewed values of the other band tile are carried in
+//     registers) and double-buffered K / V tiles: ONE workgroup barrier per key tile instead of two (60 KB LDS, 2 workgroups per CU).
 #include "cfm_common.h"
 #include <math.h>
 
@@ -33,11 +35,11 @@ template <typename T16>
 __global__ __launch_bounds__(256, 2) void relpos_attn_fwd_mfma16_kernel(const Attn16Args a) {
     using x8 = typename Lowp<T16>::x8;
     using x4 = typename Lowp<T16>::x4;
-    __shared__ __attribute__((aligned(16))) T16 smem16[32 * KROWH + 32 * VROWH + RINGH * KROWH];
+    __shared__ __attribute__((aligned(16))) T16 smem16[2 * 32 * KROWH + 2 * 32 * VROWH + RINGH * KROWH];
     __shared__ __attribute__((aligned(16))) float gsm[4 * 32 * 32];
-    T16* Ks = smem16;                            // [32 keys][KROWH]
-    T16* Vt = Ks + 32 * KROWH;                   // [32 keys][VROWH]: stored as loaded, read transposed (ds_read_b64_tr_b16)
-    T16* Pr = Vt + 32 * VROWH;                   // [RINGH][KROWH]
+    T16* Ksb = smem16;                           // [2][32 keys][KROWH]     double-buffered: one workgroup barrier per key tile
+    T16* Vtb = Ksb + 2 * 32 * KROWH;             // [2][32 keys][VROWH]: stored as loaded, read transposed (ds_read_b64_tr_b16)
+    T16* Pr = Vtb + 2 * 32 * VROWH;              // [RINGH][KROWH]
     float* gs = gsm + (threadIdx.x >> 6) * 1024; // per-wave skew tile [32][32]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -81,9 +83,11 @@ __global__ __launch_bounds__(256, 2) void relpos_attn_fwd_mfma16_kernel(const At
             pp[p] = sok ? *reinterpret_cast<const f32x4*>(pbase + (int64_t)j * a.ldp + sch * 4) : z;
         }
     };
-    auto commit = [&](int kt) {
-        const int k0 = kt * 32;
+    auto commit = [&](int kt) {                                    // tile kt -> buffer (kt & 1); its 32 new ring rows replace rows
+        const int k0 = kt * 32;                                    // that only band tile 1 of the PREVIOUS key tile could still need
         const int jnew = T - 1 - q0 + k0;
+        T16* Ks = Ksb + (kt & 1) * 32 * KROWH;
+        T16* Vt = Vtb + (kt & 1) * 32 * VROWH;
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
             const int r = srow + 16 * p;
@@ -141,37 +145,52 @@ __global__ __launch_bounds__(256, 2) void relpos_attn_fwd_mfma16_kernel(const At
     float mrow = -INFINITY, lrow = 0.f;
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
+    // Positional band: one 32-row band tile per key tile (band tile 1 of key tile kt+1 = band tile 0 of key tile kt, and the
+    // 16 unconditional skew reads of band tile 0 already fetch what the next key tile needs from its band tile 1: carried in
+    // `skp`, see attention_f32.hip).
+    auto band = [&](int jbase, int mt) {
+        const int slot = (jbase - (32 * mt + li) + ring_bias) % RINGH;
+        const T16* prow = Pr + slot * KROWH + 8 * hf;
+        f32x16 ga = zero16;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) ga = Lowp<T16>::mfma(*reinterpret_cast<const x8*>(prow + 16 * s), qv[s], ga);
+        return ga;
+    };
+    auto spill_band = [&](const f32x16& ga) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) gs[((r & 3) + 8 * (r >> 2) + 4 * hf) * 32 + li] = ga[r];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    auto skew_reads = [&](float (&dst)[16]) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int jj = li - ((r & 3) + 8 * (r >> 2) + 4 * hf) + 31;
+            dst[r] = gs[(jj & 31) * 32 + li];
+        }
+    };
+    float skp[16];
+    if (active) {                                                   // first key tile: its band tile 1 explicitly
+        spill_band(band(T - 1 - i0 + 31, 1));
+        skew_reads(skp);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();                                                // every wave has read its band-1 rows: commit(1) may replace them
+
     for (int kt = 0; kt < ntiles; ++kt) {
         const int k0 = kt * 32;
+        const T16* Ks = Ksb + (kt & 1) * 32 * KROWH;
+        const T16* Vt = Vtb + (kt & 1) * 32 * VROWH;
+        // stage the next key tile into the other buffer (its readers passed the barrier that ended tile kt-1), request the one after
+        if (kt + 1 < ntiles) {
+            commit(kt + 1);
+            if (kt + 2 < ntiles) prefetch(kt + 2);
+        }
         if (active) {
             const int jbase = T - 1 - i0 + k0 + 31;
-            auto band = [&](int mt) {
-                const int slot = (jbase - (32 * mt + li) + ring_bias) % RINGH;
-                const T16* prow = Pr + slot * KROWH + 8 * hf;
-                f32x16 ga = zero16;
-#pragma unroll
-                for (int s = 0; s < 4; ++s)
-                    ga = Lowp<T16>::mfma(*reinterpret_cast<const x8*>(prow + 16 * s), qv[s], ga);
-                return ga;
-            };
-            auto spill_band = [&](const f32x16& ga) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) gs[((r & 3) + 8 * (r >> 2) + 4 * hf) * 32 + li] = ga[r];
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            };
-            float sk[16];
-            spill_band(band(0));
-            const f32x16 g1 = band(1);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int jj = li - ((r & 3) + 8 * (r >> 2) + 4 * hf) + 31;
-                sk[r] = gs[(jj & 31) * 32 + li];
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            spill_band(g1);
+            spill_band(band(jbase, 0));
             f32x16 sc = zero16;
             {
                 const T16* krow = Ks + li * KROWH + 8 * hf;
@@ -179,14 +198,16 @@ __global__ __launch_bounds__(256, 2) void relpos_attn_fwd_mfma16_kernel(const At
                 for (int s = 0; s < 4; ++s)
                     sc = Lowp<T16>::mfma(*reinterpret_cast<const x8*>(krow + 16 * s), qu[s], sc);
             }
+            float skn[16], sk[16];
+            skew_reads(skn);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int jj = li - ((r & 3) + 8 * (r >> 2) + 4 * hf) + 31;
-                const float g1v = gs[(jj & 31) * 32 + li];
-                sk[r] = (jj >> 5) ? g1v : sk[r];
+                sk[r] = (jj >> 5) ? skp[r] : skn[r];
+                skp[r] = skn[r];
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
             // ---- scale + mask, online softmax
             float p[16];
             float tmax = -INFINITY;
@@ -240,12 +261,7 @@ __global__ __launch_bounds__(256, 2) void relpos_attn_fwd_mfma16_kernel(const At
                 }
             }
         }
-        if (kt + 1 < ntiles) {
-            __syncthreads();
-            commit(kt + 1);
-            __syncthreads();
-            if (kt + 2 < ntiles) prefetch(kt + 2);
-        }
+        if (kt + 1 < ntiles) __syncthreads();                       // one barrier per key tile
     }
 
     if (active && i0 + li < T) {
