@@ -22,7 +22,10 @@ namespace {
 // The K-loop is bound by the operand stream L2 -> L1 -> LDS: at 128x128 two co-resident workgroups pull 64 KB per ~1 us K-tile
 // step into a CU (16 TB/s chip-wide, about half of the L2's peak) for 0.23 us of MFMA work each -- deeper prefetch and
 // fragment pipelining changed nothing -- so the big tiles exist to halve the bytes per MFMA.
-template <typename T16, int BM, int BN, int EPI, bool CONV, bool W16, bool A16 = false, int WM = 2>
+// CONV: 0 plain rows; 1 the stem's 3x3 / stride-2 im2col gather (forward conv2); 2 a parity class of its transposed conv (the
+// input gradient of conv2): row = class position (b, a, c), K-tile = a tap (dt, df) of dz2 -- rows whose tap falls outside dz2
+// are zero (per-row validity, re-derived when the tap changes), output rows are scattered to the class's dh1 positions.
+template <typename T16, int BM, int BN, int EPI, int CONV, bool W16, bool A16 = false, int WM = 2>
 __global__ __launch_bounds__(WM * 128, 2) void gemm_mfma16_kernel(const GemmArgs g) {
     static_assert(!A16 || W16, "16-bit A operand comes together with 16-bit weights");
     using x8 = typename Lowp<T16>::x8;
@@ -65,6 +68,18 @@ __global__ __launch_bounds__(WM * 128, 2) void gemm_mfma16_kernel(const GemmArgs
 #pragma unroll
         for (int p = 0; p < NA; ++p) a_ptr[p] = a_row_ptr<CONV>(g, m0 + srow + RP4 * p);
     }
+    static_assert(CONV != 2 || !A16, "the class gather stages fp32 rows");
+    int cls_a[CONV == 2 ? NA : 1], cls_c[CONV == 2 ? NA : 1];         // class coordinates of the rows this thread stages
+    if constexpr (CONV == 2) {
+#pragma unroll
+        for (int p = 0; p < NA; ++p) {
+            const int64_t m = min(m0 + srow + RP4 * p, g.M - 1);
+            const int per = g.pA * g.pC;
+            const int r = (int)(m - (m / per) * per);
+            cls_a[p] = r / g.pC;
+            cls_c[p] = r - cls_a[p] * g.pC;
+        }
+    }
     if (W16) {
 #pragma unroll
         for (int p = 0; p < NBH; ++p)
@@ -82,6 +97,7 @@ __global__ __launch_bounds__(WM * 128, 2) void gemm_mfma16_kernel(const GemmArgs
         f32x4 ra[A16 ? 1 : NA], rb[W16 ? 1 : NB];
         x8 rah[A16 ? NAH : 1], rbh[W16 ? NBH : 1];
         bool kvalid, kvalid_h;
+        unsigned amask;                                       // CONV == 2: bit p = row p of this thread has the K-tile's tap inside dz2
     };
     constexpr bool DEEP = WM == 2;                            // 8-wave tiles: one set (the second one spills at 256x256)
     Stage st0, st1;
@@ -93,6 +109,17 @@ __global__ __launch_bounds__(WM * 128, 2) void gemm_mfma16_kernel(const GemmArgs
             const int64_t ahoff = a_k_offset<CONV>(g, khc - hch * 8) + hch * 8;
 #pragma unroll
             for (int p = 0; p < NAH; ++p) t.rah[p] = *reinterpret_cast<const x8*>(ah_ptr[p] + ahoff);
+        } else if constexpr (CONV == 2) {
+            const int tap = (kc - sch * 4) / g.cC;                    // (uniform: a K-tile lies inside one tap, C % 64 == 0)
+            const int dt = g.tap_dt[tap], df = g.tap_df[tap];
+            const int64_t aoff = a_k_offset<CONV>(g, kc - sch * 4) + sch * 4;
+            t.amask = 0;
+#pragma unroll
+            for (int p = 0; p < NA; ++p) {                            // unconditional load: invalid rows read the tensor's first row
+                const bool ok = (unsigned)(cls_a[p] + dt) < (unsigned)g.cT2 && (unsigned)(cls_c[p] + df) < (unsigned)g.cF2;
+                t.ra[p] = *reinterpret_cast<const f32x4*>(ok ? a_ptr[p] + aoff : g.A + sch * 4);
+                t.amask |= ok ? (1u << p) : 0u;
+            }
         } else {
             const int64_t aoff = a_k_offset<CONV>(g, kc - sch * 4) + sch * 4;
 #pragma unroll
@@ -118,7 +145,8 @@ __global__ __launch_bounds__(WM * 128, 2) void gemm_mfma16_kernel(const GemmArgs
         } else {
 #pragma unroll
             for (int p = 0; p < NA; ++p)
-                *reinterpret_cast<x4*>(As + (buf * BM + srow + RP4 * p) * ROWB + sch * 4) = Lowp<T16>::cvt4(t.kvalid ? t.ra[p] : z4);
+                *reinterpret_cast<x4*>(As + (buf * BM + srow + RP4 * p) * ROWB + sch * 4) =
+                    Lowp<T16>::cvt4((t.kvalid && (CONV != 2 || ((t.amask >> p) & 1u))) ? t.ra[p] : z4);
         }
         if (W16) {
 #pragma unroll
@@ -213,14 +241,17 @@ __global__ __launch_bounds__(WM * 128, 2) void gemm_mfma16_kernel(const GemmArgs
     }
 }
 
-template <typename T16, int BM, int BN, int EPI, bool CONV>
+template <typename T16, int BM, int BN, int EPI, int CONV>
 int launch_cfg(GemmArgs g, int src16, hipStream_t s) {          // src16: 0 = fp32 operands, 1 = 16-bit W, 2 = 16-bit A and W
     const int ncols = EPI == EPI_GLU ? g.n_out : g.N;
     const int bn = EPI == EPI_GLU ? BN / 2 : BN;
     g.tiles_m = (unsigned)((g.M + BM - 1) / BM);
     g.tiles_n = (unsigned)((ncols + bn - 1) / bn);
     const dim3 grid(g.tiles_m * g.tiles_n);
-    if (src16 == 2) hipLaunchKernelGGL((gemm_mfma16_kernel<T16, BM, BN, EPI, CONV, true, true>), grid, dim3(256), 0, s, g);
+    if constexpr (CONV == 2) {
+        if (src16 == 2) return CFM_ERR_UNSUPPORTED;
+    }
+    if (src16 == 2) hipLaunchKernelGGL((gemm_mfma16_kernel<T16, BM, BN, EPI, (CONV == 2 ? 0 : CONV), true, true>), grid, dim3(256), 0, s, g);
     else if (src16 == 1) hipLaunchKernelGGL((gemm_mfma16_kernel<T16, BM, BN, EPI, CONV, true>), grid, dim3(256), 0, s, g);
     else if (src16 == 0) hipLaunchKernelGGL((gemm_mfma16_kernel<T16, BM, BN, EPI, CONV, false>), grid, dim3(256), 0, s, g);
     else return CFM_ERR_UNSUPPORTED;
@@ -233,17 +264,21 @@ inline bool gemm_epilogue_vec_ok_host(const GemmArgs& g, int epi) {      // the 
            (epi != EPI_RESID || (reinterpret_cast<uintptr_t>(g.R) & 15) == 0);
 }
 
-template <typename T16, int BM, int BN, int EPI>
-int launch_big(GemmArgs g, int src16, hipStream_t s) {          // 512-thread workgroups, 16-bit weights, no conv gather, no GLU
+template <typename T16, int BM, int BN, int EPI, int CONV = 0>
+int launch_big(GemmArgs g, int src16, hipStream_t s) {          // 512-thread workgroups, 16-bit weights, no im2col gather, no GLU
     g.tiles_m = (unsigned)((g.M + BM - 1) / BM);
     g.tiles_n = (unsigned)((g.N + BN - 1) / BN);
     const dim3 grid(g.tiles_m * g.tiles_n);
-    if (src16 == 2) hipLaunchKernelGGL((gemm_mfma16_kernel<T16, BM, BN, EPI, false, true, true, 4>), grid, dim3(512), 0, s, g);
-    else hipLaunchKernelGGL((gemm_mfma16_kernel<T16, BM, BN, EPI, false, true, false, 4>), grid, dim3(512), 0, s, g);
+    if constexpr (CONV == 2) {
+        hipLaunchKernelGGL((gemm_mfma16_kernel<T16, BM, BN, EPI, 2, true, false, 4>), grid, dim3(512), 0, s, g);
+    } else {
+        if (src16 == 2) hipLaunchKernelGGL((gemm_mfma16_kernel<T16, BM, BN, EPI, 0, true, true, 4>), grid, dim3(512), 0, s, g);
+        else hipLaunchKernelGGL((gemm_mfma16_kernel<T16, BM, BN, EPI, 0, true, false, 4>), grid, dim3(512), 0, s, g);
+    }
     return cfm_launch_status();
 }
 
-template <typename T16, int EPI, bool CONV>
+template <typename T16, int EPI, int CONV>
 int launch_t(const GemmArgs& g, int src16, hipStream_t s) {
     const int ncols = EPI == EPI_GLU ? g.n_out : g.N;
     const int bn = EPI == EPI_GLU ? 64 : 128;
@@ -251,7 +286,11 @@ int launch_t(const GemmArgs& g, int src16, hipStream_t s) {
     if constexpr (EPI == EPI_GLU) {
         return t128 >= 512 ? launch_cfg<T16, 128, 128, EPI, CONV>(g, src16, s) : launch_cfg<T16, 64, 128, EPI, CONV>(g, src16, s);
     } else {
-        if constexpr (!CONV) {
+        if constexpr (CONV == 2) {                                // transposed-conv classes: hundreds of thousands of rows, N = C
+            if (src16 == 1 && gemm_epilogue_vec_ok_host(g, EPI) && (g.N % 256) == 0 && g.occ_cap != 1)
+                return launch_big<T16, 256, 256, EPI, 2>(g, src16, s);
+        }
+        if constexpr (CONV == 0) {
             // big tiles (one 8-wave workgroup per CU) once they fill the chip about once over: half / three quarters of the
             // operand bytes per MFMA of the 128x128 tile
             const int force = g.occ_cap;                          // tuning hook: 1 = 128x128 family, 2 = 256x128, 3 = 256x256
@@ -308,7 +347,7 @@ __global__ __launch_bounds__(256) void cast16_multi_kernel(const CastBatch b) {
     }
 }
 
-template <int EPI, bool CONV>
+template <int EPI, int CONV>
 int launch(int prec, const GemmArgs& g, int src16, hipStream_t s) {
     if (prec == CFM_PREC_BF16) return launch_t<__bf16, EPI, CONV>(g, src16, s);
     if (prec == CFM_PREC_FP16) return launch_t<_Float16, EPI, CONV>(g, src16, s);
@@ -360,22 +399,22 @@ extern "C" int cfm_gemm_mfma16_f32(int prec, int epi, const void* A, int a_is_16
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (epi == EPI_GLU) {
         g.n_out = N; g.N = 2 * N;
-        return launch<EPI_GLU, false>(prec, g, src16, s);
+        return launch<EPI_GLU, 0>(prec, g, src16, s);
     }
     g.N = N;
     switch (epi) {
-        case EPI_BIAS: return launch<EPI_BIAS, false>(prec, g, src16, s);
-        case EPI_SWISH: return launch<EPI_SWISH, false>(prec, g, src16, s);
-        case EPI_RELU: return launch<EPI_RELU, false>(prec, g, src16, s);
+        case EPI_BIAS: return launch<EPI_BIAS, 0>(prec, g, src16, s);
+        case EPI_SWISH: return launch<EPI_SWISH, 0>(prec, g, src16, s);
+        case EPI_RELU: return launch<EPI_RELU, 0>(prec, g, src16, s);
         case EPI_RESID:
             CFM_REQUIRE(R_or_null != nullptr, CFM_ERR_NULL);
             CFM_REQUIRE(ldr >= N, CFM_ERR_BAD_SHAPE);
-            return launch<EPI_RESID, false>(prec, g, src16, s);
+            return launch<EPI_RESID, 0>(prec, g, src16, s);
         case EPI_DSWISH:                                        // backward: C = alpha * (A.W^T) * swish'(Z); Z is READ, ldr = its leading dim
             CFM_REQUIRE(Z_or_null != nullptr, CFM_ERR_NULL);
             CFM_REQUIRE((N & 7) == 0 && (ldc & 7) == 0 && (ldr & 7) == 0 && ldr >= N && CFM_ALIGNED16(C) && CFM_ALIGNED16(Z_or_null),
                         CFM_ERR_UNSUPPORTED);
-            return launch<EPI_DSWISH, false>(prec, g, src16, s);
+            return launch<EPI_DSWISH, 0>(prec, g, src16, s);
         default: return CFM_ERR_UNSUPPORTED;
     }
 }
@@ -395,7 +434,7 @@ extern "C" int cfm_subsample_conv2_relu_mfma16_f32(int prec, const void* h1, int
     g.A = static_cast<const float*>(h1); g.W = static_cast<const float*>(w2p); g.bias = b2; g.C = static_cast<float*>(h2);
     g.c_prec = h2_is_16bit ? prec : 0;
     g.M = (int64_t)B * g.cT2 * g.cF2; g.N = C; g.K = 9 * C; g.lda = 0; g.ldc = C; g.alpha = 1.f;
-    return launch<EPI_RELU, true>(prec, g, h1_is_16bit ? 2 : (w_is_16bit ? 1 : 0), static_cast<hipStream_t>(stream));
+    return launch<EPI_RELU, 1>(prec, g, h1_is_16bit ? 2 : (w_is_16bit ? 1 : 0), static_cast<hipStream_t>(stream));
 }
 
 // dst (16-bit, prec) <- RNE(src) for n fp32 values (n % 4 == 0): the per-optimizer-step cast of the master weights that
@@ -438,4 +477,37 @@ extern "C" int cfm_cast16_multi_f32(int prec, const cfm_cast_item* items, int co
         else hipLaunchKernelGGL(cast16_multi_kernel<_Float16>, grid, dim3(256), 0, s, b);
     }
     return cfm_launch_status();
+}
+
+// Input gradient of the stem's conv2 (3x3, stride 2) on the forward kernel: dh1 (B,T1,F1,C) = conv_transpose(dz2 (B,T2,F2,C), w2)
+// as four parity-class implicit GEMMs (t1 = 2a+pt, f1 = 2c+pf; the class's taps (kt,kf) = (pt,pf) mod 2), CONV == 2.
+// w2c16: the transposed-pack of w2 (cfm_pack_conv2_weight_t_f32) cast to `prec` (cfm_cast16_f32); zero_bias: C zeros.
+// Every dh1 element is written exactly once.  C % 64 == 0.
+extern "C" int cfm_subsample_conv2_bwd_input_fwdkernel_mfma16_f32(int prec, const float* dz2, const void* w2c16,
+                                                                  const float* zero_bias, float* dh1, int B, int F1, int T1, int C,
+                                                                  cfm_stream_t stream) {
+    CFM_REQUIRE(dz2 && w2c16 && zero_bias && dh1, CFM_ERR_NULL);
+    CFM_REQUIRE(B > 0 && F1 >= 3 && T1 >= 3 && C > 0, CFM_ERR_BAD_SHAPE);
+    CFM_REQUIRE(C % 64 == 0, CFM_ERR_UNSUPPORTED);
+    CFM_REQUIRE(CFM_ALIGNED16(dz2) && CFM_ALIGNED16(w2c16) && CFM_ALIGNED16(dh1) && CFM_ALIGNED16(zero_bias), CFM_ERR_ALIGN);
+    const int T2 = (T1 - 1) / 2, F2 = (F1 - 1) / 2;
+    const int64_t woff[4] = {0, 4, 6, 8};                 // class q = 2*pt + pf: taps before it in the transposed pack
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    for (int pt = 0; pt < 2; ++pt)
+        for (int pf = 0; pf < 2; ++pf) {
+            GemmArgs g{};
+            g.cT1 = T1; g.cF1 = F1; g.cT2 = T2; g.cF2 = F2; g.cC = C; g.pt = pt; g.pf = pf;
+            g.pA = (T1 - pt + 1) / 2; g.pC = (F1 - pf + 1) / 2;
+            if (g.pA <= 0 || g.pC <= 0) continue;
+            int nt = 0;                                   // taps (kt,kf) with kt = pt (mod 2), kf = pf (mod 2); t2 = a - (kt-pt)/2
+            for (int kt = pt; kt < 3; kt += 2)
+                for (int kf = pf; kf < 3; kf += 2) { g.tap_dt[nt] = -(kt - pt) / 2; g.tap_df[nt] = -(kf - pf) / 2; ++nt; }
+            const int q = 2 * pt + pf;
+            g.A = dz2; g.W = reinterpret_cast<const float*>(static_cast<const char*>(w2c16) + woff[q] * C * C * 2);
+            g.bias = zero_bias; g.C = dh1; g.c_prec = 0;
+            g.M = (int64_t)B * g.pA * g.pC; g.N = C; g.K = nt * C; g.lda = 0; g.ldc = C; g.alpha = 1.f;
+            const int st = launch<EPI_BIAS, 2>(prec, g, 1, s);
+            if (st) return st;
+        }
+    return CFM_OK;
 }

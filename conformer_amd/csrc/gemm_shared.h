@@ -17,6 +17,9 @@ struct GemmArgs {
     int64_t M; int N; int K; int64_t lda, ldr, ldc; float alpha;
     int n_out;                      // GLU: output columns (N = 2*n_out)
     int cT2, cF2, cT1, cF1, cC;     // conv mode geometry
+    // CONV == 2 (16-bit kernel): transposed-conv parity class of the stem's conv2 backward (see gemm_bwd_args.h, GATHER 2): row
+    // m = (b, a, c) of the class grid pA x pC, K-tile = tap (dt, df) of dz2 (B,T2,F2,C); output row = dh1 position (b, 2a+pt, 2c+pf)
+    int pA, pC, pt, pf; int tap_dt[4], tap_df[4];
     unsigned tiles_m, tiles_n;
     int occ_cap;                    // 0 = natural; else blocks/CU cap enforced through a dynamic-LDS pad
     int c_prec;                     // 0: C is fp32; CFM_PREC_BF16 / CFM_PREC_FP16: C is stored in that 16-bit type (ldc in elements)
@@ -24,10 +27,16 @@ struct GemmArgs {
 };
 
 // ---- shared pieces --------------------------------------------------------------------------------------------
-template <bool CONV>
+template <int CONV>
 __device__ __forceinline__ const float* a_row_ptr(const GemmArgs& g, int64_t m) {
     if (m >= g.M) m = g.M - 1;                           // clamp: the row is loaded but never stored
-    if (CONV) {
+    if (CONV == 2) {                                     // class row (b, a, c): formal base of dz2[b][a][c][:] (taps add (dt, df))
+        const int per = g.pA * g.pC;
+        const int b = (int)(m / per), r = (int)(m - (int64_t)b * per);
+        const int a = r / g.pC, c = r - a * g.pC;
+        return g.A + (((int64_t)b * g.cT2 + a) * g.cF2 + c) * (int64_t)g.cC;
+    }
+    if (CONV == 1) {
         const int f2 = (int)(m % g.cF2);
         const int64_t bt = m / g.cF2;
         const int t2 = (int)(bt % g.cT2);
@@ -57,9 +66,13 @@ __device__ __forceinline__ const float* w_row_ptr(const GemmArgs& g, int n0, int
     return g.W + (int64_t)w_row_index<EPI, BN>(g, n0, r) * g.K;
 }
 
-template <bool CONV>
+template <int CONV>
 __device__ __forceinline__ int64_t a_k_offset(const GemmArgs& g, int k) {   // k = first K index of an aligned slab
-    if (CONV) {
+    if (CONV == 2) {                                     // k = (tap, co): the tap's (dt, df) neighbour of the class row
+        const int tap = k / g.cC, co = k - tap * g.cC;
+        return ((int64_t)g.tap_dt[tap] * g.cF2 + g.tap_df[tap]) * g.cC + co;
+    }
+    if (CONV == 1) {
         const int tap = k / g.cC, ci = k - tap * g.cC;
         const int kf = tap / 3, ktp = tap - 3 * kf;
         return ((int64_t)ktp * g.cF1 + kf) * g.cC + ci;
@@ -73,9 +86,11 @@ __device__ __forceinline__ int64_t a_k_offset(const GemmArgs& g, int k) {   // k
 //
 // gemm_epilogue_at: bias / activation / dropout / residual / stores for FOUR consecutive columns of one output row
 // (av = the accumulator values, gv = the matching gate values of a GLU tile).
+// `crow`: the row of C the result is stored to (differs from `row` only for the scattered rows of CONV == 2)
 template <int EPI>
 __device__ __forceinline__ void gemm_epilogue_at(const GemmArgs& g, const f32x4 av, const f32x4 gv, int64_t row, int col,
-                                                 bool vec_ok) {
+                                                 bool vec_ok, int64_t crow = -1) {
+    if (crow < 0) crow = row;
     const int ncols = EPI == EPI_GLU ? g.n_out : g.N;
     if (row >= g.M || col >= ncols) return;
     if constexpr (EPI == EPI_DSWISH) {
@@ -144,12 +159,12 @@ __device__ __forceinline__ void gemm_epilogue_at(const GemmArgs& g, const f32x4 
             }
             if (EPI == EPI_RELU) v[e] = fmaxf(v[e], 0.f);
         }
-        if (g.c_prec == 0) *reinterpret_cast<f32x4*>(g.C + row * g.ldc + col) = f32x4{v[0], v[1], v[2], v[3]};
+        if (g.c_prec == 0) *reinterpret_cast<f32x4*>(g.C + crow * g.ldc + col) = f32x4{v[0], v[1], v[2], v[3]};
         else if (g.c_prec == CFM_PREC_BF16)
-            *reinterpret_cast<Lowp<__bf16>::x4*>(reinterpret_cast<__bf16*>(g.C) + row * g.ldc + col) =
+            *reinterpret_cast<Lowp<__bf16>::x4*>(reinterpret_cast<__bf16*>(g.C) + crow * g.ldc + col) =
                 Lowp<__bf16>::cvt4(f32x4{v[0], v[1], v[2], v[3]});
         else
-            *reinterpret_cast<Lowp<_Float16>::x4*>(reinterpret_cast<_Float16*>(g.C) + row * g.ldc + col) =
+            *reinterpret_cast<Lowp<_Float16>::x4*>(reinterpret_cast<_Float16*>(g.C) + crow * g.ldc + col) =
                 Lowp<_Float16>::cvt4(f32x4{v[0], v[1], v[2], v[3]});
     } else {                                                       // odd leading dims / widths: scalar path
 #pragma unroll
@@ -233,7 +248,15 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmArgs& g, const f32x
         for (int it = 0; it < 32 / RPI; ++it) {
             const int rl = it * RPI + rsub;
             const f32x4 v = *reinterpret_cast<const f32x4*>(scratch + rl * P + c4);
-            gemm_epilogue_at<EPI>(g, v, v, m0 + wr * (BM / WM) + mt * 32 + rl, col, true);
+            const int64_t row = m0 + wr * (BM / WM) + mt * 32 + rl;
+            int64_t crow = row;
+            if (g.pA > 0 && row < g.M) {                                // CONV == 2: class row (b, a, c) -> dh1 position (b, 2a+pt, 2c+pf)
+                const int per = g.pA * g.pC;
+                const int b = (int)(row / per), r = (int)(row - (int64_t)b * per);
+                const int a = r / g.pC, c = r - a * g.pC;
+                crow = ((int64_t)b * g.cT1 + 2 * a + g.pt) * g.cF1 + 2 * c + g.pf;
+            }
+            gemm_epilogue_at<EPI>(g, v, v, row, col, true, crow);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();

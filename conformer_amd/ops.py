@@ -867,8 +867,13 @@ def subsample_stem_bwd(x, w1, b1, w2, h1, h2, dh2):
     _lib.check(lib.cfm_pack_conv2_weight_t_f32(w2.data_ptr(), w2c.data_ptr(), C, _stream()), "cfm_pack_conv2_weight_t_f32")
     dh1 = torch.empty_like(h1)
     if prec:
-        _lib.check(lib.cfm_subsample_conv2_bwd_input_mfma16_f32(prec, dz2.data_ptr(), w2c.data_ptr(), dh1.data_ptr(), B, F1,
-                                                                T1, C, _stream()), "cfm_subsample_conv2_bwd_input_mfma16_f32")
+        # transposed conv as four parity-class implicit GEMMs on the FORWARD 16-bit kernel (two-tile prefetch, row-major epilogue)
+        w2c16 = torch.empty(9 * C * C, device=x.device, dtype=_DT16[prec])
+        _lib.check(lib.cfm_cast16_f32(prec, w2c.data_ptr(), w2c16.data_ptr(), w2c.numel(), _stream()), "cfm_cast16_f32")
+        _lib.check(lib.cfm_subsample_conv2_bwd_input_fwdkernel_mfma16_f32(prec, dz2.data_ptr(), w2c16.data_ptr(),
+                                                                          _zero_bias(C, x.device).data_ptr(), dh1.data_ptr(), B, F1,
+                                                                          T1, C, _stream()),
+                   "cfm_subsample_conv2_bwd_input_fwdkernel_mfma16_f32")
     else:
         _lib.check(lib.cfm_subsample_conv2_bwd_input_f32(dz2.data_ptr(), w2c.data_ptr(), dh1.data_ptr(), B, F1, T1, C,
                                                          _stream()), "cfm_subsample_conv2_bwd_input_f32")

@@ -175,6 +175,12 @@ int cfm_gemm_bwd_batched_mfma16_f32(int prec, const float* A, int a_col, int64_t
 int cfm_linear_bwd_weight_mfma16_f32(int prec, const void* dy, int dy_is_16bit, int64_t ldy, const void* x,
                                      int x_is_16bit, int64_t ldx, float* dw, int64_t ldw, float* db_or_null, int N,
                                      int K, int64_t M, float alpha, cfm_stream_t stream);
+/* Input gradient of the stem's conv2 on the forward 16-bit GEMM kernel (four parity-class implicit GEMMs with a per-row
+ * tap-validity gather): w2c16 = cfm_pack_conv2_weight_t_f32's pack cast to `prec`; zero_bias: C zeros.  C % 64 == 0.
+ * Same result as cfm_subsample_conv2_bwd_input_mfma16_f32 (reference: autograd of convolution.py:46-47). */
+int cfm_subsample_conv2_bwd_input_fwdkernel_mfma16_f32(int prec, const float* dz2, const void* w2c16,
+                                                       const float* zero_bias, float* dh1, int B, int F1, int T1,
+                                                       int C, cfm_stream_t stream);
 int cfm_subsample_conv2_bwd_weight_mfma16_f32(int prec, const float* dz2, const float* h1, float* dw2p, int B, int F1,
                                               int T1, int C, cfm_stream_t stream);
 int cfm_subsample_conv2_bwd_input_mfma16_f32(int prec, const float* dz2, const float* w2c, float* dh1, int B, int F1,

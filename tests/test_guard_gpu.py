@@ -228,3 +228,39 @@ def test_round2_training_kernels_next_to_poison(dev):
     assert P3.intact()
     for a, b in zip(got, ref):
         assert torch.isfinite(a).all() and torch.equal(a, b)
+
+
+@pytest.mark.parametrize("C", [64, 256])
+def test_stem_backward_bf16_class_gather_next_to_poison(dev, C):
+    """Under autocast the stem's input-gradient product runs on the forward 16-bit GEMM kernel as four parity-class implicit GEMMs
+    (per-row tap validity, scattered output rows; 128x128 tiles at C = 64, the 8-wave 256x256 tiles at C = 256): operands inside
+    poison, odd T1 / F1 extents; every dh1 element written exactly once; equal to the general backward kernel's result (same
+    operand rounding, different summation order) and within bf16 distance of the float64 transposed convolution."""
+    from conformer_amd import _lib, ops
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(1)
+    B, T1, F1 = 2, 29, 39                                   # h1 extents (odd); T2 = 14, F2 = 19
+    T2, F2 = (T1 - 1) // 2, (F1 - 1) // 2
+    dz2 = torch.randn(B, T2, F2, C, generator=g)
+    w2 = torch.randn(C, C, 3, 3, generator=g) / math.sqrt(9 * C)
+    P = Poisoned(dev)
+    st = torch.cuda.current_stream().cuda_stream
+    w2d = w2.to(dev)
+    w2c = torch.empty(9 * C * C, device=dev)
+    assert lib.cfm_pack_conv2_weight_t_f32(w2d.data_ptr(), w2c.data_ptr(), C, st) == 0
+    w2c16 = P.place(w2c.to(torch.bfloat16))
+    dzp = P.place(dz2.to(dev))
+    zb = P.place(torch.zeros(C, device=dev))
+    dh1 = P.like((B, T1, F1, C), fill=float("inf"))       # every element must be overwritten
+    assert lib.cfm_subsample_conv2_bwd_input_fwdkernel_mfma16_f32(1, dzp.data_ptr(), w2c16.data_ptr(), zb.data_ptr(), dh1.data_ptr(),
+                                                                  B, F1, T1, C, st) == 0
+    old = torch.empty(B, T1, F1, C, device=dev)
+    assert lib.cfm_subsample_conv2_bwd_input_mfma16_f32(1, dzp.data_ptr(), w2c.data_ptr(), old.data_ptr(), B, F1, T1, C, st) == 0
+    torch.cuda.synchronize()
+    assert P.intact() and torch.isfinite(dh1).all()
+    assert rel_l2(dh1, old) < 1e-5
+    # float64: h2[b,co,f2,t2] = conv2d(h1[b,ci,f1,t1], w2, stride 2)  ->  dh1 = conv_transpose2d(dz2)
+    d = dz2.double().permute(0, 3, 2, 1)                    # (B, C, F2, T2)
+    ref = torch.nn.functional.conv_transpose2d(d, w2.double(), stride=2, output_padding=(F1 - (2 * F2 + 1), T1 - (2 * T2 + 1)))
+    ref = ref.permute(0, 3, 2, 1)                           # (B, T1, F1, C)
+    assert rel_l2(dh1, ref) < 1e-2
