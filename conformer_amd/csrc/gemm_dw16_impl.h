@@ -36,10 +36,14 @@ struct DwArgs {
     float alpha;
     unsigned tiles_i, tiles_j;
     unsigned long long* trace;        // diagnostics: s_memrealtime stamps of thread 0 of workgroups 0 and nwg/2 (64 each)
+    // GATHER (B operand = im2col of the stem's h1 for the conv2 weight gradient): row m of B is position rowtab[m] of h1 (rows
+    // of gC elements); column j = (tap, ci) adds ((tap % 3) * gF1 + tap / 3) * gC + ci.  rowtab has Kc rounded up to 64, + 64 entries.
+    const int* rowtab; int gC, gF1;
 };
 
-template <typename T16, bool A16, bool B16>
+template <typename T16, bool A16, bool B16, bool GATHER = false>
 __global__ __launch_bounds__(256, 2) void gemm_dw16_kernel(const DwArgs g) {
+    static_assert(!GATHER || (B16 && !A16), "the im2col gather is built for a 16-bit h1 and a fp32 dz2");
     using x8 = typename Lowp<T16>::x8;
     using x4 = typename Lowp<T16>::x4;
     typedef int i32x4 __attribute__((ext_vector_type(4)));
@@ -88,6 +92,15 @@ __global__ __launch_bounds__(256, 2) void gemm_dw16_kernel(const DwArgs g) {
         offb[p] = (unsigned)(rowb[p] * g.ldb + c) * (B16 ? 2u : 4u);
         if (p == 0) { offb0 = (unsigned)c * (B16 ? 2u : 4u); colb_ok = j0 + col < g.J; }
     }
+    unsigned gcol = 0;                                                  // GATHER: byte offset of this thread's column chunk inside an h1 row group
+    typedef int i32x4g __attribute__((ext_vector_type(4)));
+    i32x4g rt = {0, 0, 0, 0};                                           // GATHER: h1 positions of this thread's 4 rows of the NEXT tile to request
+    if constexpr (GATHER) {
+        const int j = min(j0 + (tid & 15) * 8, g.J - 8);
+        const int tap = j / g.gC, ci = j - tap * g.gC;
+        gcol = (unsigned)(((tap % 3) * g.gF1 + tap / 3) * g.gC + ci) * 2u;
+        rt = *reinterpret_cast<const i32x4g*>(g.rowtab + kbeg + (tid >> 4) * 4);
+    }
     const char* baseA = static_cast<const char*>(g.A) + kbeg * g.lda * (A16 ? 2 : 4);
     const char* baseB = static_cast<const char*>(g.B) + kbeg * g.ldb * (B16 ? 2 : 4);
     const int64_t stepA = (int64_t)BK * g.lda * (A16 ? 2 : 4), stepB = (int64_t)BK * g.ldb * (B16 ? 2 : 4);
@@ -111,8 +124,20 @@ __global__ __launch_bounds__(256, 2) void gemm_dw16_kernel(const DwArgs g) {
             const char* pb = baseB + (int64_t)kt * stepB;
 #pragma unroll
             for (int p = 0; p < NLA; ++p) s.a[p] = *reinterpret_cast<const RegA*>(pa + (rowa[p] <= rmax ? offa[p] : offa0));
+            if constexpr (GATHER) {
+                // (load_set is called for kt = 0, 1, 2, ... in order: `rt` holds tile kt's positions, the next tile's are requested now,
+                //  one call ahead of the h1 loads that depend on them)
+                const i32x4g cur = rt;
+                rt = *reinterpret_cast<const i32x4g*>(g.rowtab + kbeg + (int64_t)min(kt + 1, nkt - 1) * BK + (tid >> 4) * 4);
+                const char* hb = static_cast<const char*>(g.B);
+                const unsigned rowbytes = (unsigned)g.gC * 2u;
 #pragma unroll
-            for (int p = 0; p < NLB; ++p) s.b[p] = *reinterpret_cast<const RegB*>(pb + (rowb[p] <= rmax ? offb[p] : offb0));
+                for (int p = 0; p < NLB; ++p)
+                    s.b[p] = *reinterpret_cast<const RegB*>(hb + (size_t)((unsigned)(rowb[p] <= rmax ? cur[p] : cur[0]) * rowbytes + gcol));
+            } else {
+#pragma unroll
+                for (int p = 0; p < NLB; ++p) s.b[p] = *reinterpret_cast<const RegB*>(pb + (rowb[p] <= rmax ? offb[p] : offb0));
+            }
         }
     };
     // bias gradient: the workgroups of column tile 0 sum the dY values they stage (per thread: its 8 / 4 fixed columns)
@@ -284,11 +309,14 @@ int launch_dw16(DwArgs g, int a16, int b16, hipStream_t s) {
     if (forced > 0) splits = forced;
     const int64_t per = (g.Kc + splits - 1) / splits;
     g.k_per_split = (per + 63) / 64 * 64;
-    const int64_t span_a = (g.k_per_split + 64) * g.lda * (a16 ? 2 : 4), span_b = (g.k_per_split + 64) * g.ldb * (b16 ? 2 : 4);
+    const int64_t span_a = (g.k_per_split + 64) * g.lda * (a16 ? 2 : 4), span_b = g.rowtab ? 0 : (g.k_per_split + 64) * g.ldb * (b16 ? 2 : 4);
     if (span_a >= (int64_t)1 << 31 || span_b >= (int64_t)1 << 31) return CFM_ERR_UNSUPPORTED;
     const dim3 grid(tiles, (unsigned)((g.Kc + g.k_per_split - 1) / g.k_per_split));
 #define DW(A_, B_) hipLaunchKernelGGL((gemm_dw16_kernel<T16, A_, B_>), grid, dim3(256), 0, s, g)
-    if (a16 && b16) DW(true, true);
+    if (g.rowtab) {
+        if (a16 || !b16) return CFM_ERR_UNSUPPORTED;
+        hipLaunchKernelGGL((gemm_dw16_kernel<T16, false, true, true>), grid, dim3(256), 0, s, g);
+    } else if (a16 && b16) DW(true, true);
     else if (a16) DW(true, false);
     else if (b16) DW(false, true);
     else DW(false, false);
@@ -309,4 +337,15 @@ int CFM_CAT(cfm_dw16_, CFM_T16_FN)(const void* dy, int dy16, int64_t ldy, const 
     g.trace = g_dw16_trace;
     g.A = dy; g.B = x; g.C = dw; g.colsum = db; g.lda = ldy; g.ldb = ldx; g.ldc = ldw; g.I = N; g.J = K; g.Kc = M; g.alpha = alpha;
     return launch_dw16<CFM_T16>(g, dy16, x16, s);
+}
+
+// conv2 weight gradient of the stem: dw2p (C, 9C) += dz2^T (M x C, fp32) . im2col(h1) (M x 9C gathered from the 16-bit h1 through
+// rowtab: see DwArgs)
+int CFM_CAT(cfm_dw16_conv2_, CFM_T16_FN)(const float* dz2, const void* h1_16, const int* rowtab, float* dw2p, int C, int F1, int64_t M,
+                                         hipStream_t s) {
+    DwArgs g{};
+    g.trace = g_dw16_trace;
+    g.A = dz2; g.B = h1_16; g.C = dw2p; g.colsum = nullptr; g.lda = C; g.ldb = 0; g.ldc = 9 * C; g.I = C; g.J = 9 * C; g.Kc = M;
+    g.alpha = 1.f; g.rowtab = rowtab; g.gC = C; g.gF1 = F1;
+    return launch_dw16<CFM_T16>(g, 0, 1, s);
 }

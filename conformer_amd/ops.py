@@ -827,17 +827,24 @@ def relpos_attention_bwd(qkv, pos, u, v, lengths, n_heads, ctx, lse, dctx, drop_
 
 # ---- conv-subsampling stem: training forward (keeps h1, h2) and backward -------------------------------------------
 def subsample_stem_train(x, w1, b1, w2p, b2):
-    """Like subsample_stem but also returns h1 (B,T1,F1,C), needed by the backward (both fp32: the stem's gradient
-    kernels read them)."""
+    """Like subsample_stem but also returns h1 (B,T1,F1,C), needed by the backward (h2 fp32; h1 in the 16-bit type under
+    autocast: only GEMM operands read it)."""
     x = _req(x, "x")
     B, F, T = x.shape
     C = w1.shape[0]
     F1, T1 = (F - 1) // 2, (T - 1) // 2
     F2, T2 = (F1 - 1) // 2, (T1 - 1) // 2
     lib = _lib.load()
-    h1 = torch.empty(B, T1, F1, C, device=x.device, dtype=x.dtype)
-    _lib.check(lib.cfm_subsample_conv1_relu_f32(x.data_ptr(), w1.data_ptr(), b1.data_ptr(), h1.data_ptr(), B, F, T, C,
-                                                _stream()), "cfm_subsample_conv1_relu_f32")
+    p16 = out16_ok(C) if C % 64 == 0 and B * T1 * F1 * C < 2 ** 31 else 0
+    if p16:
+        # under autocast h1 only feeds the 16-bit conv2 GEMM (forward) and its weight-gradient GEMM (backward): stored in that type
+        h1 = torch.empty(B, T1, F1, C, device=x.device, dtype=_DT16[p16])
+        _lib.check(lib.cfm_subsample_conv1_relu_out16_f32(p16, x.data_ptr(), w1.data_ptr(), b1.data_ptr(), h1.data_ptr(), B, F,
+                                                          T, C, _stream()), "cfm_subsample_conv1_relu_out16_f32")
+    else:
+        h1 = torch.empty(B, T1, F1, C, device=x.device, dtype=x.dtype)
+        _lib.check(lib.cfm_subsample_conv1_relu_f32(x.data_ptr(), w1.data_ptr(), b1.data_ptr(), h1.data_ptr(), B, F, T, C,
+                                                    _stream()), "cfm_subsample_conv1_relu_f32")
     h2 = torch.empty(B, T2, F2 * C, device=x.device, dtype=x.dtype)
     _conv2_relu(lib, h1, w2p, b2, h2, B, F1, T1, C)
     return h2, h1
@@ -857,7 +864,14 @@ def subsample_stem_bwd(x, w1, b1, w2, h1, h2, dh2):
     dw2p, db2, dw1, db1 = _zeros_split(x.device, x.dtype, (C, 9 * C), (C,), tuple(w1.shape), (C,))
     colsum(dz2.view(-1, C), out=db2)
     prec = mfma16_prec() if C % 64 == 0 else 0
-    if prec:
+    if h1.dtype != torch.float32:
+        if not prec or h1.dtype != _DT16[prec]:
+            raise _lib.ConformerHipError("a 16-bit h1 needs the matching precision mode in the backward")
+        rowtab = torch.empty(int(lib.cfm_subsample_conv2_rowtab_elems(B, F1, T1)), device=x.device, dtype=torch.int32)
+        _lib.check(lib.cfm_subsample_conv2_bwd_weight_h16_mfma16_f32(prec, dz2.data_ptr(), h1.data_ptr(), rowtab.data_ptr(),
+                                                                     dw2p.data_ptr(), B, F1, T1, C, _stream()),
+                   "cfm_subsample_conv2_bwd_weight_h16_mfma16_f32")
+    elif prec:
         _lib.check(lib.cfm_subsample_conv2_bwd_weight_mfma16_f32(prec, dz2.data_ptr(), h1.data_ptr(), dw2p.data_ptr(), B, F1,
                                                                  T1, C, _stream()), "cfm_subsample_conv2_bwd_weight_mfma16_f32")
     else:
@@ -865,7 +879,7 @@ def subsample_stem_bwd(x, w1, b1, w2, h1, h2, dh2):
                                                           _stream()), "cfm_subsample_conv2_bwd_weight_f32")
     w2c = torch.empty(9 * C * C, device=x.device, dtype=x.dtype)
     _lib.check(lib.cfm_pack_conv2_weight_t_f32(w2.data_ptr(), w2c.data_ptr(), C, _stream()), "cfm_pack_conv2_weight_t_f32")
-    dh1 = torch.empty_like(h1)
+    dh1 = torch.empty(h1.shape, device=h1.device, dtype=torch.float32)          # (h1 itself may be stored in the 16-bit type)
     if prec:
         # transposed conv as four parity-class implicit GEMMs on the FORWARD 16-bit kernel (two-tile prefetch, row-major epilogue)
         w2c16 = torch.empty(9 * C * C, device=x.device, dtype=_DT16[prec])
