@@ -264,3 +264,24 @@ def test_stem_backward_bf16_class_gather_next_to_poison(dev, C):
     ref = torch.nn.functional.conv_transpose2d(d, w2.double(), stride=2, output_padding=(F1 - (2 * F2 + 1), T1 - (2 * T2 + 1)))
     ref = ref.permute(0, 3, 2, 1)                           # (B, T1, F1, C)
     assert rel_l2(dh1, ref) < 1e-2
+    # ---- the weight gradient from a 16-bit h1: im2col gather through the position table inside the weight-gradient kernel
+    h1 = torch.relu(torch.randn(B, T1, F1, C, generator=g)).to(torch.bfloat16)
+    h1p = P.place(h1.to(dev))
+    n_tab = int(lib.cfm_subsample_conv2_rowtab_elems(B, F1, T1))
+    tab = torch.empty(n_tab, device=dev, dtype=torch.int32)
+    dw_new = P.like((C, 9 * C))
+    assert lib.cfm_subsample_conv2_bwd_weight_h16_mfma16_f32(1, dzp.data_ptr(), h1p.data_ptr(), tab.data_ptr(), dw_new.data_ptr(),
+                                                             B, F1, T1, C, st) == 0
+    dw_old = torch.zeros(C, 9 * C, device=dev)
+    h1f = h1.to(dev).float()                                # exactly representable: the general kernel's rounding is the identity
+    assert lib.cfm_subsample_conv2_bwd_weight_mfma16_f32(1, dzp.data_ptr(), h1f.data_ptr(), dw_old.data_ptr(), B, F1, T1, C, st) == 0
+    torch.cuda.synchronize()
+    assert P.intact() and torch.isfinite(dw_new).all() and rel_l2(dw_new, dw_old) < 1e-4
+    # float64: dw2[co][ci][kf][kt] = sum dz2 * h1 patches  (conv2d weight gradient), packed (co, kf, kt, ci)
+    hh = h1.double().permute(0, 3, 2, 1).requires_grad_(False)          # (B, C, F1, T1)
+    wz = torch.zeros(C, C, 3, 3, dtype=torch.float64, requires_grad=True)
+    out = torch.nn.functional.conv2d(hh, wz, stride=2)                   # (B, C, F2, T2)
+    (out * dz2.double().permute(0, 3, 2, 1)).sum().backward()
+    ref_dw = wz.grad.permute(0, 2, 3, 1).reshape(C, 9 * C)               # (co, kf, kt, ci)
+    assert rel_l2(dw_new, ref_dw) < 1e-2
+
