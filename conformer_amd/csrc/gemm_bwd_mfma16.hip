@@ -20,8 +20,10 @@ int cfm_bwd16_conv2_weight_f16(BwdArgs g, hipStream_t s);
 int cfm_bwd16_conv2_input_bf16(const float* dz2, const float* w2c, float* dh1, int B, int F1, int T1, int C, hipStream_t s);
 int cfm_bwd16_conv2_input_f16(const float* dz2, const float* w2c, float* dh1, int B, int F1, int T1, int C, hipStream_t s);
 // gemm_dw16_{bf16,f16}.hip
-int cfm_dw16_conv2_bf16(const float* dz2, const void* h1_16, const int* rowtab, float* dw2p, int C, int F1, int64_t M, hipStream_t s);
-int cfm_dw16_conv2_f16(const float* dz2, const void* h1_16, const int* rowtab, float* dw2p, int C, int F1, int64_t M, hipStream_t s);
+int cfm_dw16_conv2_bf16(const void* dz2, int dz16, const void* h1_16, const int* rowtab, float* dw2p, float* db2, int C, int F1, int64_t M,
+                        hipStream_t s);
+int cfm_dw16_conv2_f16(const void* dz2, int dz16, const void* h1_16, const int* rowtab, float* dw2p, float* db2, int C, int F1, int64_t M,
+                       hipStream_t s);
 void cfm_dw16_trace_bf16(void* p);
 void cfm_dw16_trace_f16(void* p);
 int cfm_dw16_bf16(const void* dy, int dy16, int64_t ldy, const void* x, int x16, int64_t ldx, float* dw, int64_t ldw, float* db, int N,
@@ -137,15 +139,17 @@ __global__ __launch_bounds__(256) void conv2_rowtab_kernel(int* __restrict__ tab
 }  // namespace
 
 // Weight gradient of the stem's conv2 with a 16-bit h1 (cfm_subsample_conv1_relu_out16_f32) on the weight-gradient kernel of
-// gemm_dw16_impl.h: dw2p (C, 3(kf), 3(kt), C) += dz2^T . im2col(h1); `rowtab_scratch`: cfm_subsample_conv2_rowtab_elems(B, F1, T1)
+// gemm_dw16_impl.h: dw2p (C, 3(kf), 3(kt), C) += dz2^T . im2col(h1), db2 (C) += column sums of dz2 (NULL: skipped; dz2 fp32 or
+// 16-bit); `rowtab_scratch`: cfm_subsample_conv2_rowtab_elems(B, F1, T1)
 // ints (any contents; 16-byte aligned).  C % 64 == 0; B*T1*F1*C < 2^31.
 extern "C" int64_t cfm_subsample_conv2_rowtab_elems(int B, int F1, int T1) {
     if (B <= 0 || F1 < 3 || T1 < 3) return 0;
     const int64_t M = (int64_t)B * ((T1 - 1) / 2) * ((F1 - 1) / 2);
     return (M + 63) / 64 * 64 + 64;
 }
-extern "C" int cfm_subsample_conv2_bwd_weight_h16_mfma16_f32(int prec, const float* dz2, const void* h1_16, int* rowtab_scratch,
-                                                             float* dw2p, int B, int F1, int T1, int C, cfm_stream_t stream) {
+extern "C" int cfm_subsample_conv2_bwd_weight_h16_mfma16_f32(int prec, const void* dz2, int dz2_is_16bit, const void* h1_16,
+                                                             int* rowtab_scratch, float* dw2p, float* db2_or_null, int B, int F1,
+                                                             int T1, int C, cfm_stream_t stream) {
     CFM_REQUIRE(dz2 && h1_16 && rowtab_scratch && dw2p, CFM_ERR_NULL);
     CFM_REQUIRE(B > 0 && F1 >= 3 && T1 >= 3 && C > 0 && (C % 64) == 0, CFM_ERR_BAD_SHAPE);
     CFM_REQUIRE((int64_t)B * T1 * F1 * C < ((int64_t)1 << 31), CFM_ERR_UNSUPPORTED);
@@ -154,7 +158,7 @@ extern "C" int cfm_subsample_conv2_bwd_weight_h16_mfma16_f32(int prec, const flo
     const int64_t M = (int64_t)B * T2 * F2, n = cfm_subsample_conv2_rowtab_elems(B, F1, T1);
     hipStream_t s = static_cast<hipStream_t>(stream);
     hipLaunchKernelGGL(conv2_rowtab_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, rowtab_scratch, M, n, T2, F2, T1, F1);
-    if (prec == CFM_PREC_BF16) return cfm_dw16_conv2_bf16(dz2, h1_16, rowtab_scratch, dw2p, C, F1, M, s);
-    if (prec == CFM_PREC_FP16) return cfm_dw16_conv2_f16(dz2, h1_16, rowtab_scratch, dw2p, C, F1, M, s);
+    if (prec == CFM_PREC_BF16) return cfm_dw16_conv2_bf16(dz2, dz2_is_16bit, h1_16, rowtab_scratch, dw2p, db2_or_null, C, F1, M, s);
+    if (prec == CFM_PREC_FP16) return cfm_dw16_conv2_f16(dz2, dz2_is_16bit, h1_16, rowtab_scratch, dw2p, db2_or_null, C, F1, M, s);
     return CFM_ERR_UNSUPPORTED;
 }

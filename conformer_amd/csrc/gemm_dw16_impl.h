@@ -43,7 +43,7 @@ struct DwArgs {
 
 template <typename T16, bool A16, bool B16, bool GATHER = false>
 __global__ __launch_bounds__(256, 2) void gemm_dw16_kernel(const DwArgs g) {
-    static_assert(!GATHER || (B16 && !A16), "the im2col gather is built for a 16-bit h1 and a fp32 dz2");
+    static_assert(!GATHER || B16, "the im2col gather is built for a 16-bit h1");
     using x8 = typename Lowp<T16>::x8;
     using x4 = typename Lowp<T16>::x4;
     typedef int i32x4 __attribute__((ext_vector_type(4)));
@@ -250,9 +250,9 @@ __global__ __launch_bounds__(256, 2) void gemm_dw16_kernel(const DwArgs g) {
     // FAST steps: the tile staged (kt + 1) and the tile requested (kt + 3) are full tiles inside the matrix: no selects, no
     // zeroing, no clamps.  (The first version spent ~2000 of its ~2500 cycles per K-tile on that bookkeeping around 16 MFMAs.)
     // (only the all-16-bit instantiation: with a fp32 operand the second copy of the loop costs registers the sets need)
-    const int nfast = (A16 && B16 && i0 + BM <= g.I && j0 + BN <= g.J) ? (klen / BK - 3) & ~1 : 0;       // even: the sets keep their roles
+    const int nfast = (A16 && B16 && !GATHER && i0 + BM <= g.I && j0 + BN <= g.J) ? (klen / BK - 3) & ~1 : 0;       // even: the sets keep their roles
     int kt = 0;
-    if constexpr (A16 && B16) {
+    if constexpr (A16 && B16 && !GATHER) {
         for (; kt < nfast; kt += 2) {
             step(Fast{}, kt, s1);
             step(Fast{}, kt + 1, s0);
@@ -314,8 +314,9 @@ int launch_dw16(DwArgs g, int a16, int b16, hipStream_t s) {
     const dim3 grid(tiles, (unsigned)((g.Kc + g.k_per_split - 1) / g.k_per_split));
 #define DW(A_, B_) hipLaunchKernelGGL((gemm_dw16_kernel<T16, A_, B_>), grid, dim3(256), 0, s, g)
     if (g.rowtab) {
-        if (a16 || !b16) return CFM_ERR_UNSUPPORTED;
-        hipLaunchKernelGGL((gemm_dw16_kernel<T16, false, true, true>), grid, dim3(256), 0, s, g);
+        if (!b16) return CFM_ERR_UNSUPPORTED;
+        if (a16) hipLaunchKernelGGL((gemm_dw16_kernel<T16, true, true, true>), grid, dim3(256), 0, s, g);
+        else hipLaunchKernelGGL((gemm_dw16_kernel<T16, false, true, true>), grid, dim3(256), 0, s, g);
     } else if (a16 && b16) DW(true, true);
     else if (a16) DW(true, false);
     else if (b16) DW(false, true);
@@ -341,11 +342,11 @@ int CFM_CAT(cfm_dw16_, CFM_T16_FN)(const void* dy, int dy16, int64_t ldy, const 
 
 // conv2 weight gradient of the stem: dw2p (C, 9C) += dz2^T (M x C, fp32) . im2col(h1) (M x 9C gathered from the 16-bit h1 through
 // rowtab: see DwArgs)
-int CFM_CAT(cfm_dw16_conv2_, CFM_T16_FN)(const float* dz2, const void* h1_16, const int* rowtab, float* dw2p, int C, int F1, int64_t M,
-                                         hipStream_t s) {
+int CFM_CAT(cfm_dw16_conv2_, CFM_T16_FN)(const void* dz2, int dz16, const void* h1_16, const int* rowtab, float* dw2p, float* db2, int C,
+                                         int F1, int64_t M, hipStream_t s) {
     DwArgs g{};
     g.trace = g_dw16_trace;
-    g.A = dz2; g.B = h1_16; g.C = dw2p; g.colsum = nullptr; g.lda = C; g.ldb = 0; g.ldc = 9 * C; g.I = C; g.J = 9 * C; g.Kc = M;
+    g.A = dz2; g.B = h1_16; g.C = dw2p; g.colsum = db2; g.lda = C; g.ldb = 0; g.ldc = 9 * C; g.I = C; g.J = 9 * C; g.Kc = M;
     g.alpha = 1.f; g.rowtab = rowtab; g.gC = C; g.gF1 = F1;
-    return launch_dw16<CFM_T16>(g, 0, 1, s);
+    return launch_dw16<CFM_T16>(g, dz16, 1, s);
 }

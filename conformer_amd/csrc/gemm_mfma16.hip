@@ -68,12 +68,12 @@ __global__ __launch_bounds__(WM * 128, 2) void gemm_mfma16_kernel(const GemmArgs
 #pragma unroll
         for (int p = 0; p < NA; ++p) a_ptr[p] = a_row_ptr<CONV>(g, m0 + srow + RP4 * p);
     }
-    static_assert(CONV != 2 || !A16, "the class gather stages fp32 rows");
-    int cls_a[CONV == 2 ? NA : 1], cls_c[CONV == 2 ? NA : 1];         // class coordinates of the rows this thread stages
+    constexpr int NCLS = CONV == 2 ? (A16 ? NAH : NA) : 1;
+    int cls_a[NCLS], cls_c[NCLS];                                     // class coordinates of the rows this thread stages
     if constexpr (CONV == 2) {
 #pragma unroll
-        for (int p = 0; p < NA; ++p) {
-            const int64_t m = min(m0 + srow + RP4 * p, g.M - 1);
+        for (int p = 0; p < NCLS; ++p) {
+            const int64_t m = min(m0 + (A16 ? hrow + RP8 * p : srow + RP4 * p), g.M - 1);
             const int per = g.pA * g.pC;
             const int r = (int)(m - (m / per) * per);
             cls_a[p] = r / g.pC;
@@ -105,7 +105,18 @@ __global__ __launch_bounds__(WM * 128, 2) void gemm_mfma16_kernel(const GemmArgs
         const int k = kt * BK + sch * 4, kh = kt * BK + hch * 8;       // K % 4 == 0 (K % 8 == 0 for 16-bit operands)
         t.kvalid = k < g.K; t.kvalid_h = kh < g.K;
         const int kc = max(0, min(k, g.K - 4)), khc = max(0, min(kh, g.K - 8));
-        if (A16) {
+        if (A16 && CONV == 2) {
+            const int tap = (khc - hch * 8) / g.cC;                   // (uniform: a K-tile lies inside one tap, C % 64 == 0)
+            const int dt = g.tap_dt[tap], df = g.tap_df[tap];
+            const int64_t ahoff = a_k_offset<CONV>(g, khc - hch * 8) + hch * 8;
+            t.amask = 0;
+#pragma unroll
+            for (int p = 0; p < NAH; ++p) {
+                const bool ok = (unsigned)(cls_a[p] + dt) < (unsigned)g.cT2 && (unsigned)(cls_c[p] + df) < (unsigned)g.cF2;
+                t.rah[p] = *reinterpret_cast<const x8*>(ok ? ah_ptr[p] + ahoff : reinterpret_cast<const T16*>(g.A) + hch * 8);
+                t.amask |= ok ? (1u << p) : 0u;
+            }
+        } else if (A16) {
             const int64_t ahoff = a_k_offset<CONV>(g, khc - hch * 8) + hch * 8;
 #pragma unroll
             for (int p = 0; p < NAH; ++p) t.rah[p] = *reinterpret_cast<const x8*>(ah_ptr[p] + ahoff);
@@ -141,7 +152,8 @@ __global__ __launch_bounds__(WM * 128, 2) void gemm_mfma16_kernel(const GemmArgs
         if (A16) {
 #pragma unroll
             for (int p = 0; p < NAH; ++p)
-                *reinterpret_cast<x8*>(As + (buf * BM + hrow + RP8 * p) * ROWB + hch * 8) = t.kvalid_h ? t.rah[p] : z8;
+                *reinterpret_cast<x8*>(As + (buf * BM + hrow + RP8 * p) * ROWB + hch * 8) =
+                    (t.kvalid_h && (CONV != 2 || ((t.amask >> p) & 1u))) ? t.rah[p] : z8;
         } else {
 #pragma unroll
             for (int p = 0; p < NA; ++p)
@@ -248,10 +260,7 @@ int launch_cfg(GemmArgs g, int src16, hipStream_t s) {          // src16: 0 = fp
     g.tiles_m = (unsigned)((g.M + BM - 1) / BM);
     g.tiles_n = (unsigned)((ncols + bn - 1) / bn);
     const dim3 grid(g.tiles_m * g.tiles_n);
-    if constexpr (CONV == 2) {
-        if (src16 == 2) return CFM_ERR_UNSUPPORTED;
-    }
-    if (src16 == 2) hipLaunchKernelGGL((gemm_mfma16_kernel<T16, BM, BN, EPI, (CONV == 2 ? 0 : CONV), true, true>), grid, dim3(256), 0, s, g);
+    if (src16 == 2) hipLaunchKernelGGL((gemm_mfma16_kernel<T16, BM, BN, EPI, CONV, true, true>), grid, dim3(256), 0, s, g);
     else if (src16 == 1) hipLaunchKernelGGL((gemm_mfma16_kernel<T16, BM, BN, EPI, CONV, true>), grid, dim3(256), 0, s, g);
     else if (src16 == 0) hipLaunchKernelGGL((gemm_mfma16_kernel<T16, BM, BN, EPI, CONV, false>), grid, dim3(256), 0, s, g);
     else return CFM_ERR_UNSUPPORTED;
@@ -270,7 +279,8 @@ int launch_big(GemmArgs g, int src16, hipStream_t s) {          // 512-thread wo
     g.tiles_n = (unsigned)((g.N + BN - 1) / BN);
     const dim3 grid(g.tiles_m * g.tiles_n);
     if constexpr (CONV == 2) {
-        hipLaunchKernelGGL((gemm_mfma16_kernel<T16, BM, BN, EPI, 2, true, false, 4>), grid, dim3(512), 0, s, g);
+        if (src16 == 2) hipLaunchKernelGGL((gemm_mfma16_kernel<T16, BM, BN, EPI, 2, true, true, 4>), grid, dim3(512), 0, s, g);
+        else hipLaunchKernelGGL((gemm_mfma16_kernel<T16, BM, BN, EPI, 2, true, false, 4>), grid, dim3(512), 0, s, g);
     } else {
         if (src16 == 2) hipLaunchKernelGGL((gemm_mfma16_kernel<T16, BM, BN, EPI, 0, true, true, 4>), grid, dim3(512), 0, s, g);
         else hipLaunchKernelGGL((gemm_mfma16_kernel<T16, BM, BN, EPI, 0, true, false, 4>), grid, dim3(512), 0, s, g);
@@ -287,7 +297,7 @@ int launch_t(const GemmArgs& g, int src16, hipStream_t s) {
         return t128 >= 512 ? launch_cfg<T16, 128, 128, EPI, CONV>(g, src16, s) : launch_cfg<T16, 64, 128, EPI, CONV>(g, src16, s);
     } else {
         if constexpr (CONV == 2) {                                // transposed-conv classes: hundreds of thousands of rows, N = C
-            if (src16 == 1 && gemm_epilogue_vec_ok_host(g, EPI) && (g.N % 256) == 0 && g.occ_cap != 1)
+            if (src16 >= 1 && gemm_epilogue_vec_ok_host(g, EPI) && (g.N % 256) == 0 && g.occ_cap != 1)
                 return launch_big<T16, 256, 256, EPI, 2>(g, src16, s);
         }
         if constexpr (CONV == 0) {
@@ -481,9 +491,10 @@ extern "C" int cfm_cast16_multi_f32(int prec, const cfm_cast_item* items, int co
 
 // Input gradient of the stem's conv2 (3x3, stride 2) on the forward kernel: dh1 (B,T1,F1,C) = conv_transpose(dz2 (B,T2,F2,C), w2)
 // as four parity-class implicit GEMMs (t1 = 2a+pt, f1 = 2c+pf; the class's taps (kt,kf) = (pt,pf) mod 2), CONV == 2.
-// w2c16: the transposed-pack of w2 (cfm_pack_conv2_weight_t_f32) cast to `prec` (cfm_cast16_f32); zero_bias: C zeros.
+// w2c16: the transposed-pack of w2 (cfm_pack_conv2_weight_t_f32) cast to `prec` (cfm_cast16_f32); zero_bias: C zeros; dz2 fp32
+// or stored in `prec` (cfm_relu_bwd_out16_f32).
 // Every dh1 element is written exactly once.  C % 64 == 0.
-extern "C" int cfm_subsample_conv2_bwd_input_fwdkernel_mfma16_f32(int prec, const float* dz2, const void* w2c16,
+extern "C" int cfm_subsample_conv2_bwd_input_fwdkernel_mfma16_f32(int prec, const void* dz2, int dz2_is_16bit, const void* w2c16,
                                                                   const float* zero_bias, float* dh1, int B, int F1, int T1, int C,
                                                                   cfm_stream_t stream) {
     CFM_REQUIRE(dz2 && w2c16 && zero_bias && dh1, CFM_ERR_NULL);
@@ -503,10 +514,10 @@ extern "C" int cfm_subsample_conv2_bwd_input_fwdkernel_mfma16_f32(int prec, cons
             for (int kt = pt; kt < 3; kt += 2)
                 for (int kf = pf; kf < 3; kf += 2) { g.tap_dt[nt] = -(kt - pt) / 2; g.tap_df[nt] = -(kf - pf) / 2; ++nt; }
             const int q = 2 * pt + pf;
-            g.A = dz2; g.W = reinterpret_cast<const float*>(static_cast<const char*>(w2c16) + woff[q] * C * C * 2);
+            g.A = static_cast<const float*>(dz2); g.W = reinterpret_cast<const float*>(static_cast<const char*>(w2c16) + woff[q] * C * C * 2);
             g.bias = zero_bias; g.C = dh1; g.c_prec = 0;
             g.M = (int64_t)B * g.pA * g.pC; g.N = C; g.K = nt * C; g.lda = 0; g.ldc = C; g.alpha = 1.f;
-            const int st = launch<EPI_BIAS, 2>(prec, g, 1, s);
+            const int st = launch<EPI_BIAS, 2>(prec, g, dz2_is_16bit ? 2 : 1, s);
             if (st) return st;
         }
     return CFM_OK;

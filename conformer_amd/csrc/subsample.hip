@@ -101,6 +101,18 @@ __global__ __launch_bounds__(256) void relu_bwd_kernel(const float* __restrict__
     reinterpret_cast<f32x4*>(dz)[i] = d;
 }
 
+// the same with dz written in a 16-bit matrix-pipe type (its only consumers are 16-bit GEMM operands)
+template <typename T16>
+__global__ __launch_bounds__(256) void relu_bwd_out16_kernel(const float* __restrict__ y, const float* __restrict__ dy,
+                                                             T16* __restrict__ dz, int64_t n4) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    const f32x4 a = reinterpret_cast<const f32x4*>(y)[i];
+    f32x4 d = reinterpret_cast<const f32x4*>(dy)[i];
+    d.x = a.x > 0.f ? d.x : 0.f; d.y = a.y > 0.f ? d.y : 0.f; d.z = a.z > 0.f ? d.z : 0.f; d.w = a.w > 0.f ? d.w : 0.f;
+    *reinterpret_cast<typename Lowp<T16>::x4*>(dz + 4 * i) = Lowp<T16>::cvt4(d);
+}
+
 // conv1 parameter gradients: dw1[c][kf][kt] += sum dz1 * x[b][2f1+kf][2t1+kt], db1[c] += sum dz1 with
 // dz1 = dh1 where relu(conv1) > 0 (the pre-activation is recomputed from x: 9 FMAs, h1 need not be re-read).
 // Same thread mapping as the forward kernel (4 channels per thread); block partials through LDS, one atomic per value.
@@ -174,6 +186,21 @@ extern "C" int cfm_relu_bwd_f32(const float* y, const float* dy, float* dz, int6
     const int64_t n4 = n / 4;
     hipLaunchKernelGGL(relu_bwd_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0,
                        static_cast<hipStream_t>(stream), y, dy, dz, n4);
+    return cfm_launch_status();
+}
+
+// cfm_relu_bwd_f32 with dz stored in the 16-bit type `prec` (a gradient that only feeds 16-bit GEMM operands: the stem's conv2
+// backward under autocast)
+extern "C" int cfm_relu_bwd_out16_f32(int prec, const float* y, const float* dy, void* dz16, int64_t n, cfm_stream_t stream) {
+    CFM_REQUIRE(y && dy && dz16, CFM_ERR_NULL);
+    CFM_REQUIRE(n > 0 && (n & 3) == 0, CFM_ERR_BAD_SHAPE);
+    CFM_REQUIRE(CFM_ALIGNED16(y) && CFM_ALIGNED16(dy) && (reinterpret_cast<uintptr_t>(dz16) & 7) == 0, CFM_ERR_ALIGN);
+    const int64_t n4 = n / 4;
+    const dim3 grid((unsigned)((n4 + 255) / 256));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (prec == CFM_PREC_BF16) hipLaunchKernelGGL(relu_bwd_out16_kernel<__bf16>, grid, dim3(256), 0, s, y, dy, static_cast<__bf16*>(dz16), n4);
+    else if (prec == CFM_PREC_FP16) hipLaunchKernelGGL(relu_bwd_out16_kernel<_Float16>, grid, dim3(256), 0, s, y, dy, static_cast<_Float16*>(dz16), n4);
+    else return CFM_ERR_UNSUPPORTED;
     return cfm_launch_status();
 }
 

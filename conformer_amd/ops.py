@@ -858,25 +858,32 @@ def subsample_stem_bwd(x, w1, b1, w2, h1, h2, dh2):
     F1, T1 = (F - 1) // 2, (T - 1) // 2
     F2, T2 = (F1 - 1) // 2, (T1 - 1) // 2
     dh2 = _req(dh2, "dh2")
-    dz2 = torch.empty_like(dh2)
-    _lib.check(lib.cfm_relu_bwd_f32(h2.data_ptr(), dh2.data_ptr(), dz2.data_ptr(), dz2.numel(), _stream()),
-               "cfm_relu_bwd_f32")
-    dw2p, db2, dw1, db1 = _zeros_split(x.device, x.dtype, (C, 9 * C), (C,), tuple(w1.shape), (C,))
-    colsum(dz2.view(-1, C), out=db2)
     prec = mfma16_prec() if C % 64 == 0 else 0
-    if h1.dtype != torch.float32:
-        if not prec or h1.dtype != _DT16[prec]:
-            raise _lib.ConformerHipError("a 16-bit h1 needs the matching precision mode in the backward")
+    h16 = h1.dtype != torch.float32
+    if h16 and (not prec or h1.dtype != _DT16[prec]):
+        raise _lib.ConformerHipError("a 16-bit h1 needs the matching precision mode in the backward")
+    dw2p, db2, dw1, db1 = _zeros_split(x.device, torch.float32, (C, 9 * C), (C,), tuple(w1.shape), (C,))
+    if h16:
+        # the all-16-bit stem backward of the autocast path: dz2 = relu'(h2) * dh2 only feeds the two conv2 gradient GEMMs (and
+        # the bias gradient, which the weight-gradient kernel sums from the dz2 values it stages)
+        dz2 = torch.empty(dh2.shape, device=x.device, dtype=_DT16[prec])
+        _lib.check(lib.cfm_relu_bwd_out16_f32(prec, h2.data_ptr(), dh2.data_ptr(), dz2.data_ptr(), dz2.numel(), _stream()),
+                   "cfm_relu_bwd_out16_f32")
         rowtab = torch.empty(int(lib.cfm_subsample_conv2_rowtab_elems(B, F1, T1)), device=x.device, dtype=torch.int32)
-        _lib.check(lib.cfm_subsample_conv2_bwd_weight_h16_mfma16_f32(prec, dz2.data_ptr(), h1.data_ptr(), rowtab.data_ptr(),
-                                                                     dw2p.data_ptr(), B, F1, T1, C, _stream()),
+        _lib.check(lib.cfm_subsample_conv2_bwd_weight_h16_mfma16_f32(prec, dz2.data_ptr(), 1, h1.data_ptr(), rowtab.data_ptr(),
+                                                                     dw2p.data_ptr(), db2.data_ptr(), B, F1, T1, C, _stream()),
                    "cfm_subsample_conv2_bwd_weight_h16_mfma16_f32")
-    elif prec:
-        _lib.check(lib.cfm_subsample_conv2_bwd_weight_mfma16_f32(prec, dz2.data_ptr(), h1.data_ptr(), dw2p.data_ptr(), B, F1,
-                                                                 T1, C, _stream()), "cfm_subsample_conv2_bwd_weight_mfma16_f32")
     else:
-        _lib.check(lib.cfm_subsample_conv2_bwd_weight_f32(dz2.data_ptr(), h1.data_ptr(), dw2p.data_ptr(), B, F1, T1, C,
-                                                          _stream()), "cfm_subsample_conv2_bwd_weight_f32")
+        dz2 = torch.empty_like(dh2)
+        _lib.check(lib.cfm_relu_bwd_f32(h2.data_ptr(), dh2.data_ptr(), dz2.data_ptr(), dz2.numel(), _stream()),
+                   "cfm_relu_bwd_f32")
+        colsum(dz2.view(-1, C), out=db2)
+        if prec:
+            _lib.check(lib.cfm_subsample_conv2_bwd_weight_mfma16_f32(prec, dz2.data_ptr(), h1.data_ptr(), dw2p.data_ptr(), B, F1,
+                                                                     T1, C, _stream()), "cfm_subsample_conv2_bwd_weight_mfma16_f32")
+        else:
+            _lib.check(lib.cfm_subsample_conv2_bwd_weight_f32(dz2.data_ptr(), h1.data_ptr(), dw2p.data_ptr(), B, F1, T1, C,
+                                                              _stream()), "cfm_subsample_conv2_bwd_weight_f32")
     w2c = torch.empty(9 * C * C, device=x.device, dtype=x.dtype)
     _lib.check(lib.cfm_pack_conv2_weight_t_f32(w2.data_ptr(), w2c.data_ptr(), C, _stream()), "cfm_pack_conv2_weight_t_f32")
     dh1 = torch.empty(h1.shape, device=h1.device, dtype=torch.float32)          # (h1 itself may be stored in the 16-bit type)
@@ -884,7 +891,8 @@ def subsample_stem_bwd(x, w1, b1, w2, h1, h2, dh2):
         # transposed conv as four parity-class implicit GEMMs on the FORWARD 16-bit kernel (two-tile prefetch, row-major epilogue)
         w2c16 = torch.empty(9 * C * C, device=x.device, dtype=_DT16[prec])
         _lib.check(lib.cfm_cast16_f32(prec, w2c.data_ptr(), w2c16.data_ptr(), w2c.numel(), _stream()), "cfm_cast16_f32")
-        _lib.check(lib.cfm_subsample_conv2_bwd_input_fwdkernel_mfma16_f32(prec, dz2.data_ptr(), w2c16.data_ptr(),
+        _lib.check(lib.cfm_subsample_conv2_bwd_input_fwdkernel_mfma16_f32(prec, dz2.data_ptr(), int(dz2.dtype != torch.float32),
+                                                                          w2c16.data_ptr(),
                                                                           _zero_bias(C, x.device).data_ptr(), dh1.data_ptr(), B, F1,
                                                                           T1, C, _stream()),
                    "cfm_subsample_conv2_bwd_input_fwdkernel_mfma16_f32")

@@ -176,14 +176,18 @@ int cfm_linear_bwd_weight_mfma16_f32(int prec, const void* dy, int dy_is_16bit, 
                                      int x_is_16bit, int64_t ldx, float* dw, int64_t ldw, float* db_or_null, int N,
                                      int K, int64_t M, float alpha, cfm_stream_t stream);
 /* Weight gradient of the stem's conv2 from a 16-bit h1 (training under autocast keeps h1 in `prec`): im2col gather inside the
- * weight-gradient kernel; rowtab_scratch: cfm_subsample_conv2_rowtab_elems(B, F1, T1) ints.  dw2p accumulates (caller zero-fills). */
+ * weight-gradient kernel; rowtab_scratch: cfm_subsample_conv2_rowtab_elems(B, F1, T1) ints.  dw2p and db2 (bias gradient,
+ * may be NULL) accumulate (caller zero-fills); dz2 fp32 or stored in `prec`. */
 int64_t cfm_subsample_conv2_rowtab_elems(int B, int F1, int T1);
-int cfm_subsample_conv2_bwd_weight_h16_mfma16_f32(int prec, const float* dz2, const void* h1_16, int* rowtab_scratch,
-                                                  float* dw2p, int B, int F1, int T1, int C, cfm_stream_t stream);
+int cfm_subsample_conv2_bwd_weight_h16_mfma16_f32(int prec, const void* dz2, int dz2_is_16bit, const void* h1_16,
+                                                  int* rowtab_scratch, float* dw2p, float* db2_or_null, int B, int F1, int T1,
+                                                  int C, cfm_stream_t stream);
+/* ReLU backward with the result stored in `prec` (cfm_relu_bwd_f32 otherwise). */
+int cfm_relu_bwd_out16_f32(int prec, const float* y, const float* dy, void* dz16, int64_t n, cfm_stream_t stream);
 /* Input gradient of the stem's conv2 on the forward 16-bit GEMM kernel (four parity-class implicit GEMMs with a per-row
  * tap-validity gather): w2c16 = cfm_pack_conv2_weight_t_f32's pack cast to `prec`; zero_bias: C zeros.  C % 64 == 0.
  * Same result as cfm_subsample_conv2_bwd_input_mfma16_f32 (reference: autograd of convolution.py:46-47). */
-int cfm_subsample_conv2_bwd_input_fwdkernel_mfma16_f32(int prec, const float* dz2, const void* w2c16,
+int cfm_subsample_conv2_bwd_input_fwdkernel_mfma16_f32(int prec, const void* dz2, int dz2_is_16bit, const void* w2c16,
                                                        const float* zero_bias, float* dh1, int B, int F1, int T1,
                                                        int C, cfm_stream_t stream);
 int cfm_subsample_conv2_bwd_weight_mfma16_f32(int prec, const float* dz2, const float* h1, float* dw2p, int B, int F1,

@@ -252,7 +252,7 @@ def test_stem_backward_bf16_class_gather_next_to_poison(dev, C):
     dzp = P.place(dz2.to(dev))
     zb = P.place(torch.zeros(C, device=dev))
     dh1 = P.like((B, T1, F1, C), fill=float("inf"))       # every element must be overwritten
-    assert lib.cfm_subsample_conv2_bwd_input_fwdkernel_mfma16_f32(1, dzp.data_ptr(), w2c16.data_ptr(), zb.data_ptr(), dh1.data_ptr(),
+    assert lib.cfm_subsample_conv2_bwd_input_fwdkernel_mfma16_f32(1, dzp.data_ptr(), 0, w2c16.data_ptr(), zb.data_ptr(), dh1.data_ptr(),
                                                                   B, F1, T1, C, st) == 0
     old = torch.empty(B, T1, F1, C, device=dev)
     assert lib.cfm_subsample_conv2_bwd_input_mfma16_f32(1, dzp.data_ptr(), w2c.data_ptr(), old.data_ptr(), B, F1, T1, C, st) == 0
@@ -270,8 +270,8 @@ def test_stem_backward_bf16_class_gather_next_to_poison(dev, C):
     n_tab = int(lib.cfm_subsample_conv2_rowtab_elems(B, F1, T1))
     tab = torch.empty(n_tab, device=dev, dtype=torch.int32)
     dw_new = P.like((C, 9 * C))
-    assert lib.cfm_subsample_conv2_bwd_weight_h16_mfma16_f32(1, dzp.data_ptr(), h1p.data_ptr(), tab.data_ptr(), dw_new.data_ptr(),
-                                                             B, F1, T1, C, st) == 0
+    assert lib.cfm_subsample_conv2_bwd_weight_h16_mfma16_f32(1, dzp.data_ptr(), 0, h1p.data_ptr(), tab.data_ptr(), dw_new.data_ptr(),
+                                                             None, B, F1, T1, C, st) == 0
     dw_old = torch.zeros(C, 9 * C, device=dev)
     h1f = h1.to(dev).float()                                # exactly representable: the general kernel's rounding is the identity
     assert lib.cfm_subsample_conv2_bwd_weight_mfma16_f32(1, dzp.data_ptr(), h1f.data_ptr(), dw_old.data_ptr(), B, F1, T1, C, st) == 0
