@@ -284,4 +284,22 @@ def test_stem_backward_bf16_class_gather_next_to_poison(dev, C):
     (out * dz2.double().permute(0, 3, 2, 1)).sum().backward()
     ref_dw = wz.grad.permute(0, 2, 3, 1).reshape(C, 9 * C)               # (co, kf, kt, ci)
     assert rel_l2(dw_new, ref_dw) < 1e-2
+    # ---- 16-bit dz2 (cfm_relu_bwd_out16_f32's output type): both kernels with a 16-bit A operand, bias gradient fused
+    dz16 = P.place(dz2.to(dev).to(torch.bfloat16))
+    dzr = dz16.float()                                      # the same values as fp32: the fp32-A variants round them identically
+    dh1_b, dh1_a = P.like((B, T1, F1, C), fill=float("inf")), torch.empty(B, T1, F1, C, device=dev)
+    assert lib.cfm_subsample_conv2_bwd_input_fwdkernel_mfma16_f32(1, dz16.data_ptr(), 1, w2c16.data_ptr(), zb.data_ptr(),
+                                                                  dh1_b.data_ptr(), B, F1, T1, C, st) == 0
+    assert lib.cfm_subsample_conv2_bwd_input_fwdkernel_mfma16_f32(1, dzr.data_ptr(), 0, w2c16.data_ptr(), zb.data_ptr(),
+                                                                  dh1_a.data_ptr(), B, F1, T1, C, st) == 0
+    dw_b, db_b = P.like((C, 9 * C)), P.like((C,))
+    assert lib.cfm_subsample_conv2_bwd_weight_h16_mfma16_f32(1, dz16.data_ptr(), 1, h1p.data_ptr(), tab.data_ptr(), dw_b.data_ptr(),
+                                                             db_b.data_ptr(), B, F1, T1, C, st) == 0
+    dw_a = torch.zeros(C, 9 * C, device=dev)
+    assert lib.cfm_subsample_conv2_bwd_weight_h16_mfma16_f32(1, dzr.data_ptr(), 0, h1p.data_ptr(), tab.data_ptr(), dw_a.data_ptr(),
+                                                             None, B, F1, T1, C, st) == 0
+    torch.cuda.synchronize()
+    assert P.intact() and torch.isfinite(dh1_b).all() and torch.isfinite(dw_b).all()
+    assert rel_l2(dh1_b, dh1_a) < 1e-5 and rel_l2(dw_b, dw_a) < 1e-4
+    assert rel_l2(db_b, dzr.double().sum(dim=(0, 1, 2)).float()) < 1e-5
 
