@@ -212,7 +212,7 @@ class ConvModuleFn(Function):
         g = ops.glu_fwd(z)
         if train_bn:
             bn_mean, bn_var = ops.dwconv_bn_batch_stats(g, wd, bd, bn_mean, bn_var, momentum)
-        s = ops.dwconv_bn_swish(g, wd, bd, bn_w, bn_b, bn_mean, bn_var, eps_bn)
+        s = ops.dwconv_bn_swish(g, wd, bd, bn_w, bn_b, bn_mean, bn_var, eps_bn, for_gemm=True)
         ctx.drop_p = float(drop_p)
         ctx.seed = ops.new_seeds(1)[0] if ctx.drop_p > 0.0 else 0
         out = ops.linear_train("residual", s, w2, b2, residual=x, alpha=1.0, drop_p=ctx.drop_p, seed=ctx.seed)
@@ -230,7 +230,7 @@ class ConvModuleFn(Function):
         ds, dw2, db2 = ops.linear_bwd(_flat(s), w2, _flat(d2))
         dg, dwd, dbd, dbnw, dbnb = ops.dwconv_bn_swish_bwd(g, ds.view_as(g), wd, bd, bn_w, bn_b, bn_mean, bn_var,
                                                            ctx.eps_bn, ctx.train_bn)
-        dz = ops.glu_bwd(z, dg)
+        dz = ops.glu_bwd(z, dg, for_gemm=True)
         dh0, dw1, db1 = ops.linear_bwd(_flat(h0), w1, _flat(dz))
         dx, dlw, dlb = ops.layernorm_bwd(x, ln_w, dh0.view_as(x), mean, rstd, dres=dout)
         return dx, dlw, dlb, dw1, db1, dwd, dbd, dbnw, dbnb, None, None, dw2, db2, None, None, None, None, None

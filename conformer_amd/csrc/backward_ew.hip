@@ -249,8 +249,10 @@ __global__ __launch_bounds__(256) void glu_fwd_kernel(const float* __restrict__ 
 }
 
 // ---- GLU backward: y = a * sigmoid(g), z = [a | g] (rows, 2n) -> dz (rows, 2n) ----------------------------------------
+// TOUT = float, or a 16-bit matrix-pipe type: dz only feeds the pointwise_conv_1 gradient GEMMs (and its bias gradient).
+template <typename TOUT>
 __global__ __launch_bounds__(256) void glu_bwd_kernel(const float* __restrict__ z, const float* __restrict__ dy,
-                                                      float* __restrict__ dz, int64_t rows, int n) {
+                                                      TOUT* __restrict__ dz, int64_t rows, int n) {
     const int nv = n >> 2;
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= rows * nv) return;
@@ -266,8 +268,13 @@ __global__ __launch_bounds__(256) void glu_bwd_kernel(const float* __restrict__ 
         da[e] = d[e] * sg;
         dg[e] = d[e] * a[e] * sg * (1.0f - sg);
     }
-    *reinterpret_cast<f32x4*>(dz + r * 2 * n + c) = da;
-    *reinterpret_cast<f32x4*>(dz + r * 2 * n + n + c) = dg;
+    if constexpr (sizeof(TOUT) == 4) {
+        *reinterpret_cast<f32x4*>(dz + r * 2 * n + c) = da;
+        *reinterpret_cast<f32x4*>(dz + r * 2 * n + n + c) = dg;
+    } else {
+        *reinterpret_cast<typename Lowp<TOUT>::x4*>(dz + r * 2 * n + c) = Lowp<TOUT>::cvt4(da);
+        *reinterpret_cast<typename Lowp<TOUT>::x4*>(dz + r * 2 * n + n + c) = Lowp<TOUT>::cvt4(dg);
+    }
 }
 
 // ---- depthwise conv + BatchNorm + Swish, backward ---------------------------------------------------------------------
@@ -593,8 +600,22 @@ extern "C" int cfm_glu_bwd_f32(const float* z, const float* dy, float* dz, int64
     CFM_REQUIRE(rows > 0 && n > 0 && (n & 3) == 0, CFM_ERR_BAD_SHAPE);
     CFM_REQUIRE(CFM_ALIGNED16(z) && CFM_ALIGNED16(dy) && CFM_ALIGNED16(dz), CFM_ERR_ALIGN);
     const int64_t total = rows * (n / 4);
-    hipLaunchKernelGGL(glu_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+    hipLaunchKernelGGL(glu_bwd_kernel<float>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
                        static_cast<hipStream_t>(stream), z, dy, dz, rows, n);
+    return cfm_launch_status();
+}
+
+// cfm_glu_bwd_f32 with dz stored in the 16-bit type `prec` (a gradient that only feeds 16-bit GEMM operands)
+extern "C" int cfm_glu_bwd_out16_f32(int prec, const float* z, const float* dy, void* dz16, int64_t rows, int n, cfm_stream_t stream) {
+    CFM_REQUIRE(z && dy && dz16, CFM_ERR_NULL);
+    CFM_REQUIRE(rows > 0 && n > 0 && (n & 3) == 0, CFM_ERR_BAD_SHAPE);
+    CFM_REQUIRE(CFM_ALIGNED16(z) && CFM_ALIGNED16(dy) && (reinterpret_cast<uintptr_t>(dz16) & 7) == 0, CFM_ERR_ALIGN);
+    const int64_t total = rows * (n / 4);
+    const dim3 grid((unsigned)((total + 255) / 256));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (prec == CFM_PREC_BF16) hipLaunchKernelGGL(glu_bwd_kernel<__bf16>, grid, dim3(256), 0, s, z, dy, static_cast<__bf16*>(dz16), rows, n);
+    else if (prec == CFM_PREC_FP16) hipLaunchKernelGGL(glu_bwd_kernel<_Float16>, grid, dim3(256), 0, s, z, dy, static_cast<_Float16*>(dz16), rows, n);
+    else return CFM_ERR_UNSUPPORTED;
     return cfm_launch_status();
 }
 

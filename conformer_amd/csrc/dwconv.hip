@@ -6,11 +6,13 @@
 
 namespace {
 
-template <int K, int TT>
+// TOUT = float, or a 16-bit matrix-pipe type: under autocast the module's output only feeds the pointwise_conv_2 GEMM (and, in
+// training, its weight-gradient GEMM), which round it to that type anyway.
+template <int K, int TT, typename TOUT = float>
 __global__ __launch_bounds__(256) void dwconv_bn_swish_kernel(
     const float* __restrict__ g, const float* __restrict__ w, const float* __restrict__ bias,
     const float* __restrict__ bn_w, const float* __restrict__ bn_b, const float* __restrict__ bn_mean,
-    const float* __restrict__ bn_var, float eps, float* __restrict__ y, int T, int C) {
+    const float* __restrict__ bn_var, float eps, TOUT* __restrict__ y, int T, int C) {
     constexpr int HALF = (K - 1) / 2;
     __shared__ float taps[64 * K];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -35,11 +37,11 @@ __global__ __launch_bounds__(256) void dwconv_bn_swish_kernel(
         for (int j = 0; j < K; ++j) acc[o] = fmaf(wr[j], win[o + j], acc[o]);
     const float inv = 1.0f / sqrtf(bn_var[cc] + eps);
     const float mu = bn_mean[cc], ga = bn_w[cc], be = bn_b[cc];
-    float* yb = y + (int64_t)b * T * C + cc;
+    TOUT* yb = y + (int64_t)b * T * C + cc;
 #pragma unroll
     for (int o = 0; o < TT; ++o) {
         const int t = t0 + o;
-        if (t < T && cok) yb[(int64_t)t * C] = swishf_acc((acc[o] - mu) * inv * ga + be);
+        if (t < T && cok) yb[(int64_t)t * C] = (TOUT)swishf_acc((acc[o] - mu) * inv * ga + be);
     }
 }
 
@@ -90,3 +92,25 @@ extern "C" int cfm_dwconv_bn_swish_fwd_f32(const float* g, const float* w, const
 #undef DW_LAUNCH
     return cfm_launch_status();
 }
+
+// cfm_dwconv_bn_swish_fwd_f32 with y stored in the 16-bit type `prec` (K in {3, 7, 15, 31}; CFM_ERR_UNSUPPORTED otherwise).
+extern "C" int cfm_dwconv_bn_swish_fwd_out16_f32(int prec, const float* g, const float* w, const float* bias,
+                                                 const float* bn_weight, const float* bn_bias, const float* bn_mean,
+                                                 const float* bn_var, float bn_eps, void* y16, int B, int T, int C, int K,
+                                                 cfm_stream_t stream) {
+    CFM_REQUIRE(g && w && bias && bn_weight && bn_bias && bn_mean && bn_var && y16, CFM_ERR_NULL);
+    CFM_REQUIRE(B > 0 && T > 0 && C > 0, CFM_ERR_BAD_SHAPE);
+    CFM_REQUIRE(K == 31 || K == 15 || K == 7 || K == 3, CFM_ERR_UNSUPPORTED);
+    CFM_REQUIRE(prec == CFM_PREC_BF16 || prec == CFM_PREC_FP16, CFM_ERR_UNSUPPORTED);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    constexpr int TT = 16;
+    const dim3 grid((unsigned)((C + 63) / 64), (unsigned)((T + 4 * TT - 1) / (4 * TT)), (unsigned)B), block(256);
+#define DW16(KK, TY) hipLaunchKernelGGL((dwconv_bn_swish_kernel<KK, TT, TY>), grid, block, 0, s, g, w, bias, bn_weight, bn_bias, \
+                                        bn_mean, bn_var, bn_eps, static_cast<TY*>(y16), T, C)
+#define DW16K(TY) switch (K) { case 31: DW16(31, TY); break; case 15: DW16(15, TY); break; case 7: DW16(7, TY); break; default: DW16(3, TY); }
+    if (prec == CFM_PREC_BF16) { DW16K(__bf16) } else { DW16K(_Float16) }
+#undef DW16K
+#undef DW16
+    return cfm_launch_status();
+}
+

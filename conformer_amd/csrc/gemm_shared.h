@@ -219,7 +219,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const f32x16 (&
 // GEMM of the training step (128x128 tiles, Z saved) showed 1.2-1.6 us per K-tile, 10 us for the whole K-loop -- and 17-30 us
 // for the epilogue: all co-resident workgroups reach it together and their 32-byte write fragments (96 KB per tile) run at a
 // fraction of the HBM write rate.  scratch: per-wave, 32 * (32*TN + 4) floats, 16-byte aligned.
-template <int BM, int BN, int EPI, int TM, int TN, int WM = 2>
+// CLS: the rows are transposed-conv class rows (CONV == 2) and are scattered to their dh1 positions.  A TEMPLATE flag: as a run-time
+// test of g.pA the (skipped) 64-bit divisions were still unrolled into every kernel's epilogue -- 60 % more code in the 256x256
+// kernels, which ran 12-20 % slower from instruction-cache misses alone.
+template <int BM, int BN, int EPI, int TM, int TN, int WM = 2, bool CLS = false>
 __device__ __forceinline__ void gemm_epilogue_rows(const GemmArgs& g, const f32x16 (&acc)[TM][TN], int64_t m0, int n0,
                                                    int wr, int wc, int lane, float* scratch) {
     static_assert(EPI != EPI_GLU, "GLU pairs value and gate tiles: use gemm_epilogue");
@@ -250,9 +253,10 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmArgs& g, const f32x
             const f32x4 v = *reinterpret_cast<const f32x4*>(scratch + rl * P + c4);
             const int64_t row = m0 + wr * (BM / WM) + mt * 32 + rl;
             int64_t crow = row;
-            if (g.pA > 0 && row < g.M) {                                // CONV == 2: class row (b, a, c) -> dh1 position (b, 2a+pt, 2c+pf)
+            if constexpr (CLS) {                                        // class row (b, a, c) -> dh1 position (b, 2a+pt, 2c+pf)
+                const int64_t rr = min(row, g.M - 1);
                 const int per = g.pA * g.pC;
-                const int b = (int)(row / per), r = (int)(row - (int64_t)b * per);
+                const int b = (int)(rr / per), r = (int)(rr - (int64_t)b * per);
                 const int a = r / g.pC, c = r - a * g.pC;
                 crow = ((int64_t)b * g.cT1 + 2 * a + g.pt) * g.cF1 + 2 * c + g.pf;
             }

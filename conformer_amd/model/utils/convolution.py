@@ -50,7 +50,7 @@ class ConvolutionModule(nn.Module):
                                                bn.running_var, bn.momentum)
             bn.num_batches_tracked += 1
             s = ops.dwconv_bn_swish(g, self.deepwise_conv.weight, self.deepwise_conv.bias, bn.weight, bn.bias, bm, bv,
-                                    bn.eps)
+                                    bn.eps, for_gemm=True)
             if residual is None:
                 return ops.linear(s, self.pointwise_conv_2.weight, self.pointwise_conv_2.bias)
             return ops.linear_residual(s, self.pointwise_conv_2.weight, self.pointwise_conv_2.bias, residual, 1.0)
@@ -69,7 +69,7 @@ class ConvolutionModule(nn.Module):
         h = ops.layernorm(x, self.layer_norm.weight, self.layer_norm.bias, self.layer_norm.eps, for_gemm=True)
         g = ops.linear_glu(h, self.pointwise_conv_1.weight, self.pointwise_conv_1.bias)
         s = ops.dwconv_bn_swish(g, self.deepwise_conv.weight, self.deepwise_conv.bias, bn.weight, bn.bias,
-                                bn.running_mean, bn.running_var, bn.eps)
+                                bn.running_mean, bn.running_var, bn.eps, for_gemm=True)
         if residual is None:
             return ops.linear(s, self.pointwise_conv_2.weight, self.pointwise_conv_2.bias)
         return ops.linear_residual(s, self.pointwise_conv_2.weight, self.pointwise_conv_2.bias, residual, 1.0)

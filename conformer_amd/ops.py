@@ -388,10 +388,20 @@ def relpos_attention_rows(qkv: torch.Tensor, pos: torch.Tensor, u: torch.Tensor,
     return ctx
 
 
-def dwconv_bn_swish(g, w, b, bn_w, bn_b, bn_mean, bn_var, eps: float = 1e-5) -> torch.Tensor:
+def dwconv_bn_swish(g, w, b, bn_w, bn_b, bn_mean, bn_var, eps: float = 1e-5, for_gemm: bool = False) -> torch.Tensor:
+    """for_gemm: see layernorm (the result feeds the pointwise_conv_2 GEMM of contraction length C)."""
     g = _req(g, "g"); w = _req(w, "dw weight"); b = _req(b, "dw bias")
     B, T, C = g.shape
     K = w.shape[-1]
+    p16 = out16_ok(C) if for_gemm and K in (3, 7, 15, 31) else 0
+    if p16:
+        y = torch.empty(g.shape, device=g.device, dtype=_DT16[p16])
+        st = _lib.load().cfm_dwconv_bn_swish_fwd_out16_f32(p16, g.data_ptr(), w.data_ptr(), b.data_ptr(), _req(bn_w, "bn_w").data_ptr(),
+                                                           _req(bn_b, "bn_b").data_ptr(), _req(bn_mean, "bn_mean").data_ptr(),
+                                                           _req(bn_var, "bn_var").data_ptr(), eps, y.data_ptr(), B, T, C, K,
+                                                           _stream())
+        _lib.check(st, "cfm_dwconv_bn_swish_fwd_out16_f32")
+        return y
     y = torch.empty_like(g)
     st = _lib.load().cfm_dwconv_bn_swish_fwd_f32(g.data_ptr(), w.data_ptr(), b.data_ptr(), _req(bn_w, "bn_w").data_ptr(),
                                                  _req(bn_b, "bn_b").data_ptr(), _req(bn_mean, "bn_mean").data_ptr(),
@@ -631,10 +641,17 @@ def glu_fwd(z):
     return y
 
 
-def glu_bwd(z, dy):
+def glu_bwd(z, dy, for_gemm: bool = False):
+    """for_gemm: dz only feeds the pointwise_conv_1 gradient GEMMs: under autocast it is written in the 16-bit type."""
     z = _req(z, "z"); dy = _req(dy, "dy")
     n = dy.shape[-1]
     rows = dy.numel() // n
+    p16 = out16_ok(2 * n) if for_gemm else 0
+    if p16:
+        dz = torch.empty(z.shape, device=z.device, dtype=_DT16[p16])
+        _lib.check(_lib.load().cfm_glu_bwd_out16_f32(p16, z.data_ptr(), dy.data_ptr(), dz.data_ptr(), rows, n, _stream()),
+                   "cfm_glu_bwd_out16_f32")
+        return dz
     dz = torch.empty_like(z)
     _lib.check(_lib.load().cfm_glu_bwd_f32(z.data_ptr(), dy.data_ptr(), dz.data_ptr(), rows, n, _stream()),
                "cfm_glu_bwd_f32")

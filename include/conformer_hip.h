@@ -182,6 +182,12 @@ int64_t cfm_subsample_conv2_rowtab_elems(int B, int F1, int T1);
 int cfm_subsample_conv2_bwd_weight_h16_mfma16_f32(int prec, const void* dz2, int dz2_is_16bit, const void* h1_16,
                                                   int* rowtab_scratch, float* dw2p, float* db2_or_null, int B, int F1, int T1,
                                                   int C, cfm_stream_t stream);
+/* 16-bit-output forms of producers whose results only feed 16-bit GEMM operands under autocast (identical results, half the
+ * bytes): the conv module's depthwise-conv + BatchNorm + Swish output (K in {3,7,15,31}) and the GLU backward. */
+int cfm_dwconv_bn_swish_fwd_out16_f32(int prec, const float* g, const float* w, const float* bias, const float* bn_weight,
+                                      const float* bn_bias, const float* bn_mean, const float* bn_var, float bn_eps,
+                                      void* y16, int B, int T, int C, int K, cfm_stream_t stream);
+int cfm_glu_bwd_out16_f32(int prec, const float* z, const float* dy, void* dz16, int64_t rows, int n, cfm_stream_t stream);
 /* ReLU backward with the result stored in `prec` (cfm_relu_bwd_f32 otherwise). */
 int cfm_relu_bwd_out16_f32(int prec, const float* y, const float* dy, void* dz16, int64_t n, cfm_stream_t stream);
 /* Input gradient of the stem's conv2 on the forward 16-bit GEMM kernel (four parity-class implicit GEMMs with a per-row
