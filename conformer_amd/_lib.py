@@ -85,6 +85,7 @@ SIGNATURES = {
     "cfm_debug_dw16_trace": (c_int, [_P]),
     "cfm_linear_bwd_weight_mfma16_f32": (c_int, [_I, _P, _I, _L, _P, _I, _L, _P, _L, _P, _I, _I, _L, _F, _P]),
     "cfm_lstm_fwd_mfma16_f32": (c_int, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "cfm_lstm_bwd_mfma16_f32": (c_int, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "cfm_lstm_bwd_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "cfm_swish_bn_eval_f32": (c_int, [_P, _P, _P, _P, _P, _F, _P, _L, _I, _P]),
     "cfm_swish_bn_stats_f32": (c_int, [_P, _P, _P, _P, _P, _F, _L, _I, _P]),

@@ -942,7 +942,9 @@ def lstm_forward(x, w_ih, w_hh, bias, lengths=None, save: bool = False):
     if w16 is not None:
         # under autocast the recurrent product runs on the 16-bit matrix pipe too (what autocast does to nn.LSTM on a GPU);
         # gate math, cell state and all stored tensors stay fp32
-        h16 = torch.empty(2, B, H, device=x.device, dtype=_DT16[prec])
+        h16 = torch.empty(2 * ((B + 31) // 32) * 32 * H, device=x.device, dtype=_DT16[prec])
+        # W_hh in MFMA fragment order (H/8, H/16, 2, 32, 8): one contiguous 1 KB block per workgroup and contraction step
+        w16 = w16.view(4, H // 8, 8, H // 16, 2, 8).permute(1, 3, 4, 0, 2, 5).contiguous()
         _lib.check(_lib.load().cfm_lstm_fwd_mfma16_f32(prec, gx.data_ptr(), w16.data_ptr(), _p(lengths), y.data_ptr(), c.data_ptr(),
                                                        h16.data_ptr(), _p(gates), _p(cells), B, T, H, _stream()),
                    "cfm_lstm_fwd_mfma16_f32")
@@ -973,10 +975,18 @@ def lstm_backward(x, w_ih, w_hh, y, gates, cells, dy, lengths=None, need_dx: boo
     dG = torch.empty(B, T, 4 * H, device=x.device, dtype=x.dtype)
     dc = torch.empty(B, H, device=x.device, dtype=x.dtype)
     prec = mfma16_prec()
-    # (fp32 recurrence also under autocast: the 16-bit forms of this step measured slower, see csrc/lstm_mfma16.hip)
-    whh_t = w_hh.t().contiguous()                                     # (H,4H): 6.5 MB of glue per step
-    _lib.check(lib.cfm_lstm_bwd_f32(dy.data_ptr(), gates.data_ptr(), cells.data_ptr(), whh_t.data_ptr(), _p(lengths),
-                                    dG.data_ptr(), dc.data_ptr(), B, T, H, _stream()), "cfm_lstm_bwd_f32")
+    wt16 = weight16(w_hh, prec, transposed=True) if prec and H % 16 == 0 else None
+    if wt16 is not None:
+        # W_hh^T (H,4H) in MFMA fragment order (H/16, 4H/16, 2, 16, 8); dG_t exchanged between steps in the same order
+        wt16 = wt16.view(H // 16, 16, 4 * H // 16, 2, 8).permute(0, 2, 3, 1, 4).contiguous()
+        dg16 = torch.empty(2 * ((B + 15) // 16) * 16 * 4 * H, device=x.device, dtype=_DT16[prec])
+        _lib.check(lib.cfm_lstm_bwd_mfma16_f32(prec, dy.data_ptr(), gates.data_ptr(), cells.data_ptr(), wt16.data_ptr(), _p(lengths),
+                                               dG.data_ptr(), dc.data_ptr(), dg16.data_ptr(), B, T, H, _stream()),
+                   "cfm_lstm_bwd_mfma16_f32")
+    else:
+        whh_t = w_hh.t().contiguous()                                 # (H,4H): 6.5 MB of glue per step
+        _lib.check(lib.cfm_lstm_bwd_f32(dy.data_ptr(), gates.data_ptr(), cells.data_ptr(), whh_t.data_ptr(), _p(lengths),
+                                        dG.data_ptr(), dc.data_ptr(), B, T, H, _stream()), "cfm_lstm_bwd_f32")
     dG2, x2 = dG.view(B * T, 4 * H), x.reshape(B * T, D)
     h_prev = torch.zeros_like(y)                                      # h_{t-1}: y shifted by one frame per utterance
     h_prev[:, 1:] = y[:, :-1]

@@ -378,9 +378,13 @@ int cfm_lstm_bwd_f32(const float* dy, const float* gates, const float* cells, co
                      cfm_stream_t stream);
 /* cfm_lstm_fwd_f32 with the recurrent product h.W_hh^T on the 16-bit matrix pipe -- what torch.autocast does to nn.LSTM
  * on a GPU (reference decoder.py:10,17-22 under train.py:232).  w_hh16 (4H,H): 16-bit copy of W_hh (cfm_cast16_f32);
- * h16_scratch: 2*B*H 16-bit elements.  H % 16 == 0.  (The backward uses cfm_lstm_bwd_f32: see lstm_mfma16.hip.) */
+ * h16_scratch: 2*B*H 16-bit elements.  H % 16 == 0.  The backward form takes whh_t16 (H,4H) = the 16-bit transpose and
+ * dg16_scratch: 2*B*4H 16-bit elements. */
 int cfm_lstm_fwd_mfma16_f32(int prec, const float* gates_x, const void* w_hh16, const int64_t* lengths_or_null, float* y,
                             float* c_state, void* h16_scratch, float* save_gates_or_null, float* save_c_or_null, int B,
+                            int T, int H, cfm_stream_t stream);
+int cfm_lstm_bwd_mfma16_f32(int prec, const float* dy, const float* gates, const float* cells, const void* whh_t16,
+                            const int64_t* lengths_or_null, float* dgates, float* dc_state, void* dg16_scratch, int B,
                             int T, int H, cfm_stream_t stream);
 int cfm_swish_bn_eval_f32(const float* h, const float* bn_mean, const float* bn_var, const float* bn_weight,
                           const float* bn_bias, float eps, float* out, int64_t rows, int C, cfm_stream_t stream);

@@ -36,14 +36,16 @@ def main():
     # the 16-bit recurrence (lstm_mfma16.hip): forward and backward per-step time
     for B, H, T in [(64, 640, 249), (32, 640, 249)]:
         gx = torch.randn(B, T, 4 * H, device=dev); w_hh = (torch.randn(4 * H, H, device=dev) * 0.05)
-        w16, wt16 = w_hh.to(torch.bfloat16), w_hh.t().contiguous().to(torch.bfloat16)
+        w16 = w_hh.to(torch.bfloat16).view(4, H // 8, 8, H // 16, 2, 8).permute(1, 3, 4, 0, 2, 5).contiguous()
+        wt16 = w_hh.t().contiguous().to(torch.bfloat16).view(H // 16, 16, 4 * H // 16, 2, 8).permute(0, 2, 3, 1, 4).contiguous()
         y = torch.empty(B, T, H, device=dev); c = torch.empty(B, H, device=dev)
-        h16 = torch.empty(2, B, H, device=dev, dtype=torch.bfloat16)
+        h16 = torch.empty(2 * ((B + 31) // 32) * 32 * H, device=dev, dtype=torch.bfloat16); dg16 = torch.empty(2 * ((B + 15) // 16) * 16 * 4 * H, device=dev, dtype=torch.bfloat16)
         gates = torch.rand(B, T, 4 * H, device=dev); cells = torch.randn(B, T, H, device=dev); dy = torch.randn(B, T, H, device=dev)
         dG = torch.empty(B, T, 4 * H, device=dev); dc = torch.empty(B, H, device=dev)
         wt32 = w_hh.t().contiguous()
         st = torch.cuda.current_stream().cuda_stream
         fns = {"fwd 16-bit": lambda: lib.cfm_lstm_fwd_mfma16_f32(1, gx.data_ptr(), w16.data_ptr(), None, y.data_ptr(), c.data_ptr(), h16.data_ptr(), None, None, B, T, H, st),
+               "bwd 16-bit": lambda: lib.cfm_lstm_bwd_mfma16_f32(1, dy.data_ptr(), gates.data_ptr(), cells.data_ptr(), wt16.data_ptr(), None, dG.data_ptr(), dc.data_ptr(), dg16.data_ptr(), B, T, H, st),
                "fwd fp32": lambda: lib.cfm_lstm_fwd_f32(gx.data_ptr(), w_hh.data_ptr(), None, y.data_ptr(), c.data_ptr(), None, None, B, T, H, st),
                "bwd fp32": lambda: lib.cfm_lstm_bwd_f32(dy.data_ptr(), gates.data_ptr(), cells.data_ptr(), wt32.data_ptr(), None, dG.data_ptr(), dc.data_ptr(), B, T, H, st)}
         for name, fn in fns.items():
