@@ -81,6 +81,8 @@ SIGNATURES = {
     "cfm_adam_step_f32": (c_int, [_P, _I, _F, _F, _F, _F, _F, _F, _P]),
     "cfm_greedy_ctc_decode_f32": (c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "cfm_lstm_fwd_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "cfm_lstm_fwd_frag_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "cfm_lstm_bwd_frag_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "cfm_debug_lstm_trace": (c_int, [_P]),
     "cfm_debug_dw16_trace": (c_int, [_P]),
     "cfm_linear_bwd_weight_mfma16_f32": (c_int, [_I, _P, _I, _L, _P, _I, _L, _P, _L, _P, _I, _I, _L, _F, _P]),

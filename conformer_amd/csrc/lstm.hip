@@ -24,13 +24,19 @@ struct LstmArgs {
     float* save_gates;            // (B, T, 4H) post-activation i|f|g|o, or null
     float* save_c;                // (B, T, H)  c_t, or null
     int B, T, H;
+    float* hfrag;                 // FRAG kernels: 2 x (16-utterance blocks) x H, h_t in operand-fragment order (double buffer)
     unsigned long long* trace;    // diagnostics: s_memrealtime stamps (8 per step) of thread 0 of workgroups (0,0) and (last,last)
 };
 
 __device__ __forceinline__ float sigmoid_precise(float x) { return 1.0f / (1.0f + __expf(-x)); }
 __device__ __forceinline__ float tanh_precise(float x) { return 1.0f - 2.0f / (__expf(2.0f * x) + 1.0f); }
 
-template <int RB>                 // 16-row blocks of utterances per workgroup
+// FRAG: both contraction operands are stored in the order the MFMA lanes consume them -- per 16-wide chunk of the
+// contraction a [kq 4][row 16][4 floats] block, so that a wave's 16-byte-per-lane load is ONE contiguous 1 KB run instead
+// of 16 rows x 64 B at a row stride (the step is bound by memory round trips, and a load that touches 16 lines completes
+// later than one that touches 8 consecutive ones).  W_hh is re-ordered by the caller once per call; h_t is written in
+// that order by the gate stage into a double buffer (a.hfrag) next to the row-major output y.  Needs H % 16 == 0.
+template <int RB, bool FRAG>      // 16-row blocks of utterances per workgroup
 __global__ __launch_bounds__(256) void lstm_step_kernel(const LstmArgs a, const int t) {
     __shared__ float part[4][RB * 16][17];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -59,7 +65,34 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(const LstmArgs a, const 
     f32x4 acc[RB];
 #pragma unroll
     for (int r = 0; r < RB; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (t > 0) {
+    if (FRAG && t > 0) {
+        const int nchunk = H >> 4;
+        const float* wf = a.whh + ((int64_t)blockIdx.x * nchunk) * 256 + lane * 4;
+        const float* hf[RB];
+        const int64_t hpar = (int64_t)((t - 1) & 1) * gridDim.y * RB * 16 * H;
+#pragma unroll
+        for (int r = 0; r < RB; ++r) hf[r] = a.hfrag + hpar + ((int64_t)(blockIdx.y * RB + r) * nchunk) * 256 + lane * 4;
+        constexpr int NBAT = 5;
+        for (int c0 = wave; c0 < nchunk; c0 += 4 * NBAT) {
+            f32x4 wv[NBAT], hv[NBAT][RB];
+#pragma unroll
+            for (int j = 0; j < NBAT; ++j) {
+                const int ch = min(c0 + 4 * j, nchunk - 1);
+                wv[j] = *reinterpret_cast<const f32x4*>(wf + ch * 256);
+#pragma unroll
+                for (int r = 0; r < RB; ++r) hv[j][r] = *reinterpret_cast<const f32x4*>(hf[r] + ch * 256);
+            }
+#pragma unroll
+            for (int j = 0; j < NBAT; ++j) {
+                const f32x4 w = c0 + 4 * j < nchunk ? wv[j] : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int r = 0; r < RB; ++r) acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(hv[j][r][e], w[e], acc[r], 0, 0, 0);
+            }
+        }
+    }
+    if (!FRAG && t > 0) {
         // B operand: column l16 = gate q (l16 >> 2), unit u0 + (l16 & 3)  ->  W_hh row q*H + unit
         // (columns of units >= H and rows of utterances >= B are computed on clamped addresses and never read back)
         const float* wrow = a.whh + ((int64_t)(l16 >> 2) * H + min(u0 + (l16 & 3), H - 1)) * H;
@@ -100,8 +133,13 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(const LstmArgs a, const 
     LSTM_STAMP(3);
     if (!mine) return;
     float* yo = a.y + ((int64_t)b * a.T + t) * H + unit;
+    // fragment-order slot of h_t[b][unit]: block (utterance block, unit >> 4), lane (kq = (unit >> 2) & 3, row b & 15), float unit & 3
+    float* hfo = FRAG ? a.hfrag + (int64_t)(t & 1) * gridDim.y * RB * 16 * H + ((int64_t)(b >> 4) * (H >> 4) + (unit >> 4)) * 256 +
+                            ((((unit >> 2) & 3) * 16 + (b & 15)) * 4 + (unit & 3))
+                      : nullptr;
     if (!live) {                                           // beyond the utterance: zero output, state frozen
         *yo = 0.f;
+        if (FRAG) *hfo = 0.f;
         if (a.save_c) a.save_c[((int64_t)b * a.T + t) * H + unit] = cprev;
         if (a.save_gates) {
             float* sg = a.save_gates + ((int64_t)b * a.T + t) * 4 * H + unit;
@@ -115,9 +153,11 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(const LstmArgs a, const 
         pre[q] = gxv[q] + ((part[0][bl][4 * q + u] + part[1][bl][4 * q + u]) + (part[2][bl][4 * q + u] + part[3][bl][4 * q + u]));
     const float ig = sigmoid_precise(pre[0]), fg = sigmoid_precise(pre[1]), gg = tanh_precise(pre[2]),
                 og = sigmoid_precise(pre[3]);
-    const float cn = fg * cprev + ig * gg;
+    const float cn = fmaf(fg, cprev, ig * gg);             // explicit: the same contraction in every instantiation
     a.c[(int64_t)b * H + unit] = cn;
-    *yo = og * tanh_precise(cn);
+    const float hn = og * tanh_precise(cn);
+    *yo = hn;
+    if (FRAG) *hfo = hn;
     if (a.save_c) a.save_c[((int64_t)b * a.T + t) * H + unit] = cn;
     if (a.save_gates) {
         float* sg = a.save_gates + ((int64_t)b * a.T + t) * 4 * H + unit;
@@ -143,9 +183,10 @@ struct LstmBwdArgs {
     float* dgates;                // (B, T, 4H) out
     float* dc;                    // (B, H) running dc_next, in place
     int B, T, H;
+    float* dgfrag;                // FRAG kernels: 2 x (16-utterance blocks) x 4H, dG_t in operand-fragment order (double buffer)
 };
 
-template <int RB>
+template <int RB, bool FRAG>      // FRAG: dG_{t+1} and W_hh^T in operand-fragment order (see the forward)
 __global__ __launch_bounds__(512) void lstm_bwd_step_kernel(const LstmBwdArgs a, const int t) {
     __shared__ float part[8][RB * 16][17];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -172,7 +213,34 @@ __global__ __launch_bounds__(512) void lstm_bwd_step_kernel(const LstmBwdArgs a,
     f32x4 acc[RB];
 #pragma unroll
     for (int r = 0; r < RB; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (t + 1 < a.T) {
+    if (FRAG && t + 1 < a.T) {
+        const int nchunk = H4 >> 4;
+        const float* wf = a.whh_t + ((int64_t)blockIdx.x * nchunk) * 256 + lane * 4;
+        const float* gf[RB];
+        const int64_t gpar = (int64_t)((t + 1) & 1) * gridDim.y * RB * 16 * H4;
+#pragma unroll
+        for (int r = 0; r < RB; ++r) gf[r] = a.dgfrag + gpar + ((int64_t)(blockIdx.y * RB + r) * nchunk) * 256 + lane * 4;
+        constexpr int NBAT = 5;
+        for (int c0 = wave; c0 < nchunk; c0 += 8 * NBAT) {
+            f32x4 wv[NBAT], gv[NBAT][RB];
+#pragma unroll
+            for (int j = 0; j < NBAT; ++j) {
+                const int ch = min(c0 + 8 * j, nchunk - 1);
+                wv[j] = *reinterpret_cast<const f32x4*>(wf + ch * 256);
+#pragma unroll
+                for (int r = 0; r < RB; ++r) gv[j][r] = *reinterpret_cast<const f32x4*>(gf[r] + ch * 256);
+            }
+#pragma unroll
+            for (int j = 0; j < NBAT; ++j) {
+                const f32x4 w = c0 + 8 * j < nchunk ? wv[j] : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int r = 0; r < RB; ++r) acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(gv[j][r][e], w[e], acc[r], 0, 0, 0);
+            }
+        }
+    }
+    if (!FRAG && t + 1 < a.T) {
         // (columns of units >= H and rows of utterances >= B are computed on clamped addresses and never read back)
         const float* wrow = a.whh_t + (int64_t)min(u0 + l16, H - 1) * H4;
         const float* grow[RB];
@@ -206,8 +274,20 @@ __global__ __launch_bounds__(512) void lstm_bwd_step_kernel(const LstmBwdArgs a,
     __syncthreads();
     if (!mine) return;
     float* dg = a.dgates + bt * H4 + unit;
+    // fragment-order slots of dG_t[b][q*H + unit]: row r = q*H + unit -> block (utterance block, r >> 4), lane ((r >> 2) & 3, b & 15), float r & 3
+    float* dgf = nullptr;
+    int fo[4] = {0, 0, 0, 0};
+    if (FRAG) {
+        dgf = a.dgfrag + (int64_t)(t & 1) * gridDim.y * RB * 16 * H4 + (int64_t)(b >> 4) * (H4 >> 4) * 256 + (b & 15) * 4;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int r = q * H + unit;
+            fo[q] = (r >> 4) * 256 + ((r >> 2) & 3) * 64 + (r & 3);
+        }
+    }
     if (!live) {
         dg[0] = 0.f; dg[H] = 0.f; dg[2 * H] = 0.f; dg[3 * H] = 0.f;
+        if (FRAG) { dgf[fo[0]] = 0.f; dgf[fo[1]] = 0.f; dgf[fo[2]] = 0.f; dgf[fo[3]] = 0.f; }
         a.dc[(int64_t)b * H + unit] = 0.f;
         return;
     }
@@ -215,11 +295,11 @@ __global__ __launch_bounds__(512) void lstm_bwd_step_kernel(const LstmBwdArgs a,
 #pragma unroll
     for (int w = 0; w < 8; ++w) dh += part[w][bl][u];
     const float th = tanh_precise(ct);
-    const float dct = dh * og * (1.0f - th * th) + dcn;
-    dg[0] = dct * gg * ig * (1.0f - ig);
-    dg[H] = dct * cprev * fg * (1.0f - fg);
-    dg[2 * H] = dct * ig * (1.0f - gg * gg);
-    dg[3 * H] = dh * th * og * (1.0f - og);
+    const float dct = fmaf(dh * og, fmaf(-th, th, 1.0f), dcn);   // explicit contractions: identical in every instantiation
+    const float d0 = dct * gg * ig * (1.0f - ig), d1 = dct * cprev * fg * (1.0f - fg), d2 = dct * ig * fmaf(-gg, gg, 1.0f),
+                d3 = dh * th * og * (1.0f - og);
+    dg[0] = d0; dg[H] = d1; dg[2 * H] = d2; dg[3 * H] = d3;
+    if (FRAG) { dgf[fo[0]] = d0; dgf[fo[1]] = d1; dgf[fo[2]] = d2; dgf[fo[3]] = d3; }
     a.dc[(int64_t)b * H + unit] = dct * fg;
 }
 
@@ -345,10 +425,28 @@ extern "C" int cfm_lstm_fwd_f32(const float* gates_x, const float* w_hh, const i
     CFM_REQUIRE(gates_x && w_hh && y && c_state, CFM_ERR_NULL);
     CFM_REQUIRE(B > 0 && T > 0 && H > 0 && (H & 3) == 0, CFM_ERR_BAD_SHAPE);
     CFM_REQUIRE(CFM_ALIGNED16(w_hh) && CFM_ALIGNED16(y), CFM_ERR_ALIGN);
-    const LstmArgs a{gates_x, w_hh, lengths_or_null, y, c_state, save_gates_or_null, save_c_or_null, B, T, H, g_lstm_trace};
+    const LstmArgs a{gates_x, w_hh, lengths_or_null, y, c_state, save_gates_or_null, save_c_or_null, B, T, H, nullptr, g_lstm_trace};
     hipStream_t s = static_cast<hipStream_t>(stream);
     const dim3 grid((unsigned)(H / 4), (unsigned)((B + 15) / 16));
-    for (int t = 0; t < T; ++t) hipLaunchKernelGGL(lstm_step_kernel<1>, grid, dim3(256), 0, s, a, t);
+    for (int t = 0; t < T; ++t) hipLaunchKernelGGL((lstm_step_kernel<1, false>), grid, dim3(256), 0, s, a, t);
+    return cfm_launch_status();
+}
+
+// cfm_lstm_fwd_f32 with both recurrence operands in MFMA-fragment order (H % 16 == 0): w_hh_frag = W_hh re-ordered to
+// [H/4 unit blocks][H/16 chunks][kq 4][gate q 4][unit 4][4 floats]  (element W_hh[q*H + 4*ub + u][16*ch + 4*kq + e]);
+// h_frag_scratch: 2 * ceil(B/16)*16 * H floats (need not be initialised).  Same results as cfm_lstm_fwd_f32 bit for bit
+// (same products, same summation order).
+extern "C" int cfm_lstm_fwd_frag_f32(const float* gates_x, const float* w_hh_frag, const int64_t* lengths_or_null, float* y,
+                                     float* c_state, float* h_frag_scratch, float* save_gates_or_null, float* save_c_or_null,
+                                     int B, int T, int H, cfm_stream_t stream) {
+    CFM_REQUIRE(gates_x && w_hh_frag && y && c_state && h_frag_scratch, CFM_ERR_NULL);
+    CFM_REQUIRE(B > 0 && T > 0 && H > 0 && (H & 15) == 0, CFM_ERR_BAD_SHAPE);
+    CFM_REQUIRE(CFM_ALIGNED16(w_hh_frag) && CFM_ALIGNED16(h_frag_scratch), CFM_ERR_ALIGN);
+    const LstmArgs a{gates_x, w_hh_frag, lengths_or_null, y, c_state, save_gates_or_null, save_c_or_null, B, T, H, h_frag_scratch,
+                     g_lstm_trace};
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const dim3 grid((unsigned)(H / 4), (unsigned)((B + 15) / 16));
+    for (int t = 0; t < T; ++t) hipLaunchKernelGGL((lstm_step_kernel<1, true>), grid, dim3(256), 0, s, a, t);
     return cfm_launch_status();
 }
 
@@ -361,11 +459,27 @@ extern "C" int cfm_lstm_bwd_f32(const float* dy, const float* gates, const float
     CFM_REQUIRE(dy && gates && cells && whh_t && dgates && dc_state, CFM_ERR_NULL);
     CFM_REQUIRE(B > 0 && T > 0 && H > 0 && (H & 3) == 0, CFM_ERR_BAD_SHAPE);
     CFM_REQUIRE(CFM_ALIGNED16(whh_t) && CFM_ALIGNED16(dgates), CFM_ERR_ALIGN);
-    const LstmBwdArgs a{dy, gates, cells, whh_t, lengths_or_null, dgates, dc_state, B, T, H};
+    const LstmBwdArgs a{dy, gates, cells, whh_t, lengths_or_null, dgates, dc_state, B, T, H, nullptr};
     hipStream_t s = static_cast<hipStream_t>(stream);
     // 16 utterances x 16 hidden units per workgroup: the step is latency-bound, so more, smaller workgroups win
     const dim3 grid((unsigned)((H + 15) / 16), (unsigned)((B + 15) / 16));
-    for (int t = T - 1; t >= 0; --t) hipLaunchKernelGGL(lstm_bwd_step_kernel<1>, grid, dim3(512), 0, s, a, t);
+    for (int t = T - 1; t >= 0; --t) hipLaunchKernelGGL((lstm_bwd_step_kernel<1, false>), grid, dim3(512), 0, s, a, t);
+    return cfm_launch_status();
+}
+
+// cfm_lstm_bwd_f32 with both operands of the recurrent product in MFMA-fragment order (H % 16 == 0): whh_t_frag = W_hh^T
+// re-ordered to [H/16 unit blocks][4H/16 chunks][kq 4][unit 16][4 floats]  (element W_hh^T[16*ub + u][16*ch + 4*kq + e]);
+// dg_frag_scratch: 2 * ceil(B/16)*16 * 4H floats.  Same results as cfm_lstm_bwd_f32 bit for bit.
+extern "C" int cfm_lstm_bwd_frag_f32(const float* dy, const float* gates, const float* cells, const float* whh_t_frag,
+                                     const int64_t* lengths_or_null, float* dgates, float* dc_state, float* dg_frag_scratch,
+                                     int B, int T, int H, cfm_stream_t stream) {
+    CFM_REQUIRE(dy && gates && cells && whh_t_frag && dgates && dc_state && dg_frag_scratch, CFM_ERR_NULL);
+    CFM_REQUIRE(B > 0 && T > 0 && H > 0 && (H & 15) == 0, CFM_ERR_BAD_SHAPE);
+    CFM_REQUIRE(CFM_ALIGNED16(whh_t_frag) && CFM_ALIGNED16(dg_frag_scratch), CFM_ERR_ALIGN);
+    const LstmBwdArgs a{dy, gates, cells, whh_t_frag, lengths_or_null, dgates, dc_state, B, T, H, dg_frag_scratch};
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const dim3 grid((unsigned)(H / 16), (unsigned)((B + 15) / 16));
+    for (int t = T - 1; t >= 0; --t) hipLaunchKernelGGL((lstm_bwd_step_kernel<1, true>), grid, dim3(512), 0, s, a, t);
     return cfm_launch_status();
 }
 

@@ -949,6 +949,15 @@ def lstm_forward(x, w_ih, w_hh, bias, lengths=None, save: bool = False):
                                                        h16.data_ptr(), _p(gates), _p(cells), B, T, H, _stream()),
                    "cfm_lstm_fwd_mfma16_f32")
         return (y, gates, cells) if save else y
+    if H % 16 == 0:
+        # fp32 recurrence with both operands in MFMA fragment order (bit-identical to the row-major kernel, fewer cache
+        # lines per load): W_hh -> (H/4, H/16, kq 4, gate 4, unit 4, 4)
+        wf = w_hh.view(4, H // 4, 4, H // 16, 4, 4).permute(1, 3, 4, 0, 2, 5).contiguous()
+        hf = torch.empty(2 * ((B + 15) // 16) * 16 * H, device=x.device, dtype=x.dtype)
+        _lib.check(_lib.load().cfm_lstm_fwd_frag_f32(gx.data_ptr(), wf.data_ptr(), _p(lengths), y.data_ptr(), c.data_ptr(),
+                                                     hf.data_ptr(), _p(gates), _p(cells), B, T, H, _stream()),
+                   "cfm_lstm_fwd_frag_f32")
+        return (y, gates, cells) if save else y
     _lib.check(_lib.load().cfm_lstm_fwd_f32(gx.data_ptr(), w_hh.data_ptr(), _p(lengths), y.data_ptr(), c.data_ptr(), _p(gates),
                                             _p(cells), B, T, H, _stream()), "cfm_lstm_fwd_f32")
     return (y, gates, cells) if save else y
@@ -983,6 +992,13 @@ def lstm_backward(x, w_ih, w_hh, y, gates, cells, dy, lengths=None, need_dx: boo
         _lib.check(lib.cfm_lstm_bwd_mfma16_f32(prec, dy.data_ptr(), gates.data_ptr(), cells.data_ptr(), wt16.data_ptr(), _p(lengths),
                                                dG.data_ptr(), dc.data_ptr(), dg16.data_ptr(), B, T, H, _stream()),
                    "cfm_lstm_bwd_mfma16_f32")
+    elif H % 16 == 0:
+        # fp32: W_hh^T (H,4H) -> (H/16, 4H/16, kq 4, unit 16, 4); dG_t exchanged between steps in the same order
+        wtf = w_hh.t().reshape(H // 16, 16, 4 * H // 16, 4, 4).permute(0, 2, 3, 1, 4).contiguous()
+        dgf = torch.empty(2 * ((B + 15) // 16) * 16 * 4 * H, device=x.device, dtype=x.dtype)
+        _lib.check(lib.cfm_lstm_bwd_frag_f32(dy.data_ptr(), gates.data_ptr(), cells.data_ptr(), wtf.data_ptr(), _p(lengths),
+                                             dG.data_ptr(), dc.data_ptr(), dgf.data_ptr(), B, T, H, _stream()),
+                   "cfm_lstm_bwd_frag_f32")
     else:
         whh_t = w_hh.t().contiguous()                                 # (H,4H): 6.5 MB of glue per step
         _lib.check(lib.cfm_lstm_bwd_f32(dy.data_ptr(), gates.data_ptr(), cells.data_ptr(), whh_t.data_ptr(), _p(lengths),

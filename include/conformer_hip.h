@@ -376,10 +376,23 @@ int cfm_lstm_fwd_f32(const float* gates_x, const float* w_hh, const int64_t* len
 int cfm_lstm_bwd_f32(const float* dy, const float* gates, const float* cells, const float* whh_t,
                      const int64_t* lengths_or_null, float* dgates, float* dc_state, int B, int T, int H,
                      cfm_stream_t stream);
+/* The same two entries with both operands of the recurrent product in MFMA-fragment order (a wave's 16-byte-per-lane load
+ * is one contiguous 1 KB run; the step is bound by memory round trips).  H % 16 == 0.  Results are bit-identical to the
+ * row-major entries.  w_hh_frag[ub][ch][kq][q][u][e] = W_hh[q*H + 4*ub + u][16*ch + 4*kq + e]  (ub < H/4, ch < H/16, kq,q,u,e < 4);
+ * whh_t_frag[ub][ch][kq][u][e] = W_hh[16*ch + 4*kq + e][16*ub + u]  (ub < H/16, ch < 4H/16, u < 16);
+ * h_frag_scratch: 2*ceil(B/16)*16*H floats; dg_frag_scratch: 2*ceil(B/16)*16*4H floats (neither needs initialising). */
+int cfm_lstm_fwd_frag_f32(const float* gates_x, const float* w_hh_frag, const int64_t* lengths_or_null, float* y,
+                          float* c_state, float* h_frag_scratch, float* save_gates_or_null, float* save_c_or_null, int B,
+                          int T, int H, cfm_stream_t stream);
+int cfm_lstm_bwd_frag_f32(const float* dy, const float* gates, const float* cells, const float* whh_t_frag,
+                          const int64_t* lengths_or_null, float* dgates, float* dc_state, float* dg_frag_scratch, int B,
+                          int T, int H, cfm_stream_t stream);
 /* cfm_lstm_fwd_f32 with the recurrent product h.W_hh^T on the 16-bit matrix pipe -- what torch.autocast does to nn.LSTM
- * on a GPU (reference decoder.py:10,17-22 under train.py:232).  w_hh16 (4H,H): 16-bit copy of W_hh (cfm_cast16_f32);
- * h16_scratch: 2*B*H 16-bit elements.  H % 16 == 0.  The backward form takes whh_t16 (H,4H) = the 16-bit transpose and
- * dg16_scratch: 2*B*4H 16-bit elements. */
+ * on a GPU (reference decoder.py:10,17-22 under train.py:232).  H % 16 == 0.  Operands in MFMA-fragment order:
+ * w_hh16[ub][ch][hf][q][u][e] = W_hh[q*H + 8*ub + u][16*ch + 8*hf + e]  (ub < H/8, ch < H/16, hf < 2, q < 4, u,e < 8), a
+ * 16-bit copy (cfm_cast16_f32 + re-order); h16_scratch: 2*ceil(B/32)*32*H 16-bit elements.  The backward form takes
+ * whh_t16[ub][ch][hf][u][e] = W_hh[16*ch + 8*hf + e][16*ub + u]  (ub < H/16, ch < 4H/16, u < 16) and dg16_scratch:
+ * 2*ceil(B/16)*16*4H 16-bit elements. */
 int cfm_lstm_fwd_mfma16_f32(int prec, const float* gates_x, const void* w_hh16, const int64_t* lengths_or_null, float* y,
                             float* c_state, void* h16_scratch, float* save_gates_or_null, float* save_c_or_null, int B,
                             int T, int H, cfm_stream_t stream);

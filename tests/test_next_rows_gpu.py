@@ -146,6 +146,62 @@ def test_lstm_backward_vs_oracle_autograd(dev, B, T, D, H, ragged):
         assert rel_l2(a.grad, b.grad) < 2e-5, name
 
 
+@pytest.mark.parametrize("B,T,H", [(40, 9, 48), (3, 25, 16), (64, 6, 640)])
+def test_lstm_fragment_order_kernels_are_bit_identical_to_row_major(dev, B, T, H):
+    """The fragment-order fp32 recurrence / BPTT kernels do the same products in the same order as the row-major ones:
+    outputs, saved activations and gate gradients must be EQUAL, ragged lengths included, next to poisoned scratch."""
+    from conformer_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(B + T + H)
+    gx = torch.randn(B, T, 4 * H, generator=g).to(dev)
+    w_hh = ((torch.rand(4 * H, H, generator=g) * 2 - 1) / H ** 0.5).to(dev)
+    L = torch.sort(torch.randint(1, T + 1, (B,), generator=g), descending=True).values
+    L[0] = T
+    L = L.to(dev)
+    st = torch.cuda.current_stream().cuda_stream
+    nb = (B + 15) // 16 * 16
+
+    def fwd(frag):
+        y, c = torch.full((B, T, H), float("nan"), device=dev), torch.full((B, H), float("nan"), device=dev)
+        gates, cells = torch.full((B, T, 4 * H), float("nan"), device=dev), torch.full((B, T, H), float("nan"), device=dev)
+        if frag:
+            wf = w_hh.view(4, H // 4, 4, H // 16, 4, 4).permute(1, 3, 4, 0, 2, 5).contiguous()
+            hf = torch.full((2 * nb * H,), float("nan"), device=dev)
+            rc = lib.cfm_lstm_fwd_frag_f32(gx.data_ptr(), wf.data_ptr(), L.data_ptr(), y.data_ptr(), c.data_ptr(), hf.data_ptr(),
+                                           gates.data_ptr(), cells.data_ptr(), B, T, H, st)
+        else:
+            rc = lib.cfm_lstm_fwd_f32(gx.data_ptr(), w_hh.data_ptr(), L.data_ptr(), y.data_ptr(), c.data_ptr(), gates.data_ptr(),
+                                      cells.data_ptr(), B, T, H, st)
+        assert rc == 0
+        return y, gates, cells
+
+    y0, g0, c0 = fwd(False)
+    y1, g1, c1 = fwd(True)
+    assert torch.isfinite(y0).all()
+    assert torch.equal(y0, y1) and torch.equal(g0, g1) and torch.equal(c0, c1)
+    dy = torch.randn(B, T, H, generator=g).to(dev)
+
+    def bwd(frag):
+        dG, dc = torch.full((B, T, 4 * H), float("nan"), device=dev), torch.full((B, H), float("nan"), device=dev)
+        if frag:
+            wtf = w_hh.t().reshape(H // 16, 16, 4 * H // 16, 4, 4).permute(0, 2, 3, 1, 4).contiguous()
+            dgf = torch.full((2 * nb * 4 * H,), float("nan"), device=dev)
+            rc = lib.cfm_lstm_bwd_frag_f32(dy.data_ptr(), g0.data_ptr(), c0.data_ptr(), wtf.data_ptr(), L.data_ptr(), dG.data_ptr(),
+                                           dc.data_ptr(), dgf.data_ptr(), B, T, H, st)
+        else:
+            wt = w_hh.t().contiguous()
+            rc = lib.cfm_lstm_bwd_f32(dy.data_ptr(), g0.data_ptr(), c0.data_ptr(), wt.data_ptr(), L.data_ptr(), dG.data_ptr(),
+                                      dc.data_ptr(), B, T, H, st)
+        assert rc == 0
+        return dG
+
+    d0, d1 = bwd(False), bwd(True)
+    assert torch.isfinite(d0).all() and torch.equal(d0, d1)
+    # shapes the fragment kernels cannot take are refused, not mis-indexed
+    assert lib.cfm_lstm_fwd_frag_f32(gx.data_ptr(), w_hh.data_ptr(), None, y0.data_ptr(), c0.data_ptr(), y1.data_ptr(), None, None,
+                                     B, T, 8, st) != 0
+
+
 @pytest.mark.parametrize("B,T,D,H,ragged", [(3, 25, 32, 16, True), (2, 49, 144, 320, True), (64, 30, 64, 640, True), (40, 12, 64, 48, True)])
 def test_lstm_bf16_recurrence_and_bptt_vs_oracle(dev, B, T, D, H, ragged):
     """Under autocast the forward recurrent product runs on the 16-bit matrix pipe (lstm_mfma16.hip: 32-utterance x 8-unit

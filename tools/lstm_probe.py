@@ -43,11 +43,17 @@ def main():
         gates = torch.rand(B, T, 4 * H, device=dev); cells = torch.randn(B, T, H, device=dev); dy = torch.randn(B, T, H, device=dev)
         dG = torch.empty(B, T, 4 * H, device=dev); dc = torch.empty(B, H, device=dev)
         wt32 = w_hh.t().contiguous()
+        wf = w_hh.view(4, H // 4, 4, H // 16, 4, 4).permute(1, 3, 4, 0, 2, 5).contiguous()
+        wtf = w_hh.t().reshape(H // 16, 16, 4 * H // 16, 4, 4).permute(0, 2, 3, 1, 4).contiguous()
+        hfr = torch.empty(2 * ((B + 15) // 16) * 16 * H, device=dev); dgf = torch.empty(2 * ((B + 15) // 16) * 16 * 4 * H, device=dev)
+        y2 = torch.empty_like(y); dG2 = torch.empty_like(dG)
         st = torch.cuda.current_stream().cuda_stream
         fns = {"fwd 16-bit": lambda: lib.cfm_lstm_fwd_mfma16_f32(1, gx.data_ptr(), w16.data_ptr(), None, y.data_ptr(), c.data_ptr(), h16.data_ptr(), None, None, B, T, H, st),
                "bwd 16-bit": lambda: lib.cfm_lstm_bwd_mfma16_f32(1, dy.data_ptr(), gates.data_ptr(), cells.data_ptr(), wt16.data_ptr(), None, dG.data_ptr(), dc.data_ptr(), dg16.data_ptr(), B, T, H, st),
                "fwd fp32": lambda: lib.cfm_lstm_fwd_f32(gx.data_ptr(), w_hh.data_ptr(), None, y.data_ptr(), c.data_ptr(), None, None, B, T, H, st),
-               "bwd fp32": lambda: lib.cfm_lstm_bwd_f32(dy.data_ptr(), gates.data_ptr(), cells.data_ptr(), wt32.data_ptr(), None, dG.data_ptr(), dc.data_ptr(), B, T, H, st)}
+               "bwd fp32": lambda: lib.cfm_lstm_bwd_f32(dy.data_ptr(), gates.data_ptr(), cells.data_ptr(), wt32.data_ptr(), None, dG.data_ptr(), dc.data_ptr(), B, T, H, st),
+               "fwd fp32 frag": lambda: lib.cfm_lstm_fwd_frag_f32(gx.data_ptr(), wf.data_ptr(), None, y2.data_ptr(), c.data_ptr(), hfr.data_ptr(), None, None, B, T, H, st),
+               "bwd fp32 frag": lambda: lib.cfm_lstm_bwd_frag_f32(dy.data_ptr(), gates.data_ptr(), cells.data_ptr(), wtf.data_ptr(), None, dG2.data_ptr(), dc.data_ptr(), dgf.data_ptr(), B, T, H, st)}
         for name, fn in fns.items():
             for _ in range(2):
                 assert fn() == 0
@@ -58,6 +64,7 @@ def main():
                 fn()
             e1.record(); torch.cuda.synchronize()
             print(f"B={B} H={H}: {name}: {e0.elapsed_time(e1) / 5 / T * 1e3:.2f} us per step")
+        print(f"B={B} H={H}: fragment-order fp32 kernels bit-identical to row-major: fwd {torch.equal(y, y2)}, bwd {torch.equal(dG, dG2)}")
     B, H, T = 64, 640, 249
     gx = torch.randn(B, T, 4 * H, device=dev); w_hh = torch.randn(4 * H, H, device=dev) * 0.05
     y = torch.empty(B, T, H, device=dev); c = torch.empty(B, H, device=dev)
