@@ -35,6 +35,25 @@ __device__ __forceinline__ void bwd_epilogue_rows(const BwdArgs& g, float* Cb, f
     for (int mt = 0; mt < TM; ++mt) {
         const int row = i0 + wr * (BM / 2) + mt * 32 + li;
         if (row >= g.I) continue;
+        int64_t crow = row;
+        if (GATHER == 2) {                                                 // class row -> position (b, 2a+pt, 2c+pf) of dh1
+            const int per = g.pA * g.pC;
+            const int b = row / per, r = row - b * per;
+            const int a = r / g.pC, c = r - a * g.pC;
+            crow = ((int64_t)b * g.cT1 + 2 * a + g.pt) * g.cF1 + 2 * c + g.pf;
+        }
+        // every load of the slab (Z of swish', the accumulate operand) is issued before its first store: loaded group by group
+        // they made the epilogue a chain of store-acknowledge -> load round trips (cf. EpiOps in gemm_shared.h)
+        f32x4 zq[EPI == BEPI_DSWISH ? TN : 1][4], oq[TN][4];
+#pragma unroll
+        for (int nt = 0; nt < TN; ++nt)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int col = j0 + wc * (BN / 2) + nt * 32 + 8 * q + 4 * hf;
+                const bool full = col + 3 < g.J;
+                if (EPI == BEPI_DSWISH) zq[EPI == BEPI_DSWISH ? nt : 0][q] = full ? *reinterpret_cast<const f32x4*>(g.Z + (int64_t)row * g.ldz + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+                oq[nt][q] = (full && g.accumulate) ? *reinterpret_cast<const f32x4*>(Cb + crow * g.ldc + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
 #pragma unroll
         for (int nt = 0; nt < TN; ++nt)
 #pragma unroll
@@ -50,7 +69,7 @@ __device__ __forceinline__ void bwd_epilogue_rows(const BwdArgs& g, float* Cb, f
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         if (!full && col + e >= g.J) continue;
-                        const float z = zp[e];
+                        const float z = full ? zq[EPI == BEPI_DSWISH ? nt : 0][q][e] : zp[e];
                         const float sg = sigmoidf_acc(z);
                         v[e] *= sg * (1.0f + z * (1.0f - sg));
                         if (g.drop_p > 0.f)
@@ -58,20 +77,10 @@ __device__ __forceinline__ void bwd_epilogue_rows(const BwdArgs& g, float* Cb, f
                                                  g.drop_p, 1.0f / (1.0f - g.drop_p));
                     }
                 }
-                int64_t crow = row;
-                if (GATHER == 2) {                                         // class row -> position (b, 2a+pt, 2c+pf) of dh1
-                    const int per = g.pA * g.pC;
-                    const int b = row / per, r = row - b * per;
-                    const int a = r / g.pC, c = r - a * g.pC;
-                    crow = ((int64_t)b * g.cT1 + 2 * a + g.pt) * g.cF1 + 2 * c + g.pf;
-                }
                 float* dst = Cb + crow * g.ldc + col;
                 if (full) {
-                    if (g.accumulate) {
-                        const f32x4 o = *reinterpret_cast<const f32x4*>(dst);
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] += o[e];
-                    }
+                    for (int e = 0; e < 4; ++e) v[e] += oq[nt][q][e];      // (zeros unless accumulating)
                     *reinterpret_cast<f32x4*>(dst) = f32x4{v[0], v[1], v[2], v[3]};
                 } else {
 #pragma unroll
@@ -112,51 +121,79 @@ __device__ __forceinline__ void bwd_epilogue_rows_lds(const BwdArgs& g, float* C
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // the Z / accumulate loads of up to 8 row groups are issued together, ahead of the groups' stores (cf. EpiOps in gemm_shared.h)
+        constexpr int NIT = 32 / RPI, HB = NIT < 8 ? NIT : 8;
 #pragma unroll
-        for (int it = 0; it < 32 / RPI; ++it) {
-            const int rl = it * RPI + rsub;
-            const int row = i0 + wr * (BM / 2) + mt * 32 + rl;
-            f32x4 v = *reinterpret_cast<const f32x4*>(scratch + rl * P + c4);
-            if (row >= g.I || col >= g.J) continue;
-            v = v * g.alpha;
-            if (EPI == BEPI_DSWISH) {
-                f32x4 z4;
-                if (g.z16 == 0) {
-                    z4 = *reinterpret_cast<const f32x4*>(g.Z + (int64_t)row * g.ldz + col);
-                } else {
+        for (int h = 0; h < NIT / HB; ++h) {
+            f32x4 zf[EPI == BEPI_DSWISH ? HB : 1], of[HB];
+            uint2 zh[EPI == BEPI_DSWISH ? HB : 1];
+#pragma unroll
+            for (int j = 0; j < HB; ++j) {
+                const int rl = (h * HB + j) * RPI + rsub;
+                const int row = min(i0 + wr * (BM / 2) + mt * 32 + rl, g.I - 1);
+                const int cc = col < g.J ? col : 0;
+                if (EPI == BEPI_DSWISH) {
+                    if (g.z16 == 0) zf[EPI == BEPI_DSWISH ? j : 0] = *reinterpret_cast<const f32x4*>(g.Z + (int64_t)row * g.ldz + cc);
+                    else zh[EPI == BEPI_DSWISH ? j : 0] = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(g.Z) + ((int64_t)row * g.ldz + cc) * 2);
+                }
+                if (g.accumulate && !g.c16) {
+                    int64_t crow = row;
+                    if (GATHER == 2) {
+                        const int per = g.pA * g.pC;
+                        const int b = row / per, r = row - b * per;
+                        const int a = r / g.pC, c = r - a * g.pC;
+                        crow = ((int64_t)b * g.cT1 + 2 * a + g.pt) * g.cF1 + 2 * c + g.pf;
+                    }
+                    of[j] = *reinterpret_cast<const f32x4*>(Cb + crow * g.ldc + cc);
+                } else of[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int j = 0; j < HB; ++j) {
+                const int rl = (h * HB + j) * RPI + rsub;
+                const int row = i0 + wr * (BM / 2) + mt * 32 + rl;
+                f32x4 v = *reinterpret_cast<const f32x4*>(scratch + rl * P + c4);
+                if (row >= g.I || col >= g.J) continue;
+                v = v * g.alpha;
+                if (EPI == BEPI_DSWISH) {
+                    f32x4 z4;
+                    if (g.z16 == 0) z4 = zf[EPI == BEPI_DSWISH ? j : 0];
+                    else {
+                        const uint2 t = zh[EPI == BEPI_DSWISH ? j : 0];
+                        if (g.z16 == 1) z4 = f32x4{__uint_as_float(t.x << 16), __uint_as_float(t.x & 0xffff0000u), __uint_as_float(t.y << 16), __uint_as_float(t.y & 0xffff0000u)};
+                        else {
+                            typedef _Float16 hf4 __attribute__((ext_vector_type(4)));
+                            hf4 th;
+                            __builtin_memcpy(&th, &t, 8);
+                            z4 = f32x4{(float)th[0], (float)th[1], (float)th[2], (float)th[3]};
+                        }
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float sg = sigmoidf_acc(z4[e]);
+                        v[e] *= sg * (1.0f + z4[e] * (1.0f - sg));
+                        if (g.drop_p > 0.f)
+                            v[e] *= dropout_keep(g.drop_seed, (unsigned long long)row * (unsigned long long)g.J + (unsigned)(col + e),
+                                                 g.drop_p, 1.0f / (1.0f - g.drop_p));
+                    }
+                }
+                int64_t crow = row;
+                if (GATHER == 2) {                                         // class row -> position (b, 2a+pt, 2c+pf) of dh1
+                    const int per = g.pA * g.pC;
+                    const int b = row / per, r = row - b * per;
+                    const int a = r / g.pC, c = r - a * g.pC;
+                    crow = ((int64_t)b * g.cT1 + 2 * a + g.pt) * g.cF1 + 2 * c + g.pf;
+                }
+                if (g.c16) {                                               // gradient stored for GEMM consumers only: 8-byte stores
                     typedef __bf16 bf4 __attribute__((ext_vector_type(4)));
                     typedef _Float16 hf4 __attribute__((ext_vector_type(4)));
-                    const void* zp = reinterpret_cast<const char*>(g.Z) + ((int64_t)row * g.ldz + col) * 2;
-                    if (g.z16 == 1) { const bf4 t = *reinterpret_cast<const bf4*>(zp); z4 = f32x4{(float)t[0], (float)t[1], (float)t[2], (float)t[3]}; }
-                    else { const hf4 t = *reinterpret_cast<const hf4*>(zp); z4 = f32x4{(float)t[0], (float)t[1], (float)t[2], (float)t[3]}; }
+                    void* d16 = reinterpret_cast<char*>(Cb) + (crow * g.ldc + col) * 2;
+                    if (g.c16 == 1) *reinterpret_cast<bf4*>(d16) = bf4{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+                    else *reinterpret_cast<hf4*>(d16) = hf4{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+                    continue;
                 }
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float sg = sigmoidf_acc(z4[e]);
-                    v[e] *= sg * (1.0f + z4[e] * (1.0f - sg));
-                    if (g.drop_p > 0.f)
-                        v[e] *= dropout_keep(g.drop_seed, (unsigned long long)row * (unsigned long long)g.J + (unsigned)(col + e),
-                                             g.drop_p, 1.0f / (1.0f - g.drop_p));
-                }
+                v = v + of[j];                                             // (zeros unless accumulating)
+                *reinterpret_cast<f32x4*>(Cb + crow * g.ldc + col) = v;
             }
-            int64_t crow = row;
-            if (GATHER == 2) {                                             // class row -> position (b, 2a+pt, 2c+pf) of dh1
-                const int per = g.pA * g.pC;
-                const int b = row / per, r = row - b * per;
-                const int a = r / g.pC, c = r - a * g.pC;
-                crow = ((int64_t)b * g.cT1 + 2 * a + g.pt) * g.cF1 + 2 * c + g.pf;
-            }
-            if (g.c16) {                                                   // gradient stored for GEMM consumers only: 8-byte stores
-                typedef __bf16 bf4 __attribute__((ext_vector_type(4)));
-                typedef _Float16 hf4 __attribute__((ext_vector_type(4)));
-                void* d16 = reinterpret_cast<char*>(Cb) + (crow * g.ldc + col) * 2;
-                if (g.c16 == 1) *reinterpret_cast<bf4*>(d16) = bf4{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
-                else *reinterpret_cast<hf4*>(d16) = hf4{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
-                continue;
-            }
-            float* dst = Cb + crow * g.ldc + col;
-            if (g.accumulate) v = v + *reinterpret_cast<const f32x4*>(dst);
-            *reinterpret_cast<f32x4*>(dst) = v;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();

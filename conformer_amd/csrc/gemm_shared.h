@@ -87,86 +87,159 @@ __device__ __forceinline__ int64_t a_k_offset(const GemmArgs& g, int k) {   // k
 // gemm_epilogue_at: bias / activation / dropout / residual / stores for FOUR consecutive columns of one output row
 // (av = the accumulator values, gv = the matching gate values of a GLU tile).
 // `crow`: the row of C the result is stored to (differs from `row` only for the scattered rows of CONV == 2)
+// Operands of one 4-column group that come from memory (vectorised path): FETCHED by the caller ahead of the stores of earlier
+// groups.  Loading them inside the per-group routine made every epilogue a chain of round trips -- the wait for group i's bias /
+// residual load (s_waitcnt vmcnt(0)) also waits for group i-1's stores to be acknowledged: 64 serialised ~0.3 us trips, 19 us of
+// a 40 us workgroup in the 256x256 FFN tile (per-K-tile trace, profiles/r02_gemm16_epilogue_trace.txt).
+struct EpiOps {
+    f32x4 bb, bg, rr;               // bias, GLU gate bias, residual (or fp32 Z of EPI_DSWISH)
+    unsigned z16[2];                // EPI_DSWISH: four 16-bit Z values, converted when they are used
+};
+template <int EPI>
+__device__ __forceinline__ void gemm_epilogue_fetch_bias(const GemmArgs& g, int col, EpiOps& o) {
+    const int ncols = EPI == EPI_GLU ? g.n_out : g.N;
+    const int cc = col < ncols ? col : 0;                              // (groups beyond the last column are never stored)
+    if (EPI != EPI_DSWISH) o.bb = *reinterpret_cast<const f32x4*>(g.bias + cc);
+    if (EPI == EPI_GLU) o.bg = *reinterpret_cast<const f32x4*>(g.bias + g.n_out + cc);
+}
+template <int EPI>
+__device__ __forceinline__ void gemm_epilogue_fetch_row(const GemmArgs& g, int64_t row, int col, EpiOps& o) {
+    if (EPI != EPI_RESID && EPI != EPI_DSWISH) return;
+    const int64_t rc = row < g.M ? row : g.M - 1;
+    const int cc = col < g.N ? col : 0;
+    if (EPI == EPI_RESID) o.rr = *reinterpret_cast<const f32x4*>(g.R + rc * g.ldr + cc);
+    if (EPI == EPI_DSWISH) {
+        if (g.z_prec == 0) o.rr = *reinterpret_cast<const f32x4*>(g.Zsave + rc * g.ldr + cc);
+        else {
+            const uint2 t = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(g.Zsave) + rc * g.ldr + cc);
+            o.z16[0] = t.x; o.z16[1] = t.y;
+        }
+    }
+}
+
+// gemm_epilogue_compute: activation / dropout / residual of one fetched 4-column group; returns the values to store,
+// zpre = the pre-activation (what EPI_SWISH saves as Z)
+template <int EPI>
+__device__ __forceinline__ f32x4 gemm_epilogue_compute(const GemmArgs& g, const f32x4 av, const f32x4 gv, const EpiOps& o, int64_t row,
+                                                       int col, f32x4& zpre) {
+    if constexpr (EPI == EPI_DSWISH) {
+        f32x4 z4;
+        if (g.z_prec == 0) z4 = o.rr;
+        else if (g.z_prec == CFM_PREC_BF16) {                          // bf16 -> fp32: the bits, shifted up
+            z4 = f32x4{__uint_as_float(o.z16[0] << 16), __uint_as_float(o.z16[0] & 0xffff0000u), __uint_as_float(o.z16[1] << 16),
+                       __uint_as_float(o.z16[1] & 0xffff0000u)};
+        } else {
+            Lowp<_Float16>::x4 t;
+            __builtin_memcpy(&t, o.z16, 8);
+            z4 = f32x4{(float)t[0], (float)t[1], (float)t[2], (float)t[3]};
+        }
+        f32x4 r;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float sg = sigmoidf_acc(z4[e]);
+            r[e] = g.alpha * av[e] * (sg * (1.0f + z4[e] * (1.0f - sg)));
+            if (g.drop_p > 0.f)
+                r[e] *= dropout_keep(g.drop_seed, (unsigned long long)row * (unsigned long long)g.N + (unsigned)(col + e), g.drop_p,
+                                     1.0f / (1.0f - g.drop_p));
+        }
+        zpre = z4;
+        return r;
+    }
+    float v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = av[e] + o.bb[e];
+    const bool drop = g.drop_p > 0.f && EPI != EPI_GLU && EPI != EPI_RELU;
+    const float inv_keep = drop ? 1.0f / (1.0f - g.drop_p) : 1.0f;
+    const unsigned long long e0 = (unsigned long long)row * (unsigned long long)g.N + (unsigned)col;
+    if (drop && EPI != EPI_SWISH) {                        // dropout(y) then alpha*y + R  (or plain y)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] *= dropout_keep(g.drop_seed, e0 + e, g.drop_p, inv_keep);
+    }
+    if (EPI == EPI_GLU) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] *= sigmoidf_acc(gv[e] + o.bg[e]);
+    }
+    if (EPI == EPI_RESID) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = g.alpha * v[e] + o.rr[e];
+    }
+    zpre = f32x4{v[0], v[1], v[2], v[3]};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        if (EPI == EPI_SWISH) {
+            v[e] = swishf_acc(v[e]);
+            if (drop) v[e] *= dropout_keep(g.drop_seed, e0 + e, g.drop_p, inv_keep);
+        }
+        if (EPI == EPI_RELU) v[e] = fmaxf(v[e], 0.f);
+    }
+    return f32x4{v[0], v[1], v[2], v[3]};
+}
+
+// stores of 4 / 8 consecutive elements at element offset `off` of a tensor of type `prec` (0 fp32 | bf16 | fp16)
+__device__ __forceinline__ void epi_store4(void* base, int prec, int64_t off, const f32x4 v) {
+    if (prec == 0) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(base) + off) = v;
+    else if (prec == CFM_PREC_BF16) *reinterpret_cast<Lowp<__bf16>::x4*>(reinterpret_cast<__bf16*>(base) + off) = Lowp<__bf16>::cvt4(v);
+    else *reinterpret_cast<Lowp<_Float16>::x4*>(reinterpret_cast<_Float16*>(base) + off) = Lowp<_Float16>::cvt4(v);
+}
+__device__ __forceinline__ void epi_store8(void* base, int prec, int64_t off, const f32x4 v0, const f32x4 v1) {
+    if (prec == 0) {
+        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(base) + off) = v0;
+        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(base) + off + 4) = v1;
+    } else if (prec == CFM_PREC_BF16) {
+        Lowp<__bf16>::x8 r;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { r[e] = (__bf16)v0[e]; r[4 + e] = (__bf16)v1[e]; }
+        *reinterpret_cast<Lowp<__bf16>::x8*>(reinterpret_cast<__bf16*>(base) + off) = r;
+    } else {
+        Lowp<_Float16>::x8 r;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { r[e] = (_Float16)v0[e]; r[4 + e] = (_Float16)v1[e]; }
+        *reinterpret_cast<Lowp<_Float16>::x8*>(reinterpret_cast<_Float16*>(base) + off) = r;
+    }
+}
+
+// gemm_epilogue_apply: compute + stores of one fetched 4-column group (vectorised path)
+template <int EPI>
+__device__ __forceinline__ void gemm_epilogue_apply(const GemmArgs& g, const f32x4 av, const f32x4 gv, const EpiOps& o, int64_t row,
+                                                    int col, int64_t crow) {
+    const int ncols = EPI == EPI_GLU ? g.n_out : g.N;
+    if (row >= g.M || col >= ncols) return;
+    f32x4 zpre;
+    const f32x4 v = gemm_epilogue_compute<EPI>(g, av, gv, o, row, col, zpre);
+    if (EPI == EPI_SWISH && g.Zsave) epi_store4(g.Zsave, g.z_prec, row * g.ldc + col, zpre);
+    epi_store4(g.C, g.c_prec, crow * g.ldc + col, v);
+}
+// ... of two adjacent groups = 8 consecutive columns of one row: a 16-bit output is then one 16-byte store per lane.  The
+// write-out of a tile is bound by the NUMBER of store instructions (~42 CU-cycles each at 8 or at 16 bytes per lane: the
+// 256x256 Swish tile with C and Z in bf16 took 19 us, as long as its whole K-loop, at 8-byte stores)
+template <int EPI>
+__device__ __forceinline__ void gemm_epilogue_apply8(const GemmArgs& g, const f32x4 av0, const f32x4 av1, const EpiOps& o0,
+                                                     const EpiOps& o1, int64_t row, int col, int64_t crow) {
+    static_assert(EPI != EPI_GLU, "8-column groups: no GLU");
+    if (row >= g.M || col >= g.N) return;                              // (N % 8 == 0: a group is all in or all out)
+    f32x4 z0, z1;
+    const f32x4 v0 = gemm_epilogue_compute<EPI>(g, av0, av0, o0, row, col, z0);
+    const f32x4 v1 = gemm_epilogue_compute<EPI>(g, av1, av1, o1, row, col + 4, z1);
+    if (EPI == EPI_SWISH && g.Zsave) epi_store8(g.Zsave, g.z_prec, row * g.ldc + col, z0, z1);
+    epi_store8(g.C, g.c_prec, crow * g.ldc + col, v0, v1);
+}
+
+// gemm_epilogue_at: fetch + apply of one group (scalar path for odd leading dimensions / widths)
 template <int EPI>
 __device__ __forceinline__ void gemm_epilogue_at(const GemmArgs& g, const f32x4 av, const f32x4 gv, int64_t row, int col,
                                                  bool vec_ok, int64_t crow = -1) {
     if (crow < 0) crow = row;
     const int ncols = EPI == EPI_GLU ? g.n_out : g.N;
     if (row >= g.M || col >= ncols) return;
-    if constexpr (EPI == EPI_DSWISH) {
-        if (!vec_ok) return;                                           // (excluded by the entry point)
-        f32x4 z4;
-        if (g.z_prec == 0) z4 = *reinterpret_cast<const f32x4*>(g.Zsave + row * g.ldr + col);
-        else if (g.z_prec == CFM_PREC_BF16) {
-            const Lowp<__bf16>::x4 t = *reinterpret_cast<const Lowp<__bf16>::x4*>(reinterpret_cast<const __bf16*>(g.Zsave) + row * g.ldr + col);
-            z4 = f32x4{(float)t[0], (float)t[1], (float)t[2], (float)t[3]};
-        } else {
-            const Lowp<_Float16>::x4 t = *reinterpret_cast<const Lowp<_Float16>::x4*>(reinterpret_cast<const _Float16*>(g.Zsave) + row * g.ldr + col);
-            z4 = f32x4{(float)t[0], (float)t[1], (float)t[2], (float)t[3]};
-        }
-        f32x4 o;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float sg = sigmoidf_acc(z4[e]);
-            o[e] = g.alpha * av[e] * (sg * (1.0f + z4[e] * (1.0f - sg)));
-            if (g.drop_p > 0.f)
-                o[e] *= dropout_keep(g.drop_seed, (unsigned long long)row * (unsigned long long)g.N + (unsigned)(col + e), g.drop_p,
-                                     1.0f / (1.0f - g.drop_p));
-        }
-        if (g.c_prec == 0) *reinterpret_cast<f32x4*>(g.C + row * g.ldc + col) = o;
-        else if (g.c_prec == CFM_PREC_BF16)
-            *reinterpret_cast<Lowp<__bf16>::x4*>(reinterpret_cast<__bf16*>(g.C) + row * g.ldc + col) = Lowp<__bf16>::cvt4(o);
-        else
-            *reinterpret_cast<Lowp<_Float16>::x4*>(reinterpret_cast<_Float16*>(g.C) + row * g.ldc + col) = Lowp<_Float16>::cvt4(o);
+    if (vec_ok) {
+        EpiOps o;
+        gemm_epilogue_fetch_bias<EPI>(g, col, o);
+        gemm_epilogue_fetch_row<EPI>(g, row, col, o);
+        gemm_epilogue_apply<EPI>(g, av, gv, o, row, col, crow);
         return;
     }
-    float v[4];
-    if (vec_ok) {                                                  // col + 3 < ncols because ncols % 4 == 0
-        const f32x4 bb = *reinterpret_cast<const f32x4*>(g.bias + col);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = av[e] + bb[e];
-        const bool drop = g.drop_p > 0.f && EPI != EPI_GLU && EPI != EPI_RELU;
-        const float inv_keep = drop ? 1.0f / (1.0f - g.drop_p) : 1.0f;
-        const unsigned long long e0 = (unsigned long long)row * (unsigned long long)g.N + (unsigned)col;
-        if (drop && EPI != EPI_SWISH) {                        // dropout(y) then alpha*y + R  (or plain y)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] *= dropout_keep(g.drop_seed, e0 + e, g.drop_p, inv_keep);
-        }
-        if (EPI == EPI_GLU) {
-            const f32x4 bg = *reinterpret_cast<const f32x4*>(g.bias + g.n_out + col);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] *= sigmoidf_acc(gv[e] + bg[e]);
-        }
-        if (EPI == EPI_RESID) {
-            const f32x4 rr = *reinterpret_cast<const f32x4*>(g.R + row * g.ldr + col);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = g.alpha * v[e] + rr[e];
-        }
-        if (EPI == EPI_SWISH && g.Zsave) {
-            if (g.z_prec == 0) *reinterpret_cast<f32x4*>(g.Zsave + row * g.ldc + col) = f32x4{v[0], v[1], v[2], v[3]};
-            else if (g.z_prec == CFM_PREC_BF16)
-                *reinterpret_cast<Lowp<__bf16>::x4*>(reinterpret_cast<__bf16*>(g.Zsave) + row * g.ldc + col) =
-                    Lowp<__bf16>::cvt4(f32x4{v[0], v[1], v[2], v[3]});
-            else
-                *reinterpret_cast<Lowp<_Float16>::x4*>(reinterpret_cast<_Float16*>(g.Zsave) + row * g.ldc + col) =
-                    Lowp<_Float16>::cvt4(f32x4{v[0], v[1], v[2], v[3]});
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            if (EPI == EPI_SWISH) {
-                v[e] = swishf_acc(v[e]);
-                if (drop) v[e] *= dropout_keep(g.drop_seed, e0 + e, g.drop_p, inv_keep);
-            }
-            if (EPI == EPI_RELU) v[e] = fmaxf(v[e], 0.f);
-        }
-        if (g.c_prec == 0) *reinterpret_cast<f32x4*>(g.C + crow * g.ldc + col) = f32x4{v[0], v[1], v[2], v[3]};
-        else if (g.c_prec == CFM_PREC_BF16)
-            *reinterpret_cast<Lowp<__bf16>::x4*>(reinterpret_cast<__bf16*>(g.C) + crow * g.ldc + col) =
-                Lowp<__bf16>::cvt4(f32x4{v[0], v[1], v[2], v[3]});
-        else
-            *reinterpret_cast<Lowp<_Float16>::x4*>(reinterpret_cast<_Float16*>(g.C) + crow * g.ldc + col) =
-                Lowp<_Float16>::cvt4(f32x4{v[0], v[1], v[2], v[3]});
-    } else {                                                       // odd leading dims / widths: scalar path
+    if constexpr (EPI == EPI_DSWISH) return;                           // (excluded by the entry point)
+    {                                                              // odd leading dims / widths: scalar path
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             if (col + e >= ncols) continue;
@@ -200,17 +273,49 @@ template <int BM, int BN, int EPI, int TM, int TN>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const f32x16 (&acc)[TM][TN], int64_t m0, int n0,
                                               int wr, int wc, int li, int hf) {
     const bool vec_ok = gemm_epilogue_vec_ok(g, EPI);
+    constexpr int NTN = EPI == EPI_GLU ? 1 : TN;
+    auto col_of = [&](int nt, int q) { return n0 + (EPI == EPI_GLU ? wc * 32 : wc * (BN / 2) + nt * 32) + 8 * q + 4 * hf; };
+    auto row_of = [&](int mt) { return m0 + wr * (BM / 2) + mt * 32 + li; };
+    auto av_of = [&](int mt, int nt, int q) {
+        return f32x4{acc[mt][nt][4 * q], acc[mt][nt][4 * q + 1], acc[mt][nt][4 * q + 2], acc[mt][nt][4 * q + 3]};
+    };
+    if (vec_ok) {                                                      // (kernel-uniform)
+        // every load of the epilogue is issued before its first store (see EpiOps)
+        EpiOps ob[NTN][4];
+#pragma unroll
+        for (int nt = 0; nt < NTN; ++nt)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) gemm_epilogue_fetch_bias<EPI>(g, col_of(nt, q), ob[nt][q]);
+        constexpr bool ROWOPS = EPI == EPI_RESID || EPI == EPI_DSWISH;
+        EpiOps orow[ROWOPS ? TM : 1][ROWOPS ? NTN : 1][ROWOPS ? 4 : 1];
+        if constexpr (ROWOPS) {
+#pragma unroll
+            for (int mt = 0; mt < TM; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NTN; ++nt)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        orow[mt][nt][q] = ob[nt][q];
+                        gemm_epilogue_fetch_row<EPI>(g, row_of(mt), col_of(nt, q), orow[mt][nt][q]);
+                    }
+        }
+#pragma unroll
+        for (int mt = 0; mt < TM; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NTN; ++nt)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    gemm_epilogue_apply<EPI>(g, av_of(mt, nt, q), av_of(mt, TN - 1, q), ROWOPS ? orow[ROWOPS ? mt : 0][ROWOPS ? nt : 0][ROWOPS ? q : 0] : ob[nt][q],
+                                             row_of(mt), col_of(nt, q), row_of(mt));
+        return;
+    }
 #pragma unroll
     for (int mt = 0; mt < TM; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < (EPI == EPI_GLU ? 1 : TN); ++nt)
+        for (int nt = 0; nt < NTN; ++nt)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const f32x4 av = {acc[mt][nt][4 * q], acc[mt][nt][4 * q + 1], acc[mt][nt][4 * q + 2], acc[mt][nt][4 * q + 3]};
-                const f32x4 gv = {acc[mt][TN - 1][4 * q], acc[mt][TN - 1][4 * q + 1], acc[mt][TN - 1][4 * q + 2], acc[mt][TN - 1][4 * q + 3]};
-                gemm_epilogue_at<EPI>(g, av, gv, m0 + wr * (BM / 2) + mt * 32 + li,
-                                      n0 + (EPI == EPI_GLU ? wc * 32 : wc * (BN / 2) + nt * 32) + 8 * q + 4 * hf, vec_ok);
-            }
+            for (int q = 0; q < 4; ++q)
+                gemm_epilogue_at<EPI>(g, av_of(mt, nt, q), av_of(mt, TN - 1, q), row_of(mt), col_of(nt, q), false);
 }
 
 // ROW-MAJOR epilogue: each 32-row slab of the wave's accumulators goes through a per-wave LDS tile (the K-loop's staging
@@ -234,10 +339,8 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmArgs& g, const f32x
             return;
         }
     }
-    const int rsub = lane / LPR, c4 = (lane % LPR) * 4;
-    const int col = n0 + wc * (BN / 2) + c4;
-#pragma unroll
-    for (int mt = 0; mt < TM; ++mt) {
+    constexpr bool ROWOPS = EPI == EPI_RESID || EPI == EPI_DSWISH;
+    auto stage_slab = [&](int mt) {                                   // accumulators of 32 rows -> the wave's LDS tile
 #pragma unroll
         for (int nt = 0; nt < TN; ++nt)
 #pragma unroll
@@ -247,24 +350,129 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmArgs& g, const f32x
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-        for (int it = 0; it < 32 / RPI; ++it) {
-            const int rl = it * RPI + rsub;
-            const f32x4 v = *reinterpret_cast<const f32x4*>(scratch + rl * P + c4);
-            const int64_t row = m0 + wr * (BM / WM) + mt * 32 + rl;
-            int64_t crow = row;
-            if constexpr (CLS) {                                        // class row (b, a, c) -> dh1 position (b, 2a+pt, 2c+pf)
-                const int64_t rr = min(row, g.M - 1);
-                const int per = g.pA * g.pC;
-                const int b = (int)(rr / per), r = (int)(rr - (int64_t)b * per);
-                const int a = r / g.pC, c = r - a * g.pC;
-                crow = ((int64_t)b * g.cT1 + 2 * a + g.pt) * g.cF1 + 2 * c + g.pf;
-            }
-            gemm_epilogue_at<EPI>(g, v, v, row, col, true, crow);
-        }
+    };
+    auto slab_done = [&]() {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    auto class_row = [&](int64_t row) {                               // CLS: class row (b, a, c) -> dh1 position (b, 2a+pt, 2c+pf)
+        const int64_t rr = min(row, g.M - 1);
+        const int per = g.pA * g.pC;
+        const int b = (int)(rr / per), r = (int)(rr - (int64_t)b * per);
+        const int a = r / g.pC, c = r - a * g.pC;
+        return ((int64_t)b * g.cT1 + 2 * a + g.pt) * g.cF1 + 2 * c + g.pf;
+    };
+
+    // ---- 16-bit C: 8 columns per lane, one 16-byte store per lane and output tensor (see gemm_epilogue_apply8)
+    if constexpr (EPI != EPI_RESID) {
+        const bool wide = g.c_prec != 0 && ((g.N | (int)g.ldc) & 7) == 0 && (reinterpret_cast<uintptr_t>(g.C) & 15) == 0 &&
+                          (EPI != EPI_SWISH || !g.Zsave || (reinterpret_cast<uintptr_t>(g.Zsave) & 15) == 0) &&
+                          (EPI != EPI_DSWISH || (g.z_prec != 0 && (g.ldr & 7) == 0 && (reinterpret_cast<uintptr_t>(g.Zsave) & 15) == 0));
+        if (wide) {                                                    // (kernel-uniform)
+            constexpr int LPR8 = 4 * TN, RPI8 = 64 / LPR8, NIT8 = 32 / RPI8;
+            const int rsub8 = lane / LPR8, c8 = (lane % LPR8) * 8;
+            const int col8 = n0 + wc * (BN / 2) + c8;
+            auto row8 = [&](int mt, int it) { return m0 + wr * (BM / WM) + mt * 32 + it * RPI8 + rsub8; };
+            EpiOps b0, b1;
+            gemm_epilogue_fetch_bias<EPI>(g, col8, b0);
+            gemm_epilogue_fetch_bias<EPI>(g, col8 + 4, b1);
+            uint4 zcur[EPI == EPI_DSWISH ? NIT8 : 1], znxt[EPI == EPI_DSWISH ? NIT8 : 1];
+            auto fetch_z = [&](uint4* dst, int mt) {                   // eight 16-bit Z values per group
+#pragma unroll
+                for (int it = 0; it < NIT8; ++it) {
+                    const int64_t rc = min(row8(mt, it), g.M - 1);
+                    dst[it] = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(g.Zsave) + rc * g.ldr + (col8 < g.N ? col8 : 0));
+                }
+            };
+            if constexpr (EPI == EPI_DSWISH) fetch_z(zcur, 0);
+#pragma unroll
+            for (int mt = 0; mt < TM; ++mt) {
+                stage_slab(mt);
+                if constexpr (EPI == EPI_DSWISH) {
+                    if (mt + 1 < TM) fetch_z(znxt, mt + 1);
+#pragma unroll
+                    for (int it = 0; it < NIT8; ++it) {
+                        const int rl = it * RPI8 + rsub8;
+                        const f32x4 v0 = *reinterpret_cast<const f32x4*>(scratch + rl * P + c8);
+                        const f32x4 v1 = *reinterpret_cast<const f32x4*>(scratch + rl * P + c8 + 4);
+                        EpiOps o0 = b0, o1 = b1;
+                        o0.z16[0] = zcur[it].x; o0.z16[1] = zcur[it].y; o1.z16[0] = zcur[it].z; o1.z16[1] = zcur[it].w;
+                        const int64_t row = row8(mt, it);
+                        gemm_epilogue_apply8<EPI>(g, v0, v1, o0, o1, row, col8, CLS ? class_row(row) : row);
+                    }
+#pragma unroll
+                    for (int it = 0; it < NIT8; ++it) zcur[it] = znxt[it];
+                } else {
+#pragma unroll 2
+                    for (int it = 0; it < NIT8; ++it) {
+                        const int rl = it * RPI8 + rsub8;
+                        const f32x4 v0 = *reinterpret_cast<const f32x4*>(scratch + rl * P + c8);
+                        const f32x4 v1 = *reinterpret_cast<const f32x4*>(scratch + rl * P + c8 + 4);
+                        const int64_t row = row8(mt, it);
+                        gemm_epilogue_apply8<EPI>(g, v0, v1, b0, b1, row, col8, CLS ? class_row(row) : row);
+                    }
+                }
+                slab_done();
+            }
+            return;
+        }
+    }
+
+    // ---- 4 columns per lane
+    const int rsub = lane / LPR, c4 = (lane % LPR) * 4;
+    const int col = n0 + wc * (BN / 2) + c4;
+    constexpr int NIT = 32 / RPI;
+    auto row_of = [&](int mt, int it) { return m0 + wr * (BM / WM) + mt * 32 + it * RPI + rsub; };
+    // Every load is issued ahead of the stores it would otherwise queue behind (see EpiOps): the bias once (a lane's columns
+    // are the same for all its rows), the residual / Z rows of batch i+1 before batch i is written out.
+    EpiOps ob;
+    gemm_epilogue_fetch_bias<EPI>(g, col, ob);
+    if constexpr (!ROWOPS) {
+#pragma unroll
+        for (int mt = 0; mt < TM; ++mt) {
+            stage_slab(mt);
+#pragma unroll 2
+            for (int it = 0; it < NIT; ++it) {                         // (a real loop: the unrolled form was 12 000 instructions)
+                const int rl = it * RPI + rsub;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(scratch + rl * P + c4);
+                const int64_t row = row_of(mt, it);
+                gemm_epilogue_apply<EPI>(g, v, v, ob, row, col, CLS ? class_row(row) : row);
+            }
+            slab_done();
+        }
+    } else {
+        constexpr int HB = NIT < 8 ? NIT : 8, NH = NIT / HB, NBATCH = TM * NH;   // row operands travel in batches of <= 8 groups (32 registers)
+        static_assert(NIT % HB == 0, "4, 8 or 16 row groups per 32-row slab");
+        EpiOps ocur[HB], onxt[HB];
+        auto fetch_batch = [&](EpiOps* dst, int bidx) {
+            const int mt = bidx / NH, h = bidx % NH;
+#pragma unroll
+            for (int j = 0; j < HB; ++j) gemm_epilogue_fetch_row<EPI>(g, row_of(mt, h * HB + j), col, dst[j]);
+        };
+        fetch_batch(ocur, 0);
+#pragma unroll
+        for (int mt = 0; mt < TM; ++mt) {
+            stage_slab(mt);
+#pragma unroll
+            for (int h = 0; h < NH; ++h) {
+                const int bidx = mt * NH + h;
+                if (bidx + 1 < NBATCH) fetch_batch(onxt, bidx + 1);
+#pragma unroll
+                for (int j = 0; j < HB; ++j) {
+                    const int it = h * HB + j;
+                    const int rl = it * RPI + rsub;
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(scratch + rl * P + c4);
+                    const int64_t row = row_of(mt, it);
+                    EpiOps o = ob;
+                    o.rr = ocur[j].rr; o.z16[0] = ocur[j].z16[0]; o.z16[1] = ocur[j].z16[1];
+                    gemm_epilogue_apply<EPI>(g, v, v, o, row, col, CLS ? class_row(row) : row);
+                }
+#pragma unroll
+                for (int j = 0; j < HB; ++j) ocur[j] = onxt[j];
+            }
+            slab_done();
+        }
     }
 }
 
