@@ -128,7 +128,15 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 128) ? 3 : 4) void gemm_f3
     if (kt < nkt) k_step(kt, ra1, rb1);
     if (g.trace && tid == 0) g.trace[8 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();   // main loop done
 
-    gemm_epilogue<BM, BN, EPI, TM, TN>(g, acc, m0, n0, wr, wc, li, hf);
+    // row-major write-out through a per-wave LDS tile (whole 256-byte row segments per store instruction) where the dead
+    // staging buffers can hold it; the GLU tile pairs value and gate columns in one wave and stores straight from the accumulators
+    constexpr bool ROWS = EPI != EPI_GLU && 4 * 32 * (32 * TN + 4) <= 2 * (BM + BN) * LDSR;
+    if constexpr (ROWS) {
+        __syncthreads();                                   // every wave is done reading the staging buffers
+        gemm_epilogue_rows<BM, BN, EPI, TM, TN>(g, acc, m0, n0, wr, wc, lane, lds + wave * 32 * (32 * TN + 4));
+    } else {
+        gemm_epilogue<BM, BN, EPI, TM, TN>(g, acc, m0, n0, wr, wc, li, hf);
+    }
     if (g.trace && tid == 0) {
         g.trace[8 * blockIdx.x + 4] = __builtin_amdgcn_s_memrealtime();                        // epilogue issued
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
