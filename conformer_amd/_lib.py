@@ -44,6 +44,8 @@ SIGNATURES = {
     "cfm_dwconv_bn_swish_fwd_out16_f32": (c_int, [_I, _P, _P, _P, _P, _P, _P, _P, _F, _P, _I, _I, _I, _I, _P]),
     "cfm_glu_bwd_out16_f32": (c_int, [_I, _P, _P, _P, _L, _I, _P]),
     "cfm_subsample_conv2_bwd_input_fwdkernel_mfma16_f32": (c_int, [_I, _P, _I, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "cfm_subsample_conv2_bwd_input_fwdkernel_out16_mfma16_f32": (c_int, [_I, _P, _I, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "cfm_subsample_conv1_bwd_d16_f32": (c_int, [_I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "cfm_reflect_pad_f32": (c_int, [_P, _P, _I, _L, _I, _L, _P]),
     "cfm_power_mel_log_f32": (c_int, [_P, _L, _P, _P, _I, _I, _I, _I, _F, _P]),
     "cfm_specaugment_apply_f32": (c_int, [_P, _I, _I, _I, _P, _I, _F, _P]),

@@ -501,9 +501,8 @@ extern "C" int cfm_cast16_multi_f32(int prec, const cfm_cast_item* items, int co
 // w2c16: the transposed-pack of w2 (cfm_pack_conv2_weight_t_f32) cast to `prec` (cfm_cast16_f32); zero_bias: C zeros; dz2 fp32
 // or stored in `prec` (cfm_relu_bwd_out16_f32).
 // Every dh1 element is written exactly once.  C % 64 == 0.
-extern "C" int cfm_subsample_conv2_bwd_input_fwdkernel_mfma16_f32(int prec, const void* dz2, int dz2_is_16bit, const void* w2c16,
-                                                                  const float* zero_bias, float* dh1, int B, int F1, int T1, int C,
-                                                                  cfm_stream_t stream) {
+static int conv2_bwd_input_classes(int prec, const void* dz2, int dz2_is_16bit, const void* w2c16, const float* zero_bias,
+                                   void* dh1, int dh1_is_16bit, int B, int F1, int T1, int C, cfm_stream_t stream) {
     CFM_REQUIRE(dz2 && w2c16 && zero_bias && dh1, CFM_ERR_NULL);
     CFM_REQUIRE(B > 0 && F1 >= 3 && T1 >= 3 && C > 0, CFM_ERR_BAD_SHAPE);
     CFM_REQUIRE(C % 64 == 0, CFM_ERR_UNSUPPORTED);
@@ -522,10 +521,22 @@ extern "C" int cfm_subsample_conv2_bwd_input_fwdkernel_mfma16_f32(int prec, cons
                 for (int kf = pf; kf < 3; kf += 2) { g.tap_dt[nt] = -(kt - pt) / 2; g.tap_df[nt] = -(kf - pf) / 2; ++nt; }
             const int q = 2 * pt + pf;
             g.A = static_cast<const float*>(dz2); g.W = reinterpret_cast<const float*>(static_cast<const char*>(w2c16) + woff[q] * C * C * 2);
-            g.bias = zero_bias; g.C = dh1; g.c_prec = 0;
+            g.bias = zero_bias; g.C = static_cast<float*>(dh1); g.c_prec = dh1_is_16bit ? prec : 0;
             g.M = (int64_t)B * g.pA * g.pC; g.N = C; g.K = nt * C; g.lda = 0; g.ldc = C; g.alpha = 1.f;
             const int st = launch<EPI_BIAS, 2>(prec, g, dz2_is_16bit ? 2 : 1, s);
             if (st) return st;
         }
     return CFM_OK;
+}
+extern "C" int cfm_subsample_conv2_bwd_input_fwdkernel_mfma16_f32(int prec, const void* dz2, int dz2_is_16bit, const void* w2c16,
+                                                                  const float* zero_bias, float* dh1, int B, int F1, int T1, int C,
+                                                                  cfm_stream_t stream) {
+    return conv2_bwd_input_classes(prec, dz2, dz2_is_16bit, w2c16, zero_bias, dh1, 0, B, F1, T1, C, stream);
+}
+// ... with dh1 stored in the 16-bit type `prec`: its only consumer is the conv1 parameter-gradient reduction
+// (cfm_subsample_conv1_bwd_d16_f32) -- under torch.autocast conv1's incoming gradient IS a 16-bit tensor.  Half the 2.5 GB.
+extern "C" int cfm_subsample_conv2_bwd_input_fwdkernel_out16_mfma16_f32(int prec, const void* dz2, int dz2_is_16bit,
+                                                                        const void* w2c16, const float* zero_bias, void* dh1_16,
+                                                                        int B, int F1, int T1, int C, cfm_stream_t stream) {
+    return conv2_bwd_input_classes(prec, dz2, dz2_is_16bit, w2c16, zero_bias, dh1_16, 1, B, F1, T1, C, stream);
 }

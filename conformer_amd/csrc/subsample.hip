@@ -116,8 +116,12 @@ __global__ __launch_bounds__(256) void relu_bwd_out16_kernel(const float* __rest
 // conv1 parameter gradients: dw1[c][kf][kt] += sum dz1 * x[b][2f1+kf][2t1+kt], db1[c] += sum dz1 with
 // dz1 = dh1 where relu(conv1) > 0 (the pre-activation is recomputed from x: 9 FMAs, h1 need not be re-read).
 // Same thread mapping as the forward kernel (4 channels per thread); block partials through LDS, one atomic per value.
+// TD: the type dh1 is stored in (float, or a 16-bit matrix-pipe type under autocast).  The f1 loop runs four positions at a time
+// with their dh1 / x loads issued together: one 16-byte load in flight per thread made the 2.5 GB pass latency-bound (1.2 ms
+// at cfg-3, 2 TB/s).
+template <typename TD>
 __global__ __launch_bounds__(256) void conv1_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w1,
-                                                        const float* __restrict__ b1, const float* __restrict__ dh1,
+                                                        const float* __restrict__ b1, const TD* __restrict__ dh1,
                                                         float* __restrict__ dw1, float* __restrict__ db1, int B, int F,
                                                         int T, int C, int F1, int T1, int ppb) {
     const int c4n = C >> 2;
@@ -136,25 +140,36 @@ __global__ __launch_bounds__(256) void conv1_bwd_kernel(const float* __restrict_
     // utterance and all f1 of each -- no per-position index arithmetic (the flattened 64-bit position index of the first
     // version cost two 64-bit divisions per position and thread)
     const int b = blockIdx.y;
+    constexpr int U = 4;
+    typedef TD td4 __attribute__((ext_vector_type(4)));
     if (act)
         for (int t1 = blockIdx.x; t1 < T1; t1 += gridDim.x)
-        for (int f1 = pl; f1 < F1; f1 += ppb) {
-            const float* xp = x + ((int64_t)b * F + 2 * f1) * T + 2 * t1;
-            float xv[9];
+        for (int f0 = pl; f0 < F1; f0 += U * ppb) {
+            float xv[U][9];
+            td4 dv[U];
 #pragma unroll
-            for (int kf = 0; kf < 3; ++kf)
+            for (int u = 0; u < U; ++u) {                              // (positions beyond F1 read position f1 = F1-1: never used)
+                const int f1 = min(f0 + u * ppb, F1 - 1);
+                const float* xp = x + ((int64_t)b * F + 2 * f1) * T + 2 * t1;
 #pragma unroll
-                for (int kt = 0; kt < 3; ++kt) xv[kf * 3 + kt] = xp[kf * T + kt];
-            const f32x4 d = *reinterpret_cast<const f32x4*>(dh1 + (((int64_t)b * T1 + t1) * F1 + f1) * C + c4 * 4);
+                for (int kf = 0; kf < 3; ++kf)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                float pre = bb[i];
+                    for (int kt = 0; kt < 3; ++kt) xv[u][kf * 3 + kt] = xp[kf * T + kt];
+                dv[u] = *reinterpret_cast<const td4*>(dh1 + (((int64_t)b * T1 + t1) * F1 + f1) * C + c4 * 4);
+            }
 #pragma unroll
-                for (int j = 0; j < 9; ++j) pre = fmaf(w[i][j], xv[j], pre);
-                const float dz = pre > 0.f ? d[i] : 0.f;
+            for (int u = 0; u < U; ++u) {
+                const bool ok = f0 + u * ppb < F1;
 #pragma unroll
-                for (int j = 0; j < 9; ++j) acc[i][j] = fmaf(dz, xv[j], acc[i][j]);
-                acc[i][9] += dz;
+                for (int i = 0; i < 4; ++i) {
+                    float pre = bb[i];
+#pragma unroll
+                    for (int j = 0; j < 9; ++j) pre = fmaf(w[i][j], xv[u][j], pre);
+                    const float dz = (ok && pre > 0.f) ? (float)dv[u][i] : 0.f;
+#pragma unroll
+                    for (int j = 0; j < 9; ++j) acc[i][j] = fmaf(dz, xv[u][j], acc[i][j]);
+                    acc[i][9] += dz;
+                }
             }
         }
     // threads with the same c4 (different pl) hold partials of the same channels: combine via atomics on global
@@ -215,8 +230,31 @@ extern "C" int cfm_subsample_conv1_bwd_f32(const float* x, const float* w1, cons
     CFM_REQUIRE(B <= 65535, CFM_ERR_UNSUPPORTED);
     int groups = (768 + B - 1) / B;                     // ~768 workgroups in all: 40 atomics per thread at the end
     groups = groups < 1 ? 1 : (groups > T1 ? T1 : groups);
-    hipLaunchKernelGGL(conv1_bwd_kernel, dim3((unsigned)groups, (unsigned)B), dim3(256), 0, static_cast<hipStream_t>(stream), x, w1,
-                       b1, dh1, dw1, db1, B, F, T, C, F1, T1, ppb);
+    hipLaunchKernelGGL(conv1_bwd_kernel<float>, dim3((unsigned)groups, (unsigned)B), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       x, w1, b1, dh1, dw1, db1, B, F, T, C, F1, T1, ppb);
+    return cfm_launch_status();
+}
+
+// cfm_subsample_conv1_bwd_f32 with dh1 stored in the 16-bit type `prec` (cfm_subsample_conv2_bwd_input_fwdkernel_out16_mfma16_f32)
+extern "C" int cfm_subsample_conv1_bwd_d16_f32(int prec, const float* x, const float* w1, const float* b1, const void* dh1_16,
+                                               float* dw1, float* db1, int B, int F, int T, int C, cfm_stream_t stream) {
+    CFM_REQUIRE(x && w1 && b1 && dh1_16 && dw1 && db1, CFM_ERR_NULL);
+    CFM_REQUIRE(B > 0 && F >= 3 && T >= 3 && C > 0 && (C & 3) == 0, CFM_ERR_BAD_SHAPE);
+    CFM_REQUIRE(C <= 1024 && B <= 65535, CFM_ERR_UNSUPPORTED);
+    CFM_REQUIRE((reinterpret_cast<uintptr_t>(dh1_16) & 7) == 0, CFM_ERR_ALIGN);
+    const int F1 = (F - 1) / 2, T1 = (T - 1) / 2;
+    const int ppb = 256 / (C / 4);
+    int groups = (768 + B - 1) / B;
+    groups = groups < 1 ? 1 : (groups > T1 ? T1 : groups);
+    const dim3 grid((unsigned)groups, (unsigned)B);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (prec == CFM_PREC_BF16)
+        hipLaunchKernelGGL(conv1_bwd_kernel<__bf16>, grid, dim3(256), 0, s, x, w1, b1, static_cast<const __bf16*>(dh1_16), dw1, db1, B, F,
+                           T, C, F1, T1, ppb);
+    else if (prec == CFM_PREC_FP16)
+        hipLaunchKernelGGL(conv1_bwd_kernel<_Float16>, grid, dim3(256), 0, s, x, w1, b1, static_cast<const _Float16*>(dh1_16), dw1, db1,
+                           B, F, T, C, F1, T1, ppb);
+    else return CFM_ERR_UNSUPPORTED;
     return cfm_launch_status();
 }
 

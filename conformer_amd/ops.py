@@ -903,21 +903,27 @@ def subsample_stem_bwd(x, w1, b1, w2, h1, h2, dh2):
                                                               _stream()), "cfm_subsample_conv2_bwd_weight_f32")
     w2c = torch.empty(9 * C * C, device=x.device, dtype=x.dtype)
     _lib.check(lib.cfm_pack_conv2_weight_t_f32(w2.data_ptr(), w2c.data_ptr(), C, _stream()), "cfm_pack_conv2_weight_t_f32")
-    dh1 = torch.empty(h1.shape, device=h1.device, dtype=torch.float32)          # (h1 itself may be stored in the 16-bit type)
+    # dh1: fp32, or -- all-16-bit stem of the autocast path -- in the 16-bit type: its only consumer is the conv1 parameter-gradient
+    # reduction, and under torch.autocast conv1's incoming gradient is a 16-bit tensor.  (Never empty_like(h1) for the fp32 case:
+    # h1 itself may be stored in the 16-bit type.)
+    d16 = bool(prec and h16)
+    dh1 = torch.empty(h1.shape, device=h1.device, dtype=_DT16[prec] if d16 else torch.float32)
     if prec:
         # transposed conv as four parity-class implicit GEMMs on the FORWARD 16-bit kernel (two-tile prefetch, row-major epilogue)
         w2c16 = torch.empty(9 * C * C, device=x.device, dtype=_DT16[prec])
         _lib.check(lib.cfm_cast16_f32(prec, w2c.data_ptr(), w2c16.data_ptr(), w2c.numel(), _stream()), "cfm_cast16_f32")
-        _lib.check(lib.cfm_subsample_conv2_bwd_input_fwdkernel_mfma16_f32(prec, dz2.data_ptr(), int(dz2.dtype != torch.float32),
-                                                                          w2c16.data_ptr(),
-                                                                          _zero_bias(C, x.device).data_ptr(), dh1.data_ptr(), B, F1,
-                                                                          T1, C, _stream()),
-                   "cfm_subsample_conv2_bwd_input_fwdkernel_mfma16_f32")
+        fn = lib.cfm_subsample_conv2_bwd_input_fwdkernel_out16_mfma16_f32 if d16 else lib.cfm_subsample_conv2_bwd_input_fwdkernel_mfma16_f32
+        _lib.check(fn(prec, dz2.data_ptr(), int(dz2.dtype != torch.float32), w2c16.data_ptr(), _zero_bias(C, x.device).data_ptr(),
+                      dh1.data_ptr(), B, F1, T1, C, _stream()), "cfm_subsample_conv2_bwd_input_fwdkernel_mfma16_f32")
     else:
         _lib.check(lib.cfm_subsample_conv2_bwd_input_f32(dz2.data_ptr(), w2c.data_ptr(), dh1.data_ptr(), B, F1, T1, C,
                                                          _stream()), "cfm_subsample_conv2_bwd_input_f32")
-    _lib.check(lib.cfm_subsample_conv1_bwd_f32(x.data_ptr(), w1.data_ptr(), b1.data_ptr(), dh1.data_ptr(), dw1.data_ptr(),
-                                               db1.data_ptr(), B, F, T, C, _stream()), "cfm_subsample_conv1_bwd_f32")
+    if d16:
+        _lib.check(lib.cfm_subsample_conv1_bwd_d16_f32(prec, x.data_ptr(), w1.data_ptr(), b1.data_ptr(), dh1.data_ptr(), dw1.data_ptr(),
+                                                       db1.data_ptr(), B, F, T, C, _stream()), "cfm_subsample_conv1_bwd_d16_f32")
+    else:
+        _lib.check(lib.cfm_subsample_conv1_bwd_f32(x.data_ptr(), w1.data_ptr(), b1.data_ptr(), dh1.data_ptr(), dw1.data_ptr(),
+                                                   db1.data_ptr(), B, F, T, C, _stream()), "cfm_subsample_conv1_bwd_f32")
     dw2 = dw2p.view(C, 3, 3, C).permute(0, 3, 1, 2).contiguous()        # packed (co,kf,kt,ci) -> (co,ci,kf,kt): tiny glue
     return dw1, db1, dw2, db2
 

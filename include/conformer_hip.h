@@ -196,6 +196,13 @@ int cfm_relu_bwd_out16_f32(int prec, const float* y, const float* dy, void* dz16
 int cfm_subsample_conv2_bwd_input_fwdkernel_mfma16_f32(int prec, const void* dz2, int dz2_is_16bit, const void* w2c16,
                                                        const float* zero_bias, float* dh1, int B, int F1, int T1,
                                                        int C, cfm_stream_t stream);
+/* ... the same with dh1 stored in the 16-bit type `prec` (its only consumer is the conv1 parameter-gradient reduction; under
+ * torch.autocast conv1's incoming gradient is a 16-bit tensor), and that reduction reading it: */
+int cfm_subsample_conv2_bwd_input_fwdkernel_out16_mfma16_f32(int prec, const void* dz2, int dz2_is_16bit, const void* w2c16,
+                                                             const float* zero_bias, void* dh1_16, int B, int F1, int T1, int C,
+                                                             cfm_stream_t stream);
+int cfm_subsample_conv1_bwd_d16_f32(int prec, const float* x, const float* w1, const float* b1, const void* dh1_16, float* dw1,
+                                    float* db1, int B, int F, int T, int C, cfm_stream_t stream);
 int cfm_subsample_conv2_bwd_weight_mfma16_f32(int prec, const float* dz2, const float* h1, float* dw2p, int B, int F1,
                                               int T1, int C, cfm_stream_t stream);
 int cfm_subsample_conv2_bwd_input_mfma16_f32(int prec, const float* dz2, const float* w2c, float* dh1, int B, int F1,

@@ -302,4 +302,94 @@ def test_stem_backward_bf16_class_gather_next_to_poison(dev, C):
     assert P.intact() and torch.isfinite(dh1_b).all() and torch.isfinite(dw_b).all()
     assert rel_l2(dh1_b, dh1_a) < 1e-5 and rel_l2(dw_b, dw_a) < 1e-4
     assert rel_l2(db_b, dzr.double().sum(dim=(0, 1, 2)).float()) < 1e-5
+    # ---- dh1 stored in the 16-bit type (its only consumer: the conv1 parameter gradients): the same accumulators rounded once at
+    #      the store, every element written, poison intact; the conv1 reduction from it = the fp32 reduction of the same values
+    dh1_16 = torch.full((B, T1, F1, C), float("inf"), device=dev).to(torch.bfloat16)
+    dh1_16 = P.place(dh1_16)
+    assert lib.cfm_subsample_conv2_bwd_input_fwdkernel_out16_mfma16_f32(1, dz16.data_ptr(), 1, w2c16.data_ptr(), zb.data_ptr(),
+                                                                        dh1_16.data_ptr(), B, F1, T1, C, st) == 0
+    torch.cuda.synchronize()
+    assert P.intact() and torch.isfinite(dh1_16.float()).all()
+    assert torch.equal(dh1_16, dh1_b.to(torch.bfloat16))
+    F, T = 2 * F1 + 1, 2 * T1 + 2                           # an input extent that gives (F1, T1)
+    x = P.place(torch.randn(B, F, T, generator=g).to(dev))
+    w1 = P.place((torch.randn(C, 1, 3, 3, generator=g) / 3).to(dev))
+    b1 = P.place((torch.randn(C, generator=g) * 0.1).to(dev))
+    dw_16, db_16 = P.like((C, 9), fill=0.0), P.like((C,), fill=0.0)
+    dw_32, db_32 = torch.zeros(C, 9, device=dev), torch.zeros(C, device=dev)
+    assert lib.cfm_subsample_conv1_bwd_d16_f32(1, x.data_ptr(), w1.data_ptr(), b1.data_ptr(), dh1_16.data_ptr(), dw_16.data_ptr(),
+                                               db_16.data_ptr(), B, F, T, C, st) == 0
+    up = dh1_16.float()
+    assert lib.cfm_subsample_conv1_bwd_f32(x.data_ptr(), w1.data_ptr(), b1.data_ptr(), up.data_ptr(), dw_32.data_ptr(), db_32.data_ptr(),
+                                           B, F, T, C, st) == 0
+    torch.cuda.synchronize()
+    assert P.intact() and rel_l2(dw_16, dw_32) < 1e-5 and rel_l2(db_16, db_32) < 1e-5
+    # float64: gradient of sum(relu(conv1(x)) * dh1) w.r.t. (w1, b1)
+    xd = x.double().cpu().unsqueeze(1)                       # (B, 1, F, T)
+    w1d, b1d = w1.double().cpu().requires_grad_(True), b1.double().cpu().requires_grad_(True)
+    h = torch.relu(torch.nn.functional.conv2d(xd, w1d, b1d, stride=2))   # (B, C, F1, T1)
+    (h * up.double().cpu().permute(0, 3, 2, 1)).sum().backward()
+    assert rel_l2(dw_16, w1d.grad.reshape(C, 9)) < 1e-4 and rel_l2(db_16, b1d.grad) < 1e-4
 
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 264, 128), (300, 260, 128), (77, 72, 64), (7968, 2048, 64), (4100, 512, 128)])
+@pytest.mark.parametrize("epi", ["bias", "swish", "resid", "dswish"])
+def test_gemm16_epilogue_paths_next_to_poison(dev, M, N, K, epi):
+    """The 16-bit GEMM's row-major epilogue has a 4-column and an 8-column (16-byte stores for 16-bit outputs) form, fetches
+    its bias / residual / Z operands ahead of the stores, and loops over row groups: every form is checked through the C ABI
+    against float64 on the rounded operands, with every output inside a NaN-poisoned slab (nothing outside it may change)
+    -- N % 8 == 0 takes the wide form for 16-bit outputs, N % 8 == 4 the narrow one, 7968 x 2048 the 256x256 tile."""
+    from conformer_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(M + N + K)
+    bf = torch.bfloat16
+    a = torch.randn(M, K, generator=g).to(dev)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(dev)
+    bias = torch.randn(N, generator=g).to(dev)
+    res = torch.randn(M, N, generator=g).to(dev)
+    zin = torch.randn(M, N, generator=g).to(dev).to(bf)
+    a16, w16 = a.to(bf).contiguous(), w.to(bf).contiguous()
+    acc = a16.double() @ w16.double().t()
+    st = torch.cuda.current_stream().cuda_stream
+
+    def slab(dtype):                                                   # output of M x N inside a poisoned allocation
+        full = torch.full((M + 16, N), float("nan"), device=dev, dtype=dtype)
+        return full, full[8:8 + M]
+
+    for c16 in ((False, True) if epi != "resid" else (False,)):
+        cfull, c = slab(bf if c16 else torch.float32)
+        z16 = N % 8 == 0                                               # (the entry point takes 16-bit Z tensors at N % 8 == 0 only)
+        zfull, z = slab(bf if z16 else torch.float32)
+        if epi == "bias":
+            rc = lib.cfm_gemm_mfma16_f32(1, 0, a16.data_ptr(), 1, w16.data_ptr(), 1, bias.data_ptr(), None, 1.0, c.data_ptr(), int(c16),
+                                         None, 0, M, N, K, K, N, N, 0.0, 0, st)
+            want = acc + bias.double()
+        elif epi == "swish":
+            rc = lib.cfm_gemm_mfma16_f32(1, 1, a16.data_ptr(), 1, w16.data_ptr(), 1, bias.data_ptr(), None, 1.0, c.data_ptr(), int(c16),
+                                         z.data_ptr(), int(z16), M, N, K, K, N, N, 0.0, 0, st)
+            zz = acc + bias.double()
+            want = zz * torch.sigmoid(zz)
+        elif epi == "resid":
+            rc = lib.cfm_gemm_mfma16_f32(1, 4, a16.data_ptr(), 1, w16.data_ptr(), 1, bias.data_ptr(), res.data_ptr(), 0.5, c.data_ptr(), 0,
+                                         None, 0, M, N, K, K, N, N, 0.0, 0, st)
+            want = 0.5 * (acc + bias.double()) + res.double()
+        else:
+            rc = lib.cfm_gemm_mfma16_f32(1, 5, a16.data_ptr(), 1, w16.data_ptr(), 1, None, None, 0.7, c.data_ptr(), int(c16),
+                                         zin.data_ptr(), 1, M, N, K, K, N, N, 0.0, 0, st)
+            if N % 8:                                                  # refused, not mis-indexed
+                assert rc != 0
+                continue
+            zd = zin.double()
+            sg = torch.sigmoid(zd)
+            want = 0.7 * acc * (sg * (1 + zd * (1 - sg)))
+        assert rc == 0, (epi, c16, rc)
+        torch.cuda.synchronize()
+        tol = 6e-3 if c16 else 2e-5                                   # a bf16 result carries its own rounding (2^-9 relative)
+        err = (c.double() - want).abs().max() / want.abs().max()
+        assert torch.isfinite(c.float()).all() and err < tol, (epi, c16, float(err))
+        assert torch.isnan(cfull[:8].float()).all() and torch.isnan(cfull[8 + M:].float()).all(), (epi, c16, "C neighbours")
+        if epi == "swish":
+            zerr = (z.double() - (acc + bias.double())).abs().max() / (acc + bias.double()).abs().max()
+            assert zerr < 6e-3, float(zerr)
+            assert torch.isnan(zfull[:8].float()).all() and torch.isnan(zfull[8 + M:].float()).all(), "Z neighbours"
