@@ -206,7 +206,7 @@ __global__ __launch_bounds__(256, 2) void gemm_dw16_kernel(const DwArgs g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    auto multiply = [&](int stage) {
+    auto multiply = [&](int stage, auto&& after_step0, auto&& after_step1) {
         const T16* As = lds + stage * 2 * STAGE;
         const T16* Bs = As + STAGE;
         x8 fa[2][2], fb[2][2];
@@ -225,6 +225,8 @@ __global__ __launch_bounds__(256, 2) void gemm_dw16_kernel(const DwArgs g) {
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = Lowp<T16>::mfma(fa[s & 1][mt], fb[s & 1][nt], acc[mt][nt]);
+            if (s == 0) after_step0();
+            if (s == 1) after_step1();
         }
     };
 
@@ -240,10 +242,11 @@ __global__ __launch_bounds__(256, 2) void gemm_dw16_kernel(const DwArgs g) {
     lds_barrier();
     if (tracer) tr[1] = __builtin_amdgcn_s_memrealtime();
     auto step = [&](auto fast, int kt, Set& nxt) {
-        multiply(kt & 1);
-        __builtin_amdgcn_sched_barrier(0);
-        if (decltype(fast)::value || kt + 1 < nkt) store_set(fast, nxt, kt + 1, (kt + 1) & 1);
-        load_set(fast, nxt, kt + 3);
+        // the staging of tile kt+1 (its LDS stage has been free since the last barrier) and the refill request ride behind the
+        // first two MFMA steps instead of following the last one, when every wave of the CU did them with the matrix pipe idle
+        multiply(kt & 1,
+                 [&]() { if (decltype(fast)::value || kt + 1 < nkt) store_set(fast, nxt, kt + 1, (kt + 1) & 1); },
+                 [&]() { load_set(fast, nxt, kt + 3); });
         lds_barrier();
         if (tracer && kt < 58) tr[2 + kt] = __builtin_amdgcn_s_memrealtime();
     };
