@@ -9,23 +9,26 @@ namespace {
 // A workgroup owns one (utterance, output frame t1) row of h1 -- F1 x C contiguous outputs -- and walks f1: no index
 // arithmetic per position.  (The first version flattened (b, t1, f1) into one 64-bit position index and paid two 64-bit
 // divisions per position and thread: it ran at 1.9 TB/s of stores, ALU-bound on the divisions, not write-bound.)
-template <typename TOUT>     // float, or the 16-bit matrix-pipe type when h1 only feeds the 16-bit conv2 GEMM (inference under autocast)
+// CPT channels per thread: 4 (one 16-byte fp32 store) or, for a 16-bit h1, 8 (one 16-byte store of eight values: the write-out
+// is bound by the number of store instructions, not by their width).
+template <typename TOUT, int CPT>   // TOUT: float, or the 16-bit matrix-pipe type when h1 only feeds the 16-bit conv2 GEMM
 __global__ __launch_bounds__(256) void conv1_relu_kernel(const float* __restrict__ x, const float* __restrict__ w1,
                                                          const float* __restrict__ b1, TOUT* __restrict__ h1,
                                                          int B, int F, int T, int C, int F1, int T1, int ppb) {
-    const int c4n = C >> 2;
-    const int c4 = threadIdx.x % c4n;
-    const int pl = threadIdx.x / c4n;
+    const int cgn = C / CPT;
+    const int cg = threadIdx.x % cgn;
+    const int pl = threadIdx.x / cgn;
     if (pl >= ppb) return;
-    float w[4][9];
+    float w[CPT][9], bb[CPT];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < CPT; ++i) {
 #pragma unroll
-        for (int j = 0; j < 9; ++j) w[i][j] = w1[(c4 * 4 + i) * 9 + j];
-    const f32x4 bb = *reinterpret_cast<const f32x4*>(b1 + c4 * 4);
+        for (int j = 0; j < 9; ++j) w[i][j] = w1[(cg * CPT + i) * 9 + j];
+        bb[i] = b1[cg * CPT + i];
+    }
     const int t1 = blockIdx.x, b = blockIdx.y;
     const float* xb = x + (int64_t)b * F * T + 2 * t1;
-    TOUT* hrow = h1 + ((int64_t)b * T1 + t1) * F1 * C + c4 * 4;
+    TOUT* hrow = h1 + ((int64_t)b * T1 + t1) * F1 * C + cg * CPT;
     for (int f1 = pl; f1 < F1; f1 += ppb) {
         const float* xp = xb + (int64_t)(2 * f1) * T;
         float xv[9];
@@ -33,17 +36,25 @@ __global__ __launch_bounds__(256) void conv1_relu_kernel(const float* __restrict
         for (int kf = 0; kf < 3; ++kf)
 #pragma unroll
             for (int kt = 0; kt < 3; ++kt) xv[kf * 3 + kt] = xp[kf * T + kt];
-        f32x4 o = bb;
+        float o[CPT];
 #pragma unroll
-        for (int j = 0; j < 9; ++j) {
-            o.x = fmaf(w[0][j], xv[j], o.x);
-            o.y = fmaf(w[1][j], xv[j], o.y);
-            o.z = fmaf(w[2][j], xv[j], o.z);
-            o.w = fmaf(w[3][j], xv[j], o.w);
+        for (int i = 0; i < CPT; ++i) {
+            o[i] = bb[i];
+#pragma unroll
+            for (int j = 0; j < 9; ++j) o[i] = fmaf(w[i][j], xv[j], o[i]);
+            o[i] = fmaxf(o[i], 0.f);
         }
-        o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
-        if constexpr (sizeof(TOUT) == 4) *reinterpret_cast<f32x4*>(hrow + (int64_t)f1 * C) = o;
-        else *reinterpret_cast<typename Lowp<TOUT>::x4*>(hrow + (int64_t)f1 * C) = Lowp<TOUT>::cvt4(o);
+        if constexpr (sizeof(TOUT) == 4) {
+            static_assert(sizeof(TOUT) != 4 || CPT == 4, "fp32 h1: 4 channels per thread");
+            *reinterpret_cast<f32x4*>(hrow + (int64_t)f1 * C) = f32x4{o[0], o[1], o[2], o[3]};
+        } else if constexpr (CPT == 8) {
+            typename Lowp<TOUT>::x8 r;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) r[i] = (TOUT)o[i];
+            *reinterpret_cast<typename Lowp<TOUT>::x8*>(hrow + (int64_t)f1 * C) = r;
+        } else {
+            *reinterpret_cast<typename Lowp<TOUT>::x4*>(hrow + (int64_t)f1 * C) = Lowp<TOUT>::cvt4(f32x4{o[0], o[1], o[2], o[3]});
+        }
     }
 }
 
@@ -267,8 +278,8 @@ extern "C" int cfm_subsample_conv1_relu_f32(const float* x, const float* w1, con
     const int F1 = (F - 1) / 2, T1 = (T - 1) / 2;
     const int ppb = 256 / (C / 4);
     CFM_REQUIRE(B <= 65535, CFM_ERR_UNSUPPORTED);
-    hipLaunchKernelGGL(conv1_relu_kernel<float>, dim3((unsigned)T1, (unsigned)B), dim3(256), 0, static_cast<hipStream_t>(stream), x, w1,
-                       b1, h1, B, F, T, C, F1, T1, ppb);
+    hipLaunchKernelGGL((conv1_relu_kernel<float, 4>), dim3((unsigned)T1, (unsigned)B), dim3(256), 0, static_cast<hipStream_t>(stream), x,
+                       w1, b1, h1, B, F, T, C, F1, T1, ppb);
     return cfm_launch_status();
 }
 
@@ -279,18 +290,20 @@ extern "C" int cfm_subsample_conv1_relu_out16_f32(int prec, const float* x, cons
     CFM_REQUIRE(x && w1 && b1 && h1, CFM_ERR_NULL);
     CFM_REQUIRE(B > 0 && F >= 3 && T >= 3 && C > 0 && (C & 3) == 0 && C <= 1024, CFM_ERR_BAD_SHAPE);
     const int F1 = (F - 1) / 2, T1 = (T - 1) / 2;
-    const int ppb = 256 / (C / 4) > 0 ? 256 / (C / 4) : 0;
+    const bool wide = (C & 7) == 0 && (reinterpret_cast<uintptr_t>(h1) & 15) == 0;     // eight channels per thread, 16-byte stores
+    const int cpt = wide ? 8 : 4;
+    const int ppb = 256 / (C / cpt) > 0 ? 256 / (C / cpt) : 0;
     CFM_REQUIRE(ppb > 0, CFM_ERR_UNSUPPORTED);
     CFM_REQUIRE(B <= 65535, CFM_ERR_UNSUPPORTED);
     const dim3 grid((unsigned)T1, (unsigned)B);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (prec == CFM_PREC_BF16)
-        hipLaunchKernelGGL(conv1_relu_kernel<__bf16>, grid, dim3(256), 0, s, x, w1, b1, static_cast<__bf16*>(h1),
-                           B, F, T, C, F1, T1, ppb);
-    else if (prec == CFM_PREC_FP16)
-        hipLaunchKernelGGL(conv1_relu_kernel<_Float16>, grid, dim3(256), 0, s, x, w1, b1,
-                           static_cast<_Float16*>(h1), B, F, T, C, F1, T1, ppb);
-    else return CFM_ERR_UNSUPPORTED;
+    if (prec == CFM_PREC_BF16) {
+        if (wide) hipLaunchKernelGGL((conv1_relu_kernel<__bf16, 8>), grid, dim3(256), 0, s, x, w1, b1, static_cast<__bf16*>(h1), B, F, T, C, F1, T1, ppb);
+        else hipLaunchKernelGGL((conv1_relu_kernel<__bf16, 4>), grid, dim3(256), 0, s, x, w1, b1, static_cast<__bf16*>(h1), B, F, T, C, F1, T1, ppb);
+    } else if (prec == CFM_PREC_FP16) {
+        if (wide) hipLaunchKernelGGL((conv1_relu_kernel<_Float16, 8>), grid, dim3(256), 0, s, x, w1, b1, static_cast<_Float16*>(h1), B, F, T, C, F1, T1, ppb);
+        else hipLaunchKernelGGL((conv1_relu_kernel<_Float16, 4>), grid, dim3(256), 0, s, x, w1, b1, static_cast<_Float16*>(h1), B, F, T, C, F1, T1, ppb);
+    } else return CFM_ERR_UNSUPPORTED;
     return cfm_launch_status();
 }
 
