@@ -285,9 +285,9 @@ int launch_big(GemmArgs g, int src16, hipStream_t s) {          // 512-thread wo
     g.tiles_m = (unsigned)((g.M + BM - 1) / BM);
     g.tiles_n = (unsigned)((g.N + BN - 1) / BN);
     const dim3 grid(g.tiles_m * g.tiles_n);
-    if constexpr (CONV == 2) {
-        if (src16 == 2) hipLaunchKernelGGL((gemm_mfma16_kernel<T16, BM, BN, EPI, 2, true, true, 4>), grid, dim3(512), 0, s, g);
-        else hipLaunchKernelGGL((gemm_mfma16_kernel<T16, BM, BN, EPI, 2, true, false, 4>), grid, dim3(512), 0, s, g);
+    if constexpr (CONV != 0) {
+        if (src16 == 2) hipLaunchKernelGGL((gemm_mfma16_kernel<T16, BM, BN, EPI, CONV, true, true, 4>), grid, dim3(512), 0, s, g);
+        else hipLaunchKernelGGL((gemm_mfma16_kernel<T16, BM, BN, EPI, CONV, true, false, 4>), grid, dim3(512), 0, s, g);
     } else {
         if (src16 == 2) hipLaunchKernelGGL((gemm_mfma16_kernel<T16, BM, BN, EPI, 0, true, true, 4>), grid, dim3(512), 0, s, g);
         else hipLaunchKernelGGL((gemm_mfma16_kernel<T16, BM, BN, EPI, 0, true, false, 4>), grid, dim3(512), 0, s, g);
@@ -303,9 +303,10 @@ int launch_t(const GemmArgs& g, int src16, hipStream_t s) {
     if constexpr (EPI == EPI_GLU) {
         return t128 >= 512 ? launch_cfg<T16, 128, 128, EPI, CONV>(g, src16, s) : launch_cfg<T16, 64, 128, EPI, CONV>(g, src16, s);
     } else {
-        if constexpr (CONV == 2) {                                // transposed-conv classes: hundreds of thousands of rows, N = C
-            if (src16 >= 1 && gemm_epilogue_vec_ok_host(g, EPI) && (g.N % 256) == 0 && g.occ_cap != 1)
-                return launch_big<T16, 256, 256, EPI, 2>(g, src16, s);
+        if constexpr (CONV != 0) {                                // the stem's conv2 (forward im2col gather / transposed-conv classes):
+            if (src16 >= 1 && gemm_epilogue_vec_ok_host(g, EPI) && (g.N % 256) == 0 && g.occ_cap != 1 &&      // 10^5 rows, N = C
+                (g.M + 255) / 256 * (g.N / 256) >= 224)
+                return launch_big<T16, 256, 256, EPI, CONV>(g, src16, s);
         }
         if constexpr (CONV == 0) {
             // big tiles (one 8-wave workgroup per CU) once they fill the chip about once over: half / three quarters of the
@@ -451,6 +452,7 @@ extern "C" int cfm_subsample_conv2_relu_mfma16_f32(int prec, const void* h1, int
     g.A = static_cast<const float*>(h1); g.W = static_cast<const float*>(w2p); g.bias = b2; g.C = static_cast<float*>(h2);
     g.c_prec = h2_is_16bit ? prec : 0;
     g.M = (int64_t)B * g.cT2 * g.cF2; g.N = C; g.K = 9 * C; g.lda = 0; g.ldc = C; g.alpha = 1.f;
+    g.occ_cap = g_gemm16_force_tile;
     return launch<EPI_RELU, 1>(prec, g, h1_is_16bit ? 2 : (w_is_16bit ? 1 : 0), static_cast<hipStream_t>(stream));
 }
 
