@@ -319,7 +319,15 @@ int launch_t(const GemmArgs& g, int src16, hipStream_t s) {
                 if (force == 2 || (force == 0 && t2128 >= 224)) return launch_big<T16, 256, 128, EPI>(g, src16, s);
             }
         }
-        return t128 >= 512 ? launch_cfg<T16, 128, 128, EPI, CONV>(g, src16, s) : launch_cfg<T16, 64, 64, EPI, CONV>(g, src16, s);
+        if (t128 >= 512 && g.occ_cap < 4) return launch_cfg<T16, 128, 128, EPI, CONV>(g, src16, s);   // (tuning hook: 4 = 128x64, 5 = 64x64)
+        if constexpr (CONV == 0 && (EPI == EPI_RESID || EPI == EPI_BIAS)) {
+            // between the two: 128x64 tiles (three fragment reads per two MFMAs instead of two per one) once they give every CU
+            // about two workgroups -- the N = 512 products of the B = 32 forward (FFN out, attention out, pointwise conv 2)
+            const int64_t t12864 = ((g.M + 127) / 128) * ((g.N + 63) / 64);
+            if ((t12864 >= 448 && g.K >= 1024 && g.occ_cap < 4) || g.occ_cap == 4) return      // (K = 512: no difference, measured)
+                launch_cfg<T16, 128, 64, EPI, CONV>(g, src16, s);
+        }
+        return launch_cfg<T16, 64, 64, EPI, CONV>(g, src16, s);
     }
 }
 
