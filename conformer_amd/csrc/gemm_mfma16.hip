@@ -200,7 +200,7 @@ __global__ __launch_bounds__(WM * 128, 2) void gemm_mfma16_kernel(const GemmArgs
         const bool more = kt + 1 < nkt;
         // per-wave software pipeline: the fragments of MFMA step s+1 are read while step s multiplies (one exposed LDS
         // latency per K-tile instead of four: the trace showed ~1.2 us per K-tile against 0.23 us of MFMA time)
-        constexpr int NF = (WM == 4 && BN == 256) ? 1 : 2;       // (the 256x256 tile has no registers left for a second set)
+        constexpr int NF = (WM == 4 && BN == 256 && !A16) ? 1 : 2;   // (256x256 with an fp32 A operand: no registers left for a second set)
         x8 fa[NF][TM], fb[NF][TN];
         auto read_frags = [&](int set, int s) {
 #pragma unroll
