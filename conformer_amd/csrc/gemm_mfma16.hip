@@ -315,7 +315,7 @@ int launch_t(const GemmArgs& g, int src16, hipStream_t s) {
             if (src16 >= 1 && gemm_epilogue_vec_ok_host(g, EPI)) {
                 const int64_t rows256 = (g.M + 255) / 256;
                 const int64_t t256 = rows256 * ((g.N + 255) / 256), t2128 = rows256 * ((g.N + 127) / 128);
-                if (force == 3 || (force == 0 && t256 >= 224)) return launch_big<T16, 256, 256, EPI>(g, src16, s);
+                if (force == 3 || (force == 0 && t256 >= 190)) return launch_big<T16, 256, 256, EPI>(g, src16, s);   // (192 tiles: the B=32 QKV product, 25.7 vs 29.9 us on 256x128)
                 if (force == 2 || (force == 0 && t2128 >= 224)) return launch_big<T16, 256, 128, EPI>(g, src16, s);
             }
         }
