@@ -150,13 +150,15 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 128) ? 3 : 4) void gemm_f3
 // gets a long queue of tiles (>= ~12 per CU: conv2, big square GEMMs) so that prologue/epilogue phases of different
 // blocks overlap; the K=512 layer GEMMs (4 tiles per CU or fewer, all resident at once) prefer 128x64, and the
 // N=512 GEMMs (1 tile per CU at 128x128) prefer 64x64.
-inline int choose_tile(int64_t M, int ncols, bool glu) {
+inline int choose_tile(int64_t M, int ncols, bool glu, int K) {
     const int bn = glu ? 64 : 128;
     const int64_t n128 = ((M + 127) / 128) * ((ncols + bn - 1) / bn);
     if (n128 >= 12 * 256) return 0;
     if (glu) return 2;
     if (n128 > 690 && n128 <= 768) return 0;      // exactly one full round at 3 blocks/CU (fused QKV: 756 tiles)
     if (n128 >= 3 * 256) return 1;
+    // long contractions (the input Linear, K = 9728): 128x64 once it gives ~2 workgroups per CU: 639 vs 670 us on 64x64
+    if (K >= 4096 && ((M + 127) / 128) * ((ncols + 63) / 64) >= 448) return 1;
     return 3;
 }
 
@@ -181,7 +183,7 @@ int launch_cfg(GemmArgs g, hipStream_t s) {
 template <int EPI, bool CONV>
 int launch(const GemmArgs& g, hipStream_t s, int force_cfg = -1) {
     const int ncols = EPI == EPI_GLU ? g.n_out : g.N;
-    const int tile = force_cfg >= 0 ? force_cfg : choose_tile(g.M, ncols, EPI == EPI_GLU);
+    const int tile = force_cfg >= 0 ? force_cfg : choose_tile(g.M, ncols, EPI == EPI_GLU, g.K);
     if constexpr (EPI == EPI_GLU) {
         return (tile == 0 || tile == 1) ? launch_cfg<128, 128, EPI, CONV>(g, s) : launch_cfg<64, 128, EPI, CONV>(g, s);
     } else {
@@ -313,7 +315,7 @@ extern "C" int cfm_debug_gemm_cfg_f32(int cfg, const float* A, const float* W, c
     CFM_REQUIRE(R != nullptr, CFM_ERR_NULL);
     g.occ_cap = cfg >= 0 ? (cfg >> 8) : 0;            // cfg + 256*cap: blocks/CU cap
     if (cfg >= 0) cfg &= 255;
-    CFM_REQUIRE(cfg >= -1 && (cfg & 15) <= 3 && cfg < 48, CFM_ERR_BAD_SHAPE);
+    CFM_REQUIRE(cfg >= -1 && (cfg < 0 || (cfg & 15) <= 3) && cfg < 48, CFM_ERR_BAD_SHAPE);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (cfg >= 32) return launch<EPI_SWISH, false>(g, s, cfg & 15);     // cfg + 32: swish epilogue (no residual read)
     if (cfg >= 16) return launch<EPI_BIAS, false>(g, s, cfg & 15);      // cfg + 16: bias epilogue
