@@ -12,8 +12,10 @@ __global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ 
     if (i >= n4) return;
     const float inv_keep = 1.0f / (1.0f - p);
     f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
+    float keep[4];
+    dropout_keep4(seed, (unsigned long long)(4 * i), p, inv_keep, keep);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] *= dropout_keep(seed, (unsigned long long)(4 * i + e), p, inv_keep);
+    for (int e = 0; e < 4; ++e) v[e] *= keep[e];
     reinterpret_cast<f32x4*>(y)[i] = v;
 }
 

@@ -257,8 +257,12 @@ __global__ __launch_bounds__(256, 2) void relpos_attn_fwd_kernel(const AttnArgs 
                 const float inv_keep = 1.0f / (1.0f - a.drop_p);
                 const unsigned long long rowbase = ((unsigned long long)bh * T + (unsigned)(i0 + li)) * (unsigned long long)T;
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    p[r] *= dropout_keep(a.drop_seed, rowbase + (unsigned)(k0 + (r & 3) + 8 * (r >> 2) + 4 * hf), a.drop_p, inv_keep);
+                for (int q = 0; q < 4; ++q) {                         // registers 4q .. 4q+3: four consecutive keys (any alignment: T is odd)
+                    float keep[4];
+                    dropout_keep4u(a.drop_seed, rowbase + (unsigned)(k0 + 8 * q + 4 * hf), a.drop_p, inv_keep, keep);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) p[4 * q + e] *= keep[e];
+                }
             }
 #pragma unroll
             for (int n = 0; n < ND; ++n)

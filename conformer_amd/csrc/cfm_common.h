@@ -38,17 +38,43 @@ __device__ __forceinline__ float rcp_fast(float x) { return __builtin_amdgcn_rcp
 __device__ __forceinline__ float sigmoidf_acc(float x) { return rcp_fast(1.0f + exp_fast(-x)); }
 __device__ __forceinline__ float swishf_acc(float x) { return x * sigmoidf_acc(x); }
 
-// Dropout keep-factor for element `idx` of a tensor under (seed): a counter-based generator (splitmix64 finaliser of
-// seed + idx*golden), so the backward regenerates exactly the forward's mask from (seed, idx) with no stored mask.
-// Returns 0 (dropped, probability p) or 1/(1-p).  The stream differs from torch's Philox -- parity runs use p = 0,
-// as SURVEY.md Appendix B prescribes.
-__device__ __forceinline__ float dropout_keep(unsigned long long seed, unsigned long long idx, float p, float inv_keep) {
-    unsigned long long z = seed + idx * 0x9E3779B97F4A7C15ull;
+// Dropout keep-factor for element `idx` of a tensor under (seed): a counter-based generator, so the backward regenerates exactly
+// the forward's mask from (seed, idx) with no stored mask.  ONE splitmix64 finaliser serves the FOUR elements of an aligned
+// group (idx >> 2); element idx & 3 takes 16 of its 64 bits: a GEMM epilogue's four consecutive columns cost one hash (the
+// one-hash-per-element form was 3.4 ms of a 52 ms cfg-3 step at the reference's p = 0.1).  Returns 0 (dropped, probability
+// ceil(65536 p) / 65536) or 1/(1-p).  The stream differs from torch's Philox -- parity runs use p = 0.
+__device__ __forceinline__ unsigned long long dropout_hash(unsigned long long seed, unsigned long long group) {
+    unsigned long long z = seed + group * 0x9E3779B97F4A7C15ull;
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
     z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    z ^= z >> 31;
-    const float u = (float)(unsigned)(z >> 40) * (1.0f / 16777216.0f);      // 24 random bits -> [0,1)
-    return u < p ? 0.f : inv_keep;
+    return z ^ (z >> 31);
+}
+__device__ __forceinline__ unsigned dropout_threshold(float p) { return (unsigned)ceilf(p * 65536.0f); }   // drop iff bits < threshold
+__device__ __forceinline__ float dropout_keep(unsigned long long seed, unsigned long long idx, float p, float inv_keep) {
+    const unsigned long long z = dropout_hash(seed, idx >> 2);
+    const unsigned bits = (unsigned)(z >> (16 * (unsigned)(idx & 3))) & 0xffffu;
+    return bits < dropout_threshold(p) ? 0.f : inv_keep;
+}
+// the four elements idx4 .. idx4 + 3 of an ALIGNED group (idx4 % 4 == 0): one hash
+__device__ __forceinline__ void dropout_keep4(unsigned long long seed, unsigned long long idx4, float p, float inv_keep, float (&keep)[4]) {
+    const unsigned long long z = dropout_hash(seed, idx4 >> 2);
+    const unsigned th = dropout_threshold(p), lo = (unsigned)z, hi = (unsigned)(z >> 32);
+    keep[0] = (lo & 0xffffu) < th ? 0.f : inv_keep;
+    keep[1] = (lo >> 16) < th ? 0.f : inv_keep;
+    keep[2] = (hi & 0xffffu) < th ? 0.f : inv_keep;
+    keep[3] = (hi >> 16) < th ? 0.f : inv_keep;
+}
+// four CONSECUTIVE elements a .. a + 3 at any alignment (attention rows: T is odd): the two groups they touch, two hashes
+__device__ __forceinline__ void dropout_keep4u(unsigned long long seed, unsigned long long a, float p, float inv_keep, float (&keep)[4]) {
+    const unsigned long long z0 = dropout_hash(seed, a >> 2), z1 = dropout_hash(seed, (a >> 2) + 1);
+    const unsigned th = dropout_threshold(p), sh = 16 * (unsigned)(a & 3);
+    // 128-bit window z1:z0 shifted right by sh bits (sh in {0,16,32,48})
+    const unsigned long long w = sh == 0 ? z0 : (z0 >> sh) | (z1 << (64 - sh));
+    const unsigned lo = (unsigned)w, hi = (unsigned)(w >> 32);
+    keep[0] = (lo & 0xffffu) < th ? 0.f : inv_keep;
+    keep[1] = (lo >> 16) < th ? 0.f : inv_keep;
+    keep[2] = (hi & 0xffffu) < th ? 0.f : inv_keep;
+    keep[3] = (hi >> 16) < th ? 0.f : inv_keep;
 }
 
 // Bijective XCD-aware remap of a 1-D block id: blocks that share an XCD (id % 8 under the observed

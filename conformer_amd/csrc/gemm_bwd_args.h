@@ -171,9 +171,13 @@ __device__ __forceinline__ void bwd_epilogue_rows_lds(const BwdArgs& g, float* C
                     for (int e = 0; e < 4; ++e) {
                         const float sg = sigmoidf_acc(z4[e]);
                         v[e] *= sg * (1.0f + z4[e] * (1.0f - sg));
-                        if (g.drop_p > 0.f)
-                            v[e] *= dropout_keep(g.drop_seed, (unsigned long long)row * (unsigned long long)g.J + (unsigned)(col + e),
-                                                 g.drop_p, 1.0f / (1.0f - g.drop_p));
+                    }
+                    if (g.drop_p > 0.f) {                                  // (J % 4 == 0, col % 4 == 0: an aligned group, one hash)
+                        float keep[4];
+                        dropout_keep4(g.drop_seed, (unsigned long long)row * (unsigned long long)g.J + (unsigned)col, g.drop_p,
+                                      1.0f / (1.0f - g.drop_p), keep);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] *= keep[e];
                     }
                 }
                 int64_t crow = row;

@@ -138,9 +138,12 @@ __device__ __forceinline__ f32x4 gemm_epilogue_compute(const GemmArgs& g, const 
         for (int e = 0; e < 4; ++e) {
             const float sg = sigmoidf_acc(z4[e]);
             r[e] = g.alpha * av[e] * (sg * (1.0f + z4[e] * (1.0f - sg)));
-            if (g.drop_p > 0.f)
-                r[e] *= dropout_keep(g.drop_seed, (unsigned long long)row * (unsigned long long)g.N + (unsigned)(col + e), g.drop_p,
-                                     1.0f / (1.0f - g.drop_p));
+        }
+        if (g.drop_p > 0.f) {                                          // (vectorised path: N % 4 == 0 and col % 4 == 0 -- an aligned group)
+            float keep[4];
+            dropout_keep4(g.drop_seed, (unsigned long long)row * (unsigned long long)g.N + (unsigned)col, g.drop_p, 1.0f / (1.0f - g.drop_p), keep);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) r[e] *= keep[e];
         }
         zpre = z4;
         return r;
@@ -151,9 +154,11 @@ __device__ __forceinline__ f32x4 gemm_epilogue_compute(const GemmArgs& g, const 
     const bool drop = g.drop_p > 0.f && EPI != EPI_GLU && EPI != EPI_RELU;
     const float inv_keep = drop ? 1.0f / (1.0f - g.drop_p) : 1.0f;
     const unsigned long long e0 = (unsigned long long)row * (unsigned long long)g.N + (unsigned)col;
+    float keep[4] = {1.f, 1.f, 1.f, 1.f};
+    if (drop) dropout_keep4(g.drop_seed, e0, g.drop_p, inv_keep, keep);   // (vectorised path: e0 % 4 == 0 -- one hash for the group)
     if (drop && EPI != EPI_SWISH) {                        // dropout(y) then alpha*y + R  (or plain y)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] *= dropout_keep(g.drop_seed, e0 + e, g.drop_p, inv_keep);
+        for (int e = 0; e < 4; ++e) v[e] *= keep[e];
     }
     if (EPI == EPI_GLU) {
 #pragma unroll
@@ -168,7 +173,7 @@ __device__ __forceinline__ f32x4 gemm_epilogue_compute(const GemmArgs& g, const 
     for (int e = 0; e < 4; ++e) {
         if (EPI == EPI_SWISH) {
             v[e] = swishf_acc(v[e]);
-            if (drop) v[e] *= dropout_keep(g.drop_seed, e0 + e, g.drop_p, inv_keep);
+            if (drop) v[e] *= keep[e];
         }
         if (EPI == EPI_RELU) v[e] = fmaxf(v[e], 0.f);
     }
