@@ -56,6 +56,7 @@ SIGNATURES = {
     "cfm_gemm_train_f32": (c_int, [_I, _P, _P, _P, _P, _F, _P, _P, _L, _I, _I, _L, _L, _L, _F, _U, _P]),
     "cfm_relpos_attention_train_f32": (c_int, [_P, _P, _P, _L, _P, _L, _P, _P, _P, _P, _L, _P, _I, _I, _I, _I, _F, _U, _P]),
     "cfm_dropout_f32": (c_int, [_P, _P, _L, _F, _U, _P]),
+    "cfm_dropout_out16_f32": (c_int, [_I, _P, _P, _L, _F, _U, _P]),
     "cfm_layernorm_bwd_dx_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, _L, _I, _P]),
     "cfm_layernorm_bwd_params_f32": (c_int, [_P, _P, _P, _P, _P, _P, _L, _I, _P]),
     "cfm_layernorm_bwd_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _P, ctypes.c_size_t, _P]),

@@ -124,7 +124,7 @@ class FeedForwardFn(Function):
     def backward(ctx, dout):
         x, ln_w, mean, rstd, h0, z, h, w1, w2 = ctx.saved_tensors
         dout = dout.contiguous()
-        d2 = ops.dropout_apply(dout, ctx.drop_p, ctx.seeds[1])       # gradient w.r.t. the out-projection result
+        d2 = ops.dropout_apply(dout, ctx.drop_p, ctx.seeds[1], for_gemm=True)   # gradient w.r.t. the out-projection result (GEMM operand only)
         # d(pre-activation) = alpha * (d2 . W2) * mask1 * swish'(z); dW2 = alpha * d2^T . h (h already carries mask1)
         # (dz only feeds the two GEMMs below: under autocast it is stored in the 16-bit type they would round it to)
         dz, dw2, db2 = ops.linear_bwd(_flat(h), w2, _flat(d2), alpha=ctx.alpha, Z=_flat(z), drop_p=ctx.drop_p,
@@ -186,7 +186,7 @@ class SelfAttentionFn(Function):
         lengths = lengths if ctx.has_len else None
         dout = dout.contiguous()
         d = x.shape[-1]
-        d2 = ops.dropout_apply(dout, ctx.drop_p, ctx.seeds[1])
+        d2 = ops.dropout_apply(dout, ctx.drop_p, ctx.seeds[1], for_gemm=True)
         datt, dwo, dbo = ops.linear_bwd(_flat(att), wo, _flat(d2))
         dqkv, dpos, du, dvb = ops.relpos_attention_bwd(qkv, pos, u, vb, lengths, ctx.n_heads, att,
                                                        lse, datt.view_as(att), ctx.drop_p, ctx.seeds[0])
@@ -226,7 +226,7 @@ class ConvModuleFn(Function):
     def backward(ctx, dout):
         x, ln_w, mean, rstd, h0, z, g, s, w1, wd, bd, bn_w, bn_b, bn_mean, bn_var, w2 = ctx.saved_tensors
         dout = dout.contiguous()
-        d2 = ops.dropout_apply(dout, ctx.drop_p, ctx.seed)
+        d2 = ops.dropout_apply(dout, ctx.drop_p, ctx.seed, for_gemm=True)
         ds, dw2, db2 = ops.linear_bwd(_flat(s), w2, _flat(d2))
         dg, dwd, dbd, dbnw, dbnb = ops.dwconv_bn_swish_bwd(g, ds.view_as(g), wd, bd, bn_w, bn_b, bn_mean, bn_var,
                                                            ctx.eps_bn, ctx.train_bn)

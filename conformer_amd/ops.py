@@ -621,9 +621,18 @@ def linear_train(epi: str, a, w, b, *, residual=None, alpha: float = 1.0, drop_p
     return (c, z) if save_z else c
 
 
-def dropout_apply(x, drop_p: float, seed: int):
-    """x * mask(seed, flat index) -- the same mask cfm_gemm_train_f32 applied to a contiguous (M,N) result."""
+def dropout_apply(x, drop_p: float, seed: int, for_gemm: bool = False):
+    """x * mask(seed, flat index) -- the same mask cfm_gemm_train_f32 applied to a contiguous (M,N) result.
+    for_gemm: the result only feeds GEMM operands (a masked gradient going into dX / dW products): under a 16-bit precision
+    mode it is written in that type -- what those kernels would round it to anyway; with drop_p = 0 this is the plain cast that
+    lets them run their all-16-bit forms."""
     x = _req(x, "x")
+    prec = mfma16_prec() if for_gemm else 0
+    if prec and x.numel() % 8 == 0 and x.shape[-1] % 8 == 0:
+        y = torch.empty(x.shape, device=x.device, dtype=_DT16[prec])
+        _lib.check(_lib.load().cfm_dropout_out16_f32(prec, x.data_ptr(), y.data_ptr(), x.numel(), float(max(drop_p, 0.0)), int(seed),
+                                                     _stream()), "cfm_dropout_out16_f32")
+        return y
     if drop_p <= 0.0:
         return x
     y = torch.empty_like(x)
@@ -714,25 +723,26 @@ def linear_bwd(x2d, w, dy2d, *, alpha: float = 1.0, Z=None, need_dx: bool = True
     dx = None
     prec = mfma16_prec()
     dy16 = dy2d.dtype != torch.float32
-    if dy16 and not (prec and dy2d.dtype == _DT16[prec] and n % 8 == 0 and k % 8 == 0 and alpha == 1.0 and Z is None):
-        raise _lib.ConformerHipError("a 16-bit dY needs the matching precision mode, N % 8 == 0, K % 8 == 0, alpha = 1, no Z")
+    z_ok = Z is not None and n % 8 == 0 and k % 8 == 0 and Z.stride(0) % 8 == 0      # the swish' product on the forward kernel
+    if dy16 and not (prec and dy2d.dtype == _DT16[prec] and n % 8 == 0 and k % 8 == 0 and (z_ok or (Z is None and alpha == 1.0))):
+        raise _lib.ConformerHipError("a 16-bit dY needs the matching precision mode, N % 8 == 0, K % 8 == 0 and alpha = 1 (or a saved Z)")
     if dy2d.stride(0) & 3:                        # e.g. the vocabulary projection (N = 370): rows must start 16-byte aligned
         padded = torch.zeros(m, (n + 3) // 4 * 4, device=dy2d.device, dtype=dy2d.dtype)
         padded[:, :n] = dy2d
         dy2d = padded[:, :n]
-    if need_dx and dy16:
+    if need_dx and dy16 and Z is None:
         # dX = dY.W with a 16-bit dY: the forward kernel (row-major 16-bit A operand) on the cached transposed 16-bit weight
         wt16 = weight16(w2, prec, transposed=True)
         dx = torch.empty(m, k, device=dy2d.device, dtype=torch.float32)
         _lib.check(_lib.load().cfm_gemm_mfma16_f32(prec, 0, dy2d.data_ptr(), 1, wt16.data_ptr(), 1, _zero_bias(k, dy2d.device).data_ptr(),
                                                    None, 1.0, dx.data_ptr(), 0, None, 0, m, k, n, dy2d.stride(0), k, k, 0.0, 0, _stream()),
                    "cfm_gemm_mfma16_f32")
-    elif need_dx and prec and Z is not None and n % 8 == 0 and k % 8 == 0 and Z.stride(0) % 8 == 0:
+    elif need_dx and prec and z_ok:
         # d(pre-activation) = alpha * (dY.W) * swish'(Z) [* dropout mask]: forward kernel (big tiles, deep prefetch) on the
         # cached transposed 16-bit weight, swish' fused in its row-major epilogue
         wt16 = weight16(w2, prec, transposed=True)
         dx = torch.empty(m, k, device=dy2d.device, dtype=_DT16[prec] if dx16 else torch.float32)
-        _lib.check(_lib.load().cfm_gemm_mfma16_f32(prec, 5, dy2d.data_ptr(), 0, wt16.data_ptr(), 1, None, None, alpha, dx.data_ptr(),
+        _lib.check(_lib.load().cfm_gemm_mfma16_f32(prec, 5, dy2d.data_ptr(), int(dy16), wt16.data_ptr(), 1, None, None, alpha, dx.data_ptr(),
                                                    int(dx16), Z.data_ptr(), int(Z.dtype != torch.float32), m, k, n, dy2d.stride(0),
                                                    Z.stride(0), k, float(drop_p), int(drop_seed), _stream()), "cfm_gemm_mfma16_f32")
     elif need_dx:

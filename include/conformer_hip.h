@@ -259,6 +259,8 @@ int cfm_relpos_attention_train_f32(const float* q, const float* k, const float* 
                                    int B, int T, int H, int dh, float drop_p, uint64_t drop_seed,
                                    cfm_stream_t stream);
 int cfm_dropout_f32(const float* x, float* y, int64_t n, float p, uint64_t seed, cfm_stream_t stream);
+/* ... with y stored in the 16-bit type `prec` (a masked gradient that only feeds GEMM operands); p = 0 is a plain cast.  n % 8 == 0. */
+int cfm_dropout_out16_f32(int prec, const float* x, void* y16, int64_t n, float p, uint64_t seed, cfm_stream_t stream);
 
 /* LayerNorm backward (mean/rstd = the forward's saved row statistics).  dx = LN'(dy) [+ dres];
  * dgamma/dbeta accumulated. */
