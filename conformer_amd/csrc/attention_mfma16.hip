@@ -27,6 +27,7 @@ struct Attn16Args {
     const float* q; const float* k; const float* v; int64_t ld;
     const float* pos; int64_t ldp; const float* u; const float* vb;
     const int64_t* lengths; float* ctx; int64_t ldo; float* lse;
+    int ctx16;                   // ctx is stored in the kernel's 16-bit type (inference: its only consumer is the out-projection GEMM)
     int B, T, H, dh; float inv_sqrt_dh;
     float drop_p; unsigned long long drop_seed;
 };
@@ -278,7 +279,10 @@ __global__ __launch_bounds__(256, 2) void relpos_attn_fwd_mfma16_kernel(const At
                 const int dd = 32 * n + 8 * gq + 4 * hf;
                 if (dd < dh) {
                     f32x4 out = {o[n][4 * gq] * inv, o[n][4 * gq + 1] * inv, o[n][4 * gq + 2] * inv, o[n][4 * gq + 3] * inv};
-                    *reinterpret_cast<f32x4*>(orow + dd) = out;
+                    if (a.ctx16)
+                        *reinterpret_cast<typename Lowp<T16>::x4*>(reinterpret_cast<T16*>(a.ctx) + ((int64_t)b * T + i0 + li) * a.ldo + h * dh + dd) =
+                            Lowp<T16>::cvt4(out);
+                    else *reinterpret_cast<f32x4*>(orow + dd) = out;
                 }
             }
         if (a.lse && hf == 0) a.lse[((int64_t)b * a.H + h) * T + i0 + li] = mrow + logf(lrow);
@@ -288,11 +292,10 @@ __global__ __launch_bounds__(256, 2) void relpos_attn_fwd_mfma16_kernel(const At
 }  // namespace
 
 // 16-bit-MFMA form of cfm_relpos_attention_train_f32 (prec = CFM_PREC_BF16 | CFM_PREC_FP16; lse_or_null; drop_p may be 0).
-extern "C" int cfm_relpos_attention_mfma16_f32(int prec, const float* q, const float* k, const float* v, int64_t ld,
-                                               const float* pos, int64_t ldp, const float* u, const float* vbias,
-                                               const int64_t* lengths_or_null, float* ctx, int64_t ldo, float* lse_or_null,
-                                               int B, int T, int H, int dh, float drop_p, uint64_t drop_seed,
-                                               cfm_stream_t stream) {
+static int attn16_launch(int prec, const float* q, const float* k, const float* v, int64_t ld, const float* pos, int64_t ldp,
+                         const float* u, const float* vbias, const int64_t* lengths_or_null, void* ctxv, int ctx16, int64_t ldo,
+                         float* lse_or_null, int B, int T, int H, int dh, float drop_p, uint64_t drop_seed, cfm_stream_t stream) {
+    float* ctx = static_cast<float*>(ctxv);
     CFM_REQUIRE(q && k && v && pos && u && vbias && ctx, CFM_ERR_NULL);
     CFM_REQUIRE(B > 0 && T > 0 && H > 0 && dh > 0 && (dh & 3) == 0, CFM_ERR_BAD_SHAPE);
     CFM_REQUIRE((ld & 3) == 0 && (ldp & 3) == 0 && (ldo & 3) == 0 && drop_p >= 0.f && drop_p < 1.f, CFM_ERR_BAD_SHAPE);
@@ -300,7 +303,7 @@ extern "C" int cfm_relpos_attention_mfma16_f32(int prec, const float* q, const f
     CFM_REQUIRE(CFM_ALIGNED16(q) && CFM_ALIGNED16(k) && CFM_ALIGNED16(v) && CFM_ALIGNED16(pos) && CFM_ALIGNED16(u) &&
                 CFM_ALIGNED16(vbias) && CFM_ALIGNED16(ctx), CFM_ERR_ALIGN);
     CFM_REQUIRE((int64_t)B * H <= 65535 && T < (1 << 28), CFM_ERR_UNSUPPORTED);
-    const Attn16Args a{q, k, v, ld, pos, ldp, u, vbias, lengths_or_null, ctx, ldo, lse_or_null, B, T, H, dh,
+    const Attn16Args a{q, k, v, ld, pos, ldp, u, vbias, lengths_or_null, ctx, ldo, lse_or_null, ctx16, B, T, H, dh,
                        1.0f / sqrtf((float)dh), drop_p, drop_seed};
     const dim3 grid((unsigned)((T + 127) / 128), (unsigned)(B * H)), block(256);
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -308,4 +311,21 @@ extern "C" int cfm_relpos_attention_mfma16_f32(int prec, const float* q, const f
     else if (prec == CFM_PREC_FP16) hipLaunchKernelGGL(relpos_attn_fwd_mfma16_kernel<_Float16>, grid, block, 0, s, a);
     else return CFM_ERR_UNSUPPORTED;
     return cfm_launch_status();
+}
+
+extern "C" int cfm_relpos_attention_mfma16_f32(int prec, const float* q, const float* k, const float* v, int64_t ld,
+                                               const float* pos, int64_t ldp, const float* u, const float* vbias,
+                                               const int64_t* lengths_or_null, float* ctx, int64_t ldo, float* lse_or_null,
+                                               int B, int T, int H, int dh, float drop_p, uint64_t drop_seed,
+                                               cfm_stream_t stream) {
+    return attn16_launch(prec, q, k, v, ld, pos, ldp, u, vbias, lengths_or_null, ctx, 0, ldo, lse_or_null, B, T, H, dh, drop_p,
+                         drop_seed, stream);
+}
+// ... with the context stored in the 16-bit type `prec` (ldo in elements): inference, where its only consumer is the
+// out-projection GEMM -- which rounds an fp32 context to that type anyway, so the layer's result is bit-identical.
+extern "C" int cfm_relpos_attention_out16_mfma16_f32(int prec, const float* q, const float* k, const float* v, int64_t ld,
+                                                     const float* pos, int64_t ldp, const float* u, const float* vbias,
+                                                     const int64_t* lengths_or_null, void* ctx16, int64_t ldo, int B, int T, int H,
+                                                     int dh, cfm_stream_t stream) {
+    return attn16_launch(prec, q, k, v, ld, pos, ldp, u, vbias, lengths_or_null, ctx16, 1, ldo, nullptr, B, T, H, dh, 0.f, 0, stream);
 }

@@ -52,7 +52,7 @@ class RelativeMultiHeadAttention(nn.Module):
         return w, b
 
     def context(self, x: torch.Tensor, pos_table: torch.Tensor, lengths: Optional[torch.Tensor],
-                pos_projected: Optional[torch.Tensor] = None) -> torch.Tensor:
+                pos_projected: Optional[torch.Tensor] = None, for_gemm: bool = False) -> torch.Tensor:
         """x: (B,T,d) already layer-normed; pos_table: (2T-1,d) un-projected; returns concat-head context.
         `pos_projected` (a (2T-1,d) view, any row stride) is this layer's slice of the encoder-wide batched
         pos_proj GEMM (Encoder._projected_positions); without it the projection runs here."""
@@ -60,11 +60,11 @@ class RelativeMultiHeadAttention(nn.Module):
         qkv = ops.linear(x, w, b)
         pos = pos_projected if pos_projected is not None else \
             ops.linear(pos_table, self.pos_proj.weight, self.pos_proj.bias)
-        return ops.relpos_attention(qkv, pos, self.content_bias, self.position_bias, lengths, self.n_heads)
+        return ops.relpos_attention(qkv, pos, self.content_bias, self.position_bias, lengths, self.n_heads, for_gemm=for_gemm)
 
     def fused(self, x, pos_table, lengths, residual: Optional[torch.Tensor] = None,
               pos_projected: Optional[torch.Tensor] = None) -> torch.Tensor:
-        ctx = self.context(x, pos_table, lengths, pos_projected)
+        ctx = self.context(x, pos_table, lengths, pos_projected, for_gemm=True)      # (the context only feeds out_proj)
         if residual is None:
             return ops.linear(ctx, self.out_proj.weight, self.out_proj.bias)
         return ops.linear_residual(ctx, self.out_proj.weight, self.out_proj.bias, residual, 1.0)

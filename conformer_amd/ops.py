@@ -332,8 +332,10 @@ def relpos_table(div_term: torch.Tensor, t: int) -> torch.Tensor:
 
 
 def relpos_attention(qkv: torch.Tensor, pos: torch.Tensor, u: torch.Tensor, v: torch.Tensor,
-                     lengths: Optional[torch.Tensor], n_heads: int) -> torch.Tensor:
-    """qkv: (B,T,3d) fused projections [q|k|v]; pos: (2T-1,d) projected table; returns ctx (B,T,d)."""
+                     lengths: Optional[torch.Tensor], n_heads: int, for_gemm: bool = False) -> torch.Tensor:
+    """qkv: (B,T,3d) fused projections [q|k|v]; pos: (2T-1,d) projected table; returns ctx (B,T,d).
+    for_gemm: the context only feeds the out-projection GEMM: under autocast it is written in the 16-bit type (that GEMM rounds
+    an fp32 context to it anyway: bit-identical layer output, half the bytes, the GEMM's 16-bit-A staging)."""
     qkv = _req(qkv, "qkv"); u = _req(u, "content_bias"); v = _req(v, "position_bias")
     B, T, d3 = qkv.shape
     d = d3 // 3
@@ -347,6 +349,13 @@ def relpos_attention(qkv: torch.Tensor, pos: torch.Tensor, u: torch.Tensor, v: t
     ctx = torch.empty(B, T, d, device=qkv.device, dtype=qkv.dtype)
     base = qkv.data_ptr()
     prec = mfma16_prec()
+    if prec and for_gemm and d % 8 == 0:
+        ctx = torch.empty(B, T, d, device=qkv.device, dtype=_DT16[prec])
+        st = _lib.load().cfm_relpos_attention_out16_mfma16_f32(prec, base, base + 4 * d, base + 8 * d, d3, pos.data_ptr(), ldp,
+                                                               u.data_ptr(), v.data_ptr(), _p(lengths), ctx.data_ptr(), d,
+                                                               B, T, n_heads, dh, _stream())
+        _lib.check(st, "cfm_relpos_attention_out16_mfma16_f32")
+        return ctx
     if prec:
         st = _lib.load().cfm_relpos_attention_mfma16_f32(prec, base, base + 4 * d, base + 8 * d, d3, pos.data_ptr(), ldp,
                                                          u.data_ptr(), v.data_ptr(), _p(lengths), ctx.data_ptr(), d, None,

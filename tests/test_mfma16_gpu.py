@@ -266,3 +266,27 @@ def test_weight16_refresh_after_fused_adam(dev):
     for t, w in zip(after[3:5], ws[:2]):
         assert torch.equal(t, w.detach().t().to(torch.bfloat16))
     assert torch.equal(after[5], conv.detach().reshape(48, -1).to(torch.bfloat16))
+
+
+@pytest.mark.parametrize("dt16", DT)
+def test_attention_context_in_16bit_gives_the_same_layer_output(dev, dt16):
+    """Inference under autocast: the attention context is written in the 16-bit type (its only consumer, the out-projection GEMM,
+    rounds an fp32 context to that type anyway) -- the module output must EQUAL the one computed from an fp32 context."""
+    from conformer_amd import ops
+    from model.utils.attention import MultiHeadSelfAttentionModule
+    torch.manual_seed(3)
+    B, T, d, H = 3, 49, 144, 4
+    m = MultiHeadSelfAttentionModule(d, H).to(dev).eval()
+    x = torch.randn(B, T, d, device=dev)
+    L = torch.tensor([49, 30, 7], device=dev)
+    table = ops.relpos_table(torch.exp(torch.arange(0, d, 2, device=dev).float() * (-math.log(10000.0) / d)), T)
+    with torch.no_grad(), torch.autocast("cuda", dtype=dt16):
+        a = m.attention
+        got = m.fused(x, table, L, residual=x)
+        xn = ops.layernorm(x, m.layer_norm.weight, m.layer_norm.bias, m.layer_norm.eps, for_gemm=True)
+        ctx32 = a.context(xn, table, L)                           # fp32 context
+        ctx16 = a.context(xn, table, L, for_gemm=True)
+        want = ops.linear_residual(ctx32, a.out_proj.weight, a.out_proj.bias, x, 1.0)
+    assert ctx32.dtype == torch.float32 and ctx16.dtype == dt16
+    assert torch.equal(ctx16, ctx32.to(dt16))
+    assert torch.isfinite(got).all() and torch.equal(got, want)
