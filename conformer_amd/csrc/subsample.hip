@@ -29,31 +29,40 @@ __global__ __launch_bounds__(256) void conv1_relu_kernel(const float* __restrict
     const int t1 = blockIdx.x, b = blockIdx.y;
     const float* xb = x + (int64_t)b * F * T + 2 * t1;
     TOUT* hrow = h1 + ((int64_t)b * T1 + t1) * F1 * C + cg * CPT;
-    for (int f1 = pl; f1 < F1; f1 += ppb) {
-        const float* xp = xb + (int64_t)(2 * f1) * T;
-        float xv[9];
+    constexpr int U = CPT == 4 ? 4 : 2;                  // positions in flight per thread: their 9-tap windows are requested together
+    for (int f0 = pl; f0 < F1; f0 += U * ppb) {
+        float xv[U][9];
 #pragma unroll
-        for (int kf = 0; kf < 3; ++kf)
+        for (int u = 0; u < U; ++u) {                      // (positions beyond F1 re-read the last one and are not stored)
+            const float* xp = xb + (int64_t)(2 * min(f0 + u * ppb, F1 - 1)) * T;
 #pragma unroll
-            for (int kt = 0; kt < 3; ++kt) xv[kf * 3 + kt] = xp[kf * T + kt];
-        float o[CPT];
+            for (int kf = 0; kf < 3; ++kf)
 #pragma unroll
-        for (int i = 0; i < CPT; ++i) {
-            o[i] = bb[i];
-#pragma unroll
-            for (int j = 0; j < 9; ++j) o[i] = fmaf(w[i][j], xv[j], o[i]);
-            o[i] = fmaxf(o[i], 0.f);
+                for (int kt = 0; kt < 3; ++kt) xv[u][kf * 3 + kt] = xp[kf * T + kt];
         }
-        if constexpr (sizeof(TOUT) == 4) {
-            static_assert(sizeof(TOUT) != 4 || CPT == 4, "fp32 h1: 4 channels per thread");
-            *reinterpret_cast<f32x4*>(hrow + (int64_t)f1 * C) = f32x4{o[0], o[1], o[2], o[3]};
-        } else if constexpr (CPT == 8) {
-            typename Lowp<TOUT>::x8 r;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) r[i] = (TOUT)o[i];
-            *reinterpret_cast<typename Lowp<TOUT>::x8*>(hrow + (int64_t)f1 * C) = r;
-        } else {
-            *reinterpret_cast<typename Lowp<TOUT>::x4*>(hrow + (int64_t)f1 * C) = Lowp<TOUT>::cvt4(f32x4{o[0], o[1], o[2], o[3]});
+        for (int u = 0; u < U; ++u) {
+            const int f1 = f0 + u * ppb;
+            if (f1 >= F1) break;
+            float o[CPT];
+#pragma unroll
+            for (int i = 0; i < CPT; ++i) {
+                o[i] = bb[i];
+#pragma unroll
+                for (int j = 0; j < 9; ++j) o[i] = fmaf(w[i][j], xv[u][j], o[i]);
+                o[i] = fmaxf(o[i], 0.f);
+            }
+            if constexpr (sizeof(TOUT) == 4) {
+                static_assert(sizeof(TOUT) != 4 || CPT == 4, "fp32 h1: 4 channels per thread");
+                *reinterpret_cast<f32x4*>(hrow + (int64_t)f1 * C) = f32x4{o[0], o[1], o[2], o[3]};
+            } else if constexpr (CPT == 8) {
+                typename Lowp<TOUT>::x8 r;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) r[i] = (TOUT)o[i];
+                *reinterpret_cast<typename Lowp<TOUT>::x8*>(hrow + (int64_t)f1 * C) = r;
+            } else {
+                *reinterpret_cast<typename Lowp<TOUT>::x4*>(hrow + (int64_t)f1 * C) = Lowp<TOUT>::cvt4(f32x4{o[0], o[1], o[2], o[3]});
+            }
         }
     }
 }
