@@ -28,7 +28,10 @@ template <int BM, int BN, int EPI, bool CONV>
 __global__ __launch_bounds__(256, (BM == 128 && BN == 128) ? 3 : 4) void gemm_f32_kernel(const GemmArgs g) {
     constexpr int TM = BM / 64, TN = BN / 64, BK = 16, LDSR = BK + 4;   // 80-byte rows: conflict-free b128 reads
     static_assert(EPI != EPI_GLU || TN == 2, "GLU keeps value and gate tiles in one wave");
-    __shared__ __attribute__((aligned(16))) float lds[2 * (BM + BN) * LDSR];
+    // staging double buffer; the row-major epilogue re-uses it as 4 per-wave transposition tiles (a little larger for the 64x128 tile)
+    constexpr int LDS_STAGE = 2 * (BM + BN) * LDSR, LDS_EPI = 4 * 32 * (32 * TN + 4);
+    constexpr bool ROWS = LDS_EPI <= LDS_STAGE + 1024;
+    __shared__ __attribute__((aligned(16))) float lds[ROWS && LDS_EPI > LDS_STAGE ? LDS_EPI : LDS_STAGE];
     float* As = lds;                    // [2][BM][LDSR]
     float* Bs = lds + 2 * BM * LDSR;    // [2][BN][LDSR]
 
@@ -130,7 +133,6 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 128) ? 3 : 4) void gemm_f3
 
     // row-major write-out through a per-wave LDS tile (whole 256-byte row segments per store instruction) where the dead
     // staging buffers can hold it; the GLU tile pairs value and gate columns in one wave and stores straight from the accumulators
-    constexpr bool ROWS = EPI != EPI_GLU && 4 * 32 * (32 * TN + 4) <= 2 * (BM + BN) * LDSR;
     if constexpr (ROWS) {
         __syncthreads();                                   // every wave is done reading the staging buffers
         gemm_epilogue_rows<BM, BN, EPI, TM, TN>(g, acc, m0, n0, wr, wc, lane, lds + wave * 32 * (32 * TN + 4));

@@ -246,10 +246,8 @@ __global__ __launch_bounds__(WM * 128, 2) void gemm_mfma16_kernel(const GemmArgs
     } else {
         for (; kt < nkt; ++kt) k_step(kt, st0);
     }
-    if constexpr (EPI == EPI_GLU) {
-        static_assert(WM == 2, "GLU tiles: 2x2 waves");
-        gemm_epilogue<BM, BN, EPI, TM, TN>(g, acc, m0, n0, wr, wc, li, hf);
-    } else {                                                 // (the K-loop ended on a __syncthreads: the staging buffers are free)
+    static_assert(EPI != EPI_GLU || WM == 2, "GLU tiles: 2x2 waves");
+    {                                                        // (the K-loop ended on a __syncthreads: the staging buffers are free)
         static_assert(2 * WM * 32 * (32 * TN + 4) * 4 <= 2 * (BM + BN) * ROWB * 2, "row-major epilogue scratch must fit the staging LDS");
         gemm_epilogue_rows<BM, BN, EPI, TM, TN, WM, CONV == 2>(g, acc, m0, n0, wr, wc, lane, reinterpret_cast<float*>(lds) + wave * 32 * (32 * TN + 4));
     }

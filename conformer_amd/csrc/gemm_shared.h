@@ -335,8 +335,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const f32x16 (&
 template <int BM, int BN, int EPI, int TM, int TN, int WM = 2, bool CLS = false>
 __device__ __forceinline__ void gemm_epilogue_rows(const GemmArgs& g, const f32x16 (&acc)[TM][TN], int64_t m0, int n0,
                                                    int wr, int wc, int lane, float* scratch) {
-    static_assert(EPI != EPI_GLU, "GLU pairs value and gate tiles: use gemm_epilogue");
-    constexpr int P = 32 * TN + 4, LPR = 8 * TN, RPI = 64 / LPR;      // row pitch, lanes per row, rows per wave-instruction
+    static_assert(EPI != EPI_GLU || TN == 2, "GLU: n-tile 0 = values, n-tile 1 = gates of the same 32 output columns");
+    // row pitch, lanes per row, rows per wave-instruction (GLU: a row of the LDS tile is 32 values | 32 gates -> 32 output columns)
+    constexpr int P = 32 * TN + 4, LPR = EPI == EPI_GLU ? 8 : 8 * TN, RPI = 64 / LPR;
     const int li = lane & 31, hf = lane >> 5;
     if constexpr (WM == 2) {                                          // (8-wave tiles: the launcher guarantees vec_ok)
         if (!gemm_epilogue_vec_ok(g, EPI)) {                          // (kernel-uniform)
@@ -370,7 +371,7 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmArgs& g, const f32x
     };
 
     // ---- 16-bit C: 8 columns per lane, one 16-byte store per lane and output tensor (see gemm_epilogue_apply8)
-    if constexpr (EPI != EPI_RESID) {
+    if constexpr (EPI != EPI_RESID && EPI != EPI_GLU) {
         const bool wide = g.c_prec != 0 && ((g.N | (int)g.ldc) & 7) == 0 && (reinterpret_cast<uintptr_t>(g.C) & 15) == 0 &&
                           (EPI != EPI_SWISH || !g.Zsave || (reinterpret_cast<uintptr_t>(g.Zsave) & 15) == 0) &&
                           (EPI != EPI_DSWISH || (g.z_prec != 0 && (g.ldr & 7) == 0 && (reinterpret_cast<uintptr_t>(g.Zsave) & 15) == 0));
@@ -426,7 +427,7 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmArgs& g, const f32x
 
     // ---- 4 columns per lane
     const int rsub = lane / LPR, c4 = (lane % LPR) * 4;
-    const int col = n0 + wc * (BN / 2) + c4;
+    const int col = n0 + (EPI == EPI_GLU ? wc * 32 : wc * (BN / 2)) + c4;
     constexpr int NIT = 32 / RPI;
     auto row_of = [&](int mt, int it) { return m0 + wr * (BM / WM) + mt * 32 + it * RPI + rsub; };
     // Every load is issued ahead of the stores it would otherwise queue behind (see EpiOps): the bias once (a lane's columns
@@ -441,8 +442,9 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmArgs& g, const f32x
             for (int it = 0; it < NIT; ++it) {                         // (a real loop: the unrolled form was 12 000 instructions)
                 const int rl = it * RPI + rsub;
                 const f32x4 v = *reinterpret_cast<const f32x4*>(scratch + rl * P + c4);
+                const f32x4 gate = EPI == EPI_GLU ? *reinterpret_cast<const f32x4*>(scratch + rl * P + 32 + c4) : v;
                 const int64_t row = row_of(mt, it);
-                gemm_epilogue_apply<EPI>(g, v, v, ob, row, col, CLS ? class_row(row) : row);
+                gemm_epilogue_apply<EPI>(g, v, gate, ob, row, col, CLS ? class_row(row) : row);
             }
             slab_done();
         }
