@@ -28,11 +28,14 @@ struct Attn16Args {
     const float* pos; int64_t ldp; const float* u; const float* vb;
     const int64_t* lengths; float* ctx; int64_t ldo; float* lse;
     int ctx16;                   // ctx is stored in the kernel's 16-bit type (inference: its only consumer is the out-projection GEMM)
+    int qkv16;                   // q / k / v are stored in that type (ld in elements): what torch.autocast hands the attention core
     int B, T, H, dh; float inv_sqrt_dh;
     float drop_p; unsigned long long drop_seed;
 };
 
-template <typename T16>
+// QKV16: q / k / v are stored in T16 (compile-time: a run-time test around the loads costs their overlap -- the compiler waits
+// for every conditional load at once)
+template <typename T16, bool QKV16>
 __global__ __launch_bounds__(256, 2) void relpos_attn_fwd_mfma16_kernel(const Attn16Args a) {
     using x8 = typename Lowp<T16>::x8;
     using x4 = typename Lowp<T16>::x4;
@@ -60,8 +63,14 @@ __global__ __launch_bounds__(256, 2) void relpos_attn_fwd_mfma16_kernel(const At
     }
     const int ntiles = (klen + 31) / 32;
 
-    const float* kbase = a.k + (int64_t)b * T * a.ld + h * dh;
-    const float* vbase = a.v + (int64_t)b * T * a.ld + h * dh;
+    const int64_t qkv_off = (int64_t)b * T * a.ld + h * dh;          // element offset of this (utterance, head) in q / k / v
+    auto load4 = [&](const float* base, int64_t off) -> f32x4 {      // four consecutive q / k / v values at element offset `off`
+        if constexpr (QKV16) {
+            const x4 t = *reinterpret_cast<const x4*>(reinterpret_cast<const T16*>(base) + off);
+            return f32x4{(float)t[0], (float)t[1], (float)t[2], (float)t[3]};
+        }
+        else return *reinterpret_cast<const f32x4*>(base + off);
+    };
     const float* pbase = a.pos + h * dh;
     const int jmax = 2 * T - 2;
     const int ring_bias = RINGH * ((T + 128 + q0) / RINGH + 2);
@@ -70,6 +79,7 @@ __global__ __launch_bounds__(256, 2) void relpos_attn_fwd_mfma16_kernel(const At
     const int srow = tid >> 4, sch = tid & 15;
     const bool sok = sch * 4 < dh;
     f32x4 pk[2], pv[2], pp[2];
+    x4 pk16[2], pv16[2];                                           // (QKV16: the staged K / V chunks, raw)
     auto prefetch = [&](int kt) {
         const int k0 = kt * 32;
         const int jnew = T - 1 - q0 + k0;
@@ -79,8 +89,17 @@ __global__ __launch_bounds__(256, 2) void relpos_attn_fwd_mfma16_kernel(const At
             const int key = min(k0 + r, T - 1);
             const int j = max(0, min(jnew + r, jmax));
             const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-            pk[p] = sok ? *reinterpret_cast<const f32x4*>(kbase + (int64_t)key * a.ld + sch * 4) : z;
-            pv[p] = sok ? *reinterpret_cast<const f32x4*>(vbase + (int64_t)key * a.ld + sch * 4) : z;
+            if constexpr (QKV16) {                                 // raw 16-bit values: nothing may touch them before commit(),
+                x4 z16;                                              // or the prefetch stops overlapping the tile's products
+#pragma unroll
+                for (int e = 0; e < 4; ++e) z16[e] = (T16)0.f;
+                const int64_t off = qkv_off + (int64_t)key * a.ld + sch * 4;
+                pk16[p] = sok ? *reinterpret_cast<const x4*>(reinterpret_cast<const T16*>(a.k) + off) : z16;
+                pv16[p] = sok ? *reinterpret_cast<const x4*>(reinterpret_cast<const T16*>(a.v) + off) : z16;
+            } else {
+                pk[p] = sok ? load4(a.k, qkv_off + (int64_t)key * a.ld + sch * 4) : z;
+                pv[p] = sok ? load4(a.v, qkv_off + (int64_t)key * a.ld + sch * 4) : z;
+            }
             pp[p] = sok ? *reinterpret_cast<const f32x4*>(pbase + (int64_t)j * a.ldp + sch * 4) : z;
         }
     };
@@ -92,8 +111,8 @@ __global__ __launch_bounds__(256, 2) void relpos_attn_fwd_mfma16_kernel(const At
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
             const int r = srow + 16 * p;
-            *reinterpret_cast<x4*>(Ks + r * KROWH + sch * 4) = Lowp<T16>::cvt4(pk[p]);
-            *reinterpret_cast<x4*>(Vt + r * VROWH + sch * 4) = Lowp<T16>::cvt4(pv[p]);
+            *reinterpret_cast<x4*>(Ks + r * KROWH + sch * 4) = QKV16 ? pk16[p] : Lowp<T16>::cvt4(pk[p]);
+            *reinterpret_cast<x4*>(Vt + r * VROWH + sch * 4) = QKV16 ? pv16[p] : Lowp<T16>::cvt4(pv[p]);
             const int slot = (jnew + r + ring_bias) % RINGH;
             *reinterpret_cast<x4*>(Pr + slot * KROWH + sch * 4) = Lowp<T16>::cvt4(pp[p]);
         }
@@ -120,7 +139,7 @@ __global__ __launch_bounds__(256, 2) void relpos_attn_fwd_mfma16_kernel(const At
     x8 qu[4], qv[4];
     {
         const int qi = min(i0 + li, T - 1);
-        const float* qrow = a.q + ((int64_t)b * T + qi) * a.ld + h * dh;
+        const int64_t qoff = ((int64_t)b * T + qi) * a.ld + h * dh;
 #pragma unroll
         for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -128,7 +147,7 @@ __global__ __launch_bounds__(256, 2) void relpos_attn_fwd_mfma16_kernel(const At
                 const int dd = 16 * s + 8 * hf + 4 * half;
                 f32x4 x = {0.f, 0.f, 0.f, 0.f}, uu = x, vv = x;
                 if (dd < dh) {
-                    x = *reinterpret_cast<const f32x4*>(qrow + dd);
+                    x = load4(a.q, qoff + dd);
                     uu = *reinterpret_cast<const f32x4*>(a.u + h * dh + dd);
                     vv = *reinterpret_cast<const f32x4*>(a.vb + h * dh + dd);
                 }
@@ -294,7 +313,8 @@ __global__ __launch_bounds__(256, 2) void relpos_attn_fwd_mfma16_kernel(const At
 // 16-bit-MFMA form of cfm_relpos_attention_train_f32 (prec = CFM_PREC_BF16 | CFM_PREC_FP16; lse_or_null; drop_p may be 0).
 static int attn16_launch(int prec, const float* q, const float* k, const float* v, int64_t ld, const float* pos, int64_t ldp,
                          const float* u, const float* vbias, const int64_t* lengths_or_null, void* ctxv, int ctx16, int64_t ldo,
-                         float* lse_or_null, int B, int T, int H, int dh, float drop_p, uint64_t drop_seed, cfm_stream_t stream) {
+                         float* lse_or_null, int B, int T, int H, int dh, float drop_p, uint64_t drop_seed, cfm_stream_t stream,
+                         int qkv16 = 0) {
     float* ctx = static_cast<float*>(ctxv);
     CFM_REQUIRE(q && k && v && pos && u && vbias && ctx, CFM_ERR_NULL);
     CFM_REQUIRE(B > 0 && T > 0 && H > 0 && dh > 0 && (dh & 3) == 0, CFM_ERR_BAD_SHAPE);
@@ -303,13 +323,17 @@ static int attn16_launch(int prec, const float* q, const float* k, const float* 
     CFM_REQUIRE(CFM_ALIGNED16(q) && CFM_ALIGNED16(k) && CFM_ALIGNED16(v) && CFM_ALIGNED16(pos) && CFM_ALIGNED16(u) &&
                 CFM_ALIGNED16(vbias) && CFM_ALIGNED16(ctx), CFM_ERR_ALIGN);
     CFM_REQUIRE((int64_t)B * H <= 65535 && T < (1 << 28), CFM_ERR_UNSUPPORTED);
-    const Attn16Args a{q, k, v, ld, pos, ldp, u, vbias, lengths_or_null, ctx, ldo, lse_or_null, ctx16, B, T, H, dh,
+    const Attn16Args a{q, k, v, ld, pos, ldp, u, vbias, lengths_or_null, ctx, ldo, lse_or_null, ctx16, qkv16, B, T, H, dh,
                        1.0f / sqrtf((float)dh), drop_p, drop_seed};
     const dim3 grid((unsigned)((T + 127) / 128), (unsigned)(B * H)), block(256);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (prec == CFM_PREC_BF16) hipLaunchKernelGGL(relpos_attn_fwd_mfma16_kernel<__bf16>, grid, block, 0, s, a);
-    else if (prec == CFM_PREC_FP16) hipLaunchKernelGGL(relpos_attn_fwd_mfma16_kernel<_Float16>, grid, block, 0, s, a);
-    else return CFM_ERR_UNSUPPORTED;
+    if (prec == CFM_PREC_BF16) {
+        if (qkv16) hipLaunchKernelGGL((relpos_attn_fwd_mfma16_kernel<__bf16, true>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((relpos_attn_fwd_mfma16_kernel<__bf16, false>), grid, block, 0, s, a);
+    } else if (prec == CFM_PREC_FP16) {
+        if (qkv16) hipLaunchKernelGGL((relpos_attn_fwd_mfma16_kernel<_Float16, true>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((relpos_attn_fwd_mfma16_kernel<_Float16, false>), grid, block, 0, s, a);
+    } else return CFM_ERR_UNSUPPORTED;
     return cfm_launch_status();
 }
 
@@ -321,11 +345,15 @@ extern "C" int cfm_relpos_attention_mfma16_f32(int prec, const float* q, const f
     return attn16_launch(prec, q, k, v, ld, pos, ldp, u, vbias, lengths_or_null, ctx, 0, ldo, lse_or_null, B, T, H, dh, drop_p,
                          drop_seed, stream);
 }
-// ... with the context stored in the 16-bit type `prec` (ldo in elements): inference, where its only consumer is the
-// out-projection GEMM -- which rounds an fp32 context to that type anyway, so the layer's result is bit-identical.
-extern "C" int cfm_relpos_attention_out16_mfma16_f32(int prec, const float* q, const float* k, const float* v, int64_t ld,
-                                                     const float* pos, int64_t ldp, const float* u, const float* vbias,
-                                                     const int64_t* lengths_or_null, void* ctx16, int64_t ldo, int B, int T, int H,
-                                                     int dh, cfm_stream_t stream) {
-    return attn16_launch(prec, q, k, v, ld, pos, ldp, u, vbias, lengths_or_null, ctx16, 1, ldo, nullptr, B, T, H, dh, 0.f, 0, stream);
+// Inference under autocast with 16-bit tensors either side of the core: qkv_is_16bit -- q / k / v stored in `prec` (ld in elements;
+// what torch.autocast's projections hand the attention: the reference rounds them there too); ctx_is_16bit -- the context stored in
+// `prec` (ldo in elements): its only consumer is the out-projection GEMM, which rounds an fp32 context to that type anyway.
+extern "C" int cfm_relpos_attention_io16_mfma16_f32(int prec, const void* q, const void* k, const void* v, int qkv_is_16bit, int64_t ld,
+                                                    const float* pos, int64_t ldp, const float* u, const float* vbias,
+                                                    const int64_t* lengths_or_null, void* ctx, int ctx_is_16bit, int64_t ldo, int B,
+                                                    int T, int H, int dh, cfm_stream_t stream) {
+    CFM_REQUIRE(!qkv_is_16bit || (ld & 7) == 0, CFM_ERR_BAD_SHAPE);
+    return attn16_launch(prec, static_cast<const float*>(q), static_cast<const float*>(k), static_cast<const float*>(v), ld, pos, ldp, u,
+                         vbias, lengths_or_null, ctx, ctx_is_16bit ? 1 : 0, ldo, nullptr, B, T, H, dh, 0.f, 0, stream,
+                         qkv_is_16bit ? 1 : 0);
 }

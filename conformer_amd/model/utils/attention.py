@@ -57,7 +57,9 @@ class RelativeMultiHeadAttention(nn.Module):
         `pos_projected` (a (2T-1,d) view, any row stride) is this layer's slice of the encoder-wide batched
         pos_proj GEMM (Encoder._projected_positions); without it the projection runs here."""
         w, b = self._qkv_params()
-        qkv = ops.linear(x, w, b)
+        # inference under autocast: the projections are written in the 16-bit type (what torch.autocast's nn.Linear returns; the
+        # attention core rounds its operands to that type anyway -- q after the bias add, as the reference does)
+        qkv = ops.linear(x, w, b, for_gemm=for_gemm)
         pos = pos_projected if pos_projected is not None else \
             ops.linear(pos_table, self.pos_proj.weight, self.pos_proj.bias)
         return ops.relpos_attention(qkv, pos, self.content_bias, self.position_bias, lengths, self.n_heads, for_gemm=for_gemm)

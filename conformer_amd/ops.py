@@ -336,7 +336,14 @@ def relpos_attention(qkv: torch.Tensor, pos: torch.Tensor, u: torch.Tensor, v: t
     """qkv: (B,T,3d) fused projections [q|k|v]; pos: (2T-1,d) projected table; returns ctx (B,T,d).
     for_gemm: the context only feeds the out-projection GEMM: under autocast it is written in the 16-bit type (that GEMM rounds
     an fp32 context to it anyway: bit-identical layer output, half the bytes, the GEMM's 16-bit-A staging)."""
-    qkv = _req(qkv, "qkv"); u = _req(u, "content_bias"); v = _req(v, "position_bias")
+    u = _req(u, "content_bias"); v = _req(v, "position_bias")
+    prec = mfma16_prec()
+    q16 = bool(prec) and isinstance(qkv, torch.Tensor) and qkv.dtype == _DT16[prec]      # autocast inference: 16-bit projections
+    if q16:
+        if not (qkv.is_cuda and qkv.is_contiguous() and qkv.shape[-1] % 24 == 0):
+            raise _lib.ConformerHipError("16-bit qkv: expected a contiguous HIP tensor with d % 8 == 0")
+    else:
+        qkv = _req(qkv, "qkv")
     B, T, d3 = qkv.shape
     d = d3 // 3
     dh = d // n_heads
@@ -346,16 +353,17 @@ def relpos_attention(qkv: torch.Tensor, pos: torch.Tensor, u: torch.Tensor, v: t
     ldp = pos.stride(0)
     if lengths is not None:
         lengths = _req(lengths, "lengths", torch.int64)
-    ctx = torch.empty(B, T, d, device=qkv.device, dtype=qkv.dtype)
     base = qkv.data_ptr()
-    prec = mfma16_prec()
-    if prec and for_gemm and d % 8 == 0:
-        ctx = torch.empty(B, T, d, device=qkv.device, dtype=_DT16[prec])
-        st = _lib.load().cfm_relpos_attention_out16_mfma16_f32(prec, base, base + 4 * d, base + 8 * d, d3, pos.data_ptr(), ldp,
-                                                               u.data_ptr(), v.data_ptr(), _p(lengths), ctx.data_ptr(), d,
-                                                               B, T, n_heads, dh, _stream())
-        _lib.check(st, "cfm_relpos_attention_out16_mfma16_f32")
+    c16 = bool(prec and for_gemm and d % 8 == 0)
+    if q16 or c16:
+        esz = 2 if q16 else 4
+        ctx = torch.empty(B, T, d, device=qkv.device, dtype=_DT16[prec] if c16 else torch.float32)
+        st = _lib.load().cfm_relpos_attention_io16_mfma16_f32(prec, base, base + esz * d, base + 2 * esz * d, int(q16), d3,
+                                                              pos.data_ptr(), ldp, u.data_ptr(), v.data_ptr(), _p(lengths),
+                                                              ctx.data_ptr(), int(c16), d, B, T, n_heads, dh, _stream())
+        _lib.check(st, "cfm_relpos_attention_io16_mfma16_f32")
         return ctx
+    ctx = torch.empty(B, T, d, device=qkv.device, dtype=qkv.dtype)
     if prec:
         st = _lib.load().cfm_relpos_attention_mfma16_f32(prec, base, base + 4 * d, base + 8 * d, d3, pos.data_ptr(), ldp,
                                                          u.data_ptr(), v.data_ptr(), _p(lengths), ctx.data_ptr(), d, None,
@@ -810,7 +818,14 @@ def dwconv_bn_swish_bwd(g, dy, w, b, bn_w, bn_b, bn_mean, bn_var, eps: float = 1
 
 def relpos_attention_train(qkv, pos, u, v, lengths, n_heads, drop_p: float = 0.0, seed: int = 0):
     """Forward that also returns the per-row log-sum-exp (B,H,T) for the backward; optional weight dropout."""
-    qkv = _req(qkv, "qkv"); u = _req(u, "content_bias"); v = _req(v, "position_bias")
+    u = _req(u, "content_bias"); v = _req(v, "position_bias")
+    prec = mfma16_prec()
+    q16 = bool(prec) and isinstance(qkv, torch.Tensor) and qkv.dtype == _DT16[prec]      # autocast inference: 16-bit projections
+    if q16:
+        if not (qkv.is_cuda and qkv.is_contiguous() and qkv.shape[-1] % 24 == 0):
+            raise _lib.ConformerHipError("16-bit qkv: expected a contiguous HIP tensor with d % 8 == 0")
+    else:
+        qkv = _req(qkv, "qkv")
     B, T, d3 = qkv.shape
     d = d3 // 3
     dh = d // n_heads

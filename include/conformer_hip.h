@@ -153,12 +153,13 @@ int cfm_relpos_attention_mfma16_f32(int prec, const float* q, const float* k, co
                                     const float* pos, int64_t ldp, const float* u, const float* vbias,
                                     const int64_t* lengths_or_null, float* ctx, int64_t ldo, float* lse_or_null, int B,
                                     int T, int H, int dh, float drop_p, uint64_t drop_seed, cfm_stream_t stream);
-/* ... with the context stored in the 16-bit type `prec` (ldo in elements): inference, where its only consumer is the out-projection
- * GEMM, which rounds an fp32 context to that type anyway -- the layer's result is bit-identical. */
-int cfm_relpos_attention_out16_mfma16_f32(int prec, const float* q, const float* k, const float* v, int64_t ld,
-                                          const float* pos, int64_t ldp, const float* u, const float* vbias,
-                                          const int64_t* lengths_or_null, void* ctx16, int64_t ldo, int B, int T, int H, int dh,
-                                          cfm_stream_t stream);
+/* Inference under autocast with 16-bit tensors either side of the core: qkv_is_16bit -- q / k / v stored in `prec` (ld in elements,
+ * ld % 8 == 0: what autocast's projections hand the attention); ctx_is_16bit -- the context stored in `prec` (ldo in elements): its
+ * only consumer is the out-projection GEMM, which rounds an fp32 context to that type anyway (bit-identical layer output). */
+int cfm_relpos_attention_io16_mfma16_f32(int prec, const void* q, const void* k, const void* v, int qkv_is_16bit, int64_t ld,
+                                         const float* pos, int64_t ldp, const float* u, const float* vbias,
+                                         const int64_t* lengths_or_null, void* ctx, int ctx_is_16bit, int64_t ldo, int B, int T,
+                                         int H, int dh, cfm_stream_t stream);
 int cfm_subsample_conv2_relu_mfma16_f32(int prec, const void* h1, int h1_is_16bit, const void* w2p, int w_is_16bit,
                                         const float* b2, void* h2, int h2_is_16bit, int B, int F1, int T1, int C,
                                         cfm_stream_t stream);

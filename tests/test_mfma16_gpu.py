@@ -269,9 +269,11 @@ def test_weight16_refresh_after_fused_adam(dev):
 
 
 @pytest.mark.parametrize("dt16", DT)
-def test_attention_context_in_16bit_gives_the_same_layer_output(dev, dt16):
-    """Inference under autocast: the attention context is written in the 16-bit type (its only consumer, the out-projection GEMM,
-    rounds an fp32 context to that type anyway) -- the module output must EQUAL the one computed from an fp32 context."""
+def test_attention_16bit_projections_and_context_in_inference(dev, dt16):
+    """Inference under autocast: the fused q|k|v projection is written in the 16-bit type (what autocast's nn.Linear returns) and
+    so is the attention context.  (a) A 16-bit context changes nothing: its only consumer, the out-projection GEMM, rounds an
+    fp32 context to that type anyway -- EQUAL outputs.  (b) 16-bit projections: k and v are rounded exactly as the kernel's staging
+    rounds them, q is rounded before the bias add as well as after (the reference's arithmetic) -- within 16-bit distance."""
     from conformer_amd import ops
     from model.utils.attention import MultiHeadSelfAttentionModule
     torch.manual_seed(3)
@@ -284,9 +286,15 @@ def test_attention_context_in_16bit_gives_the_same_layer_output(dev, dt16):
         a = m.attention
         got = m.fused(x, table, L, residual=x)
         xn = ops.layernorm(x, m.layer_norm.weight, m.layer_norm.bias, m.layer_norm.eps, for_gemm=True)
-        ctx32 = a.context(xn, table, L)                           # fp32 context
-        ctx16 = a.context(xn, table, L, for_gemm=True)
-        want = ops.linear_residual(ctx32, a.out_proj.weight, a.out_proj.bias, x, 1.0)
-    assert ctx32.dtype == torch.float32 and ctx16.dtype == dt16
-    assert torch.equal(ctx16, ctx32.to(dt16))
+        w, b = a._qkv_params()
+        pos = ops.linear(table, a.pos_proj.weight, a.pos_proj.bias)
+        qkv32, qkv16 = ops.linear(xn, w, b), ops.linear(xn, w, b, for_gemm=True)
+        assert qkv16.dtype == dt16 and torch.equal(qkv16, qkv32.to(dt16))
+        c_a = ops.relpos_attention(qkv16, pos, a.content_bias, a.position_bias, L, H)                  # fp32 context
+        c_b = ops.relpos_attention(qkv16, pos, a.content_bias, a.position_bias, L, H, for_gemm=True)   # 16-bit context
+        c_0 = ops.relpos_attention(qkv32, pos, a.content_bias, a.position_bias, L, H)                  # fp32 projections
+        want = ops.linear_residual(c_a, a.out_proj.weight, a.out_proj.bias, x, 1.0)
+    assert c_a.dtype == torch.float32 and c_b.dtype == dt16
+    assert torch.equal(c_b, c_a.to(dt16))
     assert torch.isfinite(got).all() and torch.equal(got, want)
+    assert rel_l2(c_a, c_0) < (6e-3 if dt16 == torch.bfloat16 else 1e-3)
