@@ -14,10 +14,16 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CONFORMER_AMD_LIB") or os.path.join(_HERE, "lib", "libconformer_hip.so")
 
 _P, _I, _L, _F, _U = c_void_p, c_int, c_int64, c_float, c_uint64
+ABI_VERSION = 3        # CFM_ABI_VERSION of include/conformer_hip.h (checked in load())
 
 # name -> (restype, argtypes).  Mirrors include/conformer_hip.h one to one (checked by tests/test_abi.py).
 SIGNATURES = {
     "cfm_version": (c_int, []),
+    "cfm_abi_version": (c_int, []),
+    "cfm_gemm_bias_stats_f32": (c_int, [_P, _P, _P, _P, _P, _L, _I, _I, _L, _L, _P]),
+    "cfm_gemm_bias_residual_stats_f32": (c_int, [_P, _P, _P, _P, _F, _P, _P, _L, _I, _I, _L, _L, _L, _P]),
+    "cfm_gemm_lnfold_f32": (c_int, [_I, _P, _P, _I, _F, _P, _P, _P, _P, _L, _I, _I, _L, _L, _P]),
+    "cfm_layernorm_fwd_stats_f32": (c_int, [_P, _P, _P, _P, _P, _L, _I, _F, _P]),
     "cfm_strerror": (c_char_p, [_I]),
     "cfm_device_check": (c_int, []),
     "cfm_subsampled_length": (c_int64, [_L]),
@@ -135,6 +141,16 @@ def load() -> ctypes.CDLL:
             "(there is no CPU/eager fallback for the Conformer hot path)")
     import torch  # noqa: F401  (loads libamdhip64 from torch/lib before our DT_NEEDED is resolved)
     lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+    # a library built against another revision of include/conformer_hip.h would take shifted arguments silently (ctypes checks
+    # nothing): refuse it before the first call (matters most for the CONFORMER_AMD_LIB override)
+    try:
+        lib.cfm_abi_version.restype = c_int
+        got = int(lib.cfm_abi_version())
+    except AttributeError:
+        got = 0
+    if got != ABI_VERSION:
+        raise ConformerHipError(f"{LIB_PATH} implements C-ABI revision {got}, this binding needs {ABI_VERSION}: rebuild it with "
+                                "`python -m conformer_amd.build`")
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)
         fn.restype = res

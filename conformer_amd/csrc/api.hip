@@ -3,6 +3,7 @@
 #include <string.h>
 
 extern "C" int cfm_version(void) { return 1; }
+extern "C" int cfm_abi_version(void) { return CFM_ABI_VERSION; }
 
 extern "C" const char* cfm_strerror(int s) {
     switch (s) {

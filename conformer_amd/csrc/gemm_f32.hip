@@ -24,14 +24,22 @@ namespace {
         acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(FB[nt][e], FA[mt][e], acc[mt][nt], 0, 0, 0)
 
 // ---- the kernel: register staging, K-tile 16 (any K % 4 == 0) ---------------------------------------------------
-template <int BM, int BN, int EPI, bool CONV>
+// LN fold (inference; the four LayerNorms in front of a block's Linear layers leave the launch list):
+//   LN == 2, producer: the epilogue also writes, per 32 stored columns of every C row, (sum, M2 about their own mean);
+//   LN == 1, consumer: A is the UN-normalised row, W / bias are the folded W.diag(gamma) / b + W.beta; a prologue merges the
+//            partials of the tile's rows into (mean, rstd) in LDS (Chan's formula, fixed order) while the first K-tiles are
+//            in flight and the epilogue applies rstd * (acc - mean * colsum).  The K-loop is untouched.
+template <int BM, int BN, int EPI, bool CONV, int LN = 0>
 __global__ __launch_bounds__(256, (BM == 128 && BN == 128) ? 3 : 4) void gemm_f32_kernel(const GemmArgs g) {
     constexpr int TM = BM / 64, TN = BN / 64, BK = 16, LDSR = BK + 4;   // 80-byte rows: conflict-free b128 reads
     static_assert(EPI != EPI_GLU || TN == 2, "GLU keeps value and gate tiles in one wave");
     // staging double buffer; the row-major epilogue re-uses it as 4 per-wave transposition tiles (a little larger for the 64x128 tile)
     constexpr int LDS_STAGE = 2 * (BM + BN) * LDSR, LDS_EPI = 4 * 32 * (32 * TN + 4);
     constexpr bool ROWS = LDS_EPI <= LDS_STAGE + 1024;
-    __shared__ __attribute__((aligned(16))) float lds[ROWS && LDS_EPI > LDS_STAGE ? LDS_EPI : LDS_STAGE];
+    constexpr int LDS_MAIN = ROWS && LDS_EPI > LDS_STAGE ? LDS_EPI : LDS_STAGE;
+    static_assert(LN == 0 || ROWS, "the LN fold lives in the row-major epilogue");
+    __shared__ __attribute__((aligned(16))) float lds[LDS_MAIN + (LN == 1 ? 2 * BM : 0)];
+    float* rowstats = lds + LDS_MAIN;   // LN == 1: [BM][2] = (mean, rstd) of the tile's A rows
     float* As = lds;                    // [2][BM][LDSR]
     float* Bs = lds + 2 * BM * LDSR;    // [2][BN][LDSR]
 
@@ -100,10 +108,40 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 128) ? 3 : 4) void gemm_f3
             fb[t] = *reinterpret_cast<const f32x4*>(Bs + (buf * BN + b_row + 32 * t) * LDSR + 8 * c + 4 * hf);
     };
 
+    // LN == 1: the statistics partials of this tile's rows are requested FIRST (their wait then leaves the K-tile loads in
+    // flight); thread r < BM owns row m0 + r; at most 16 partials per row (d <= 512 at 32 columns per partial)
+    [[maybe_unused]] float2 lnp[LN == 1 ? 16 : 1];
+    if constexpr (LN == 1) {
+        // (every thread loads -- threads >= BM repeat a row: a load inside a divergent block would make the compiler's wait
+        // bookkeeping drain the K-tile prefetch at the join)
+        const float2* sp = reinterpret_cast<const float2*>(g.ln_stats) + min(m0 + (tid & (BM - 1)), g.M - 1) * g.ln_parts;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) lnp[i] = sp[i < g.ln_parts ? i : 0];
+    }
     load_tile(ra0, rb0, 0);
     store_tile(ra0, rb0, 0);
     if (nkt > 1) load_tile(ra1, rb1, 1);
     if (nkt > 2) load_tile(ra0, rb0, 2);
+    if constexpr (LN == 1) {
+        {
+            // Chan's merge of equal-sized partials in a fixed order: after i+1 partials the running count is (i+1)*ni
+            const float ni = (float)(g.K / g.ln_parts), inv_ni = 1.0f / ni;
+            float mean = lnp[0].x * inv_ni, m2 = lnp[0].y;
+#pragma unroll
+            for (int i = 1; i < 16; ++i) {
+                if (i < g.ln_parts) {
+                    const float delta = lnp[i].x * inv_ni - mean;
+                    mean += delta * (1.0f / (float)(i + 1));
+                    m2 += lnp[i].y + delta * delta * (ni * (float)i / (float)(i + 1));
+                }
+            }
+            const float var = m2 / (float)g.K;
+            if (tid < BM) {
+                rowstats[2 * tid] = mean;
+                rowstats[2 * tid + 1] = 1.0f / sqrtf(var + g.ln_eps);
+            }
+        }
+    }
     __syncthreads();
     read_frags(fa0, fb0, 0, 0);
     auto k_step = [&](int kt, f32x4 (&ra)[TM], f32x4 (&rb)[TN]) {   // (ra, rb) holds tile kt+1 on entry
@@ -135,7 +173,7 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 128) ? 3 : 4) void gemm_f3
     // staging buffers can hold it; the GLU tile pairs value and gate columns in one wave and stores straight from the accumulators
     if constexpr (ROWS) {
         __syncthreads();                                   // every wave is done reading the staging buffers
-        gemm_epilogue_rows<BM, BN, EPI, TM, TN>(g, acc, m0, n0, wr, wc, lane, lds + wave * 32 * (32 * TN + 4));
+        gemm_epilogue_rows<BM, BN, EPI, TM, TN, 2, false, LN>(g, acc, m0, n0, wr, wc, lane, lds + wave * 32 * (32 * TN + 4), rowstats);
     } else {
         gemm_epilogue<BM, BN, EPI, TM, TN>(g, acc, m0, n0, wr, wc, li, hf);
     }
@@ -164,7 +202,7 @@ inline int choose_tile(int64_t M, int ncols, bool glu, int K) {
     return 3;
 }
 
-template <int BM, int BN, int EPI, bool CONV>
+template <int BM, int BN, int EPI, bool CONV, int LN = 0>
 int launch_cfg(GemmArgs g, hipStream_t s) {
     const int ncols = EPI == EPI_GLU ? g.n_out : g.N;
     const int bn = EPI == EPI_GLU ? BN / 2 : BN;
@@ -178,24 +216,41 @@ int launch_cfg(GemmArgs g, hipStream_t s) {
         const int per = (160 * 1024) / g.occ_cap;
         pad = per > kStatic ? (size_t)((per - kStatic) & ~255) : 0;
     }
-    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, EPI, CONV>), dim3(g.tiles_m * g.tiles_n), dim3(256), pad, s, g);
+    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, EPI, CONV, LN>), dim3(g.tiles_m * g.tiles_n), dim3(256), pad, s, g);
     return cfm_launch_status();
 }
 
-template <int EPI, bool CONV>
+template <int EPI, bool CONV, int LN = 0>
 int launch(const GemmArgs& g, hipStream_t s, int force_cfg = -1) {
     const int ncols = EPI == EPI_GLU ? g.n_out : g.N;
     const int tile = force_cfg >= 0 ? force_cfg : choose_tile(g.M, ncols, EPI == EPI_GLU, g.K);
     if constexpr (EPI == EPI_GLU) {
-        return (tile == 0 || tile == 1) ? launch_cfg<128, 128, EPI, CONV>(g, s) : launch_cfg<64, 128, EPI, CONV>(g, s);
+        return (tile == 0 || tile == 1) ? launch_cfg<128, 128, EPI, CONV, LN>(g, s) : launch_cfg<64, 128, EPI, CONV, LN>(g, s);
     } else {
         switch (tile) {
-            case 0: return launch_cfg<128, 128, EPI, CONV>(g, s);
-            case 1: return launch_cfg<128, 64, EPI, CONV>(g, s);
-            case 2: return launch_cfg<64, 128, EPI, CONV>(g, s);
-            default: return launch_cfg<64, 64, EPI, CONV>(g, s);
+            case 0: return launch_cfg<128, 128, EPI, CONV, LN>(g, s);
+            case 1: return launch_cfg<128, 64, EPI, CONV, LN>(g, s);
+            case 2: return launch_cfg<64, 128, EPI, CONV, LN>(g, s);
+            default: return launch_cfg<64, 64, EPI, CONV, LN>(g, s);
         }
     }
+}
+
+// the LN-fold forms live in the row-major vectorised epilogue only
+int check_ln(const GemmArgs& g, int ncols) {
+    CFM_REQUIRE((g.ldc & 3) == 0 && (ncols & 3) == 0 && CFM_ALIGNED16(g.C) && CFM_ALIGNED16(g.bias), CFM_ERR_ALIGN);
+    if (g.R) CFM_REQUIRE((g.ldr & 3) == 0 && CFM_ALIGNED16(g.R), CFM_ERR_ALIGN);
+    if (g.stats_out) {
+        CFM_REQUIRE((g.N & 31) == 0, CFM_ERR_BAD_SHAPE);
+        CFM_REQUIRE((reinterpret_cast<uintptr_t>(g.stats_out) & 7u) == 0, CFM_ERR_ALIGN);
+    }
+    if (g.ln_stats) {
+        CFM_REQUIRE(g.ln_colsum != nullptr, CFM_ERR_NULL);
+        CFM_REQUIRE(g.ln_parts >= 1 && g.K % g.ln_parts == 0, CFM_ERR_BAD_SHAPE);
+        CFM_REQUIRE(g.ln_parts <= 16, CFM_ERR_UNSUPPORTED);
+        CFM_REQUIRE((reinterpret_cast<uintptr_t>(g.ln_stats) & 7u) == 0 && CFM_ALIGNED16(g.ln_colsum), CFM_ERR_ALIGN);
+    }
+    return CFM_OK;
 }
 
 int check(const GemmArgs& g) {
@@ -287,6 +342,51 @@ extern "C" int cfm_gemm_bias_residual_f32(const float* A, const float* W, const 
     CFM_REQUIRE(R != nullptr, CFM_ERR_NULL);
     CFM_REQUIRE(ldc >= N && ldr >= N, CFM_ERR_BAD_SHAPE);
     return launch<EPI_RESID, false>(g, static_cast<hipStream_t>(stream));
+}
+
+// ---- LayerNorm folded into its neighbours (inference) ---------------------------------------------------------------
+// producers: the plain / residual GEMM that also emits the LayerNorm statistics partials of the rows it stores
+extern "C" int cfm_gemm_bias_stats_f32(const float* A, const float* W, const float* bias, float* C, float* stats_out,
+                                       int64_t M, int N, int K, int64_t lda, int64_t ldc, cfm_stream_t stream) {
+    GEMM_ARGS_PLAIN(N);
+    g.stats_out = stats_out;
+    int st = check(g); if (st) return st;
+    CFM_REQUIRE(stats_out != nullptr, CFM_ERR_NULL);
+    CFM_REQUIRE(ldc >= N, CFM_ERR_BAD_SHAPE);
+    st = check_ln(g, N); if (st) return st;
+    return launch<EPI_BIAS, false, 2>(g, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int cfm_gemm_bias_residual_stats_f32(const float* A, const float* W, const float* bias, const float* R,
+                                                float alpha, float* C, float* stats_out, int64_t M, int N, int K,
+                                                int64_t lda, int64_t ldr, int64_t ldc, cfm_stream_t stream) {
+    GEMM_ARGS_PLAIN(N);
+    g.R = R; g.ldr = ldr; g.alpha = alpha; g.stats_out = stats_out;
+    int st = check(g); if (st) return st;
+    CFM_REQUIRE(R != nullptr && stats_out != nullptr, CFM_ERR_NULL);
+    CFM_REQUIRE(ldc >= N && ldr >= N, CFM_ERR_BAD_SHAPE);
+    st = check_ln(g, N); if (st) return st;
+    return launch<EPI_RESID, false, 2>(g, static_cast<hipStream_t>(stream));
+}
+
+// consumer: C = epi(LN(A).W^T + b) computed from the UN-normalised A, its statistics partials and the folded parameters
+// Wf = W.diag(gamma), bias_f = b + W.beta, colsum[n] = sum_k Wf[n,k].  epi: 0 bias | 1 +swish | 3 +GLU (N = n_out, Wf has 2N rows).
+extern "C" int cfm_gemm_lnfold_f32(int epi, const float* A, const float* ln_stats, int ln_parts, float ln_eps,
+                                   const float* Wf, const float* bias_f, const float* colsum, float* C, int64_t M, int N,
+                                   int K, int64_t lda, int64_t ldc, cfm_stream_t stream) {
+    const float* W = Wf; const float* bias = bias_f;
+    GEMM_ARGS_PLAIN(epi == EPI_GLU ? 2 * N : N);
+    if (epi == EPI_GLU) g.n_out = N;
+    g.ln_stats = ln_stats; g.ln_parts = ln_parts; g.ln_eps = ln_eps; g.ln_colsum = colsum;
+    int st = check(g); if (st) return st;
+    CFM_REQUIRE(ln_stats != nullptr, CFM_ERR_NULL);
+    CFM_REQUIRE(N > 0 && ldc >= N && ln_eps >= 0.f, CFM_ERR_BAD_SHAPE);
+    st = check_ln(g, N); if (st) return st;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (epi == EPI_BIAS) return launch<EPI_BIAS, false, 1>(g, s);
+    if (epi == EPI_SWISH) return launch<EPI_SWISH, false, 1>(g, s);
+    if (epi == EPI_GLU) return launch<EPI_GLU, false, 1>(g, s);
+    return CFM_ERR_UNSUPPORTED;
 }
 
 // Implicit-GEMM second stem convolution (3x3, stride 2, channel-last input, packed weight).  Declared in the stem

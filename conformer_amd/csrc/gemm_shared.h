@@ -24,6 +24,11 @@ struct GemmArgs {
     int occ_cap;                    // 0 = natural; else blocks/CU cap enforced through a dynamic-LDS pad
     int c_prec;                     // 0: C is fp32; CFM_PREC_BF16 / CFM_PREC_FP16: C is stored in that 16-bit type (ldc in elements)
     unsigned long long* trace;      // diagnostics: per-block {start, end} s_memrealtime stamps + HW id, or NULL
+    // LayerNorm folded into the GEMMs either side of it (fp32 kernel, inference; see gemm_f32.hip "LN fold"):
+    float* stats_out;               // producer (LN == 2): [M][N/32][2] = per 32 stored columns of a C row (sum, M2 about their own mean)
+    const float* ln_stats;          // consumer (LN == 1): [M][ln_parts][2] partials of the UN-normalised A rows (equal column counts)
+    const float* ln_colsum;         // consumer: colsum[n] = sum_k W'[n,k], W' = W.diag(gamma) (GLU: value rows then gate rows)
+    int ln_parts; float ln_eps;
 };
 
 // ---- shared pieces --------------------------------------------------------------------------------------------
@@ -94,13 +99,18 @@ __device__ __forceinline__ int64_t a_k_offset(const GemmArgs& g, int k) {   // k
 struct EpiOps {
     f32x4 bb, bg, rr;               // bias, GLU gate bias, residual (or fp32 Z of EPI_DSWISH)
     unsigned z16[2];                // EPI_DSWISH: four 16-bit Z values, converted when they are used
+    f32x4 cs, cg;                   // LN fold (consumer): column sums of the folded weight (values, GLU gates)
 };
-template <int EPI>
+template <int EPI, int LN = 0>
 __device__ __forceinline__ void gemm_epilogue_fetch_bias(const GemmArgs& g, int col, EpiOps& o) {
     const int ncols = EPI == EPI_GLU ? g.n_out : g.N;
     const int cc = col < ncols ? col : 0;                              // (groups beyond the last column are never stored)
     if (EPI != EPI_DSWISH) o.bb = *reinterpret_cast<const f32x4*>(g.bias + cc);
     if (EPI == EPI_GLU) o.bg = *reinterpret_cast<const f32x4*>(g.bias + g.n_out + cc);
+    if constexpr (LN == 1) {
+        o.cs = *reinterpret_cast<const f32x4*>(g.ln_colsum + cc);
+        if (EPI == EPI_GLU) o.cg = *reinterpret_cast<const f32x4*>(g.ln_colsum + g.n_out + cc);
+    }
 }
 template <int EPI>
 __device__ __forceinline__ void gemm_epilogue_fetch_row(const GemmArgs& g, int64_t row, int col, EpiOps& o) {
@@ -204,15 +214,38 @@ __device__ __forceinline__ void epi_store8(void* base, int prec, int64_t off, co
 }
 
 // gemm_epilogue_apply: compute + stores of one fetched 4-column group (vectorised path)
-template <int EPI>
-__device__ __forceinline__ void gemm_epilogue_apply(const GemmArgs& g, const f32x4 av, const f32x4 gv, const EpiOps& o, int64_t row,
-                                                    int col, int64_t crow) {
+// LN == 1 (consumer of a folded LayerNorm): the accumulator holds x.W'^T of the UN-normalised row x; with (mean, rstd) of the row
+//   (rowstats: the tile's [BM][2] table in LDS, lrow = row - m0) LN(x).W^T = rstd * (acc - mean * colsum) (+ the folded bias).
+// LN == 2 (producer): every lane takes part (no early exit); the 8 lanes that hold 32 consecutive columns of a row reduce
+//   (sum, M2 about their own mean) of the STORED values and lane 0 of the group writes the partial (Chan-mergeable: no
+//   sum-of-squares cancellation).  Needs N % 32 == 0 (a group is all in or all out).
+template <int EPI, int LN = 0>
+__device__ __forceinline__ void gemm_epilogue_apply(const GemmArgs& g, f32x4 av, f32x4 gv, const EpiOps& o, int64_t row,
+                                                    int col, int64_t crow, const float* rowstats = nullptr, int lrow = 0) {
     const int ncols = EPI == EPI_GLU ? g.n_out : g.N;
-    if (row >= g.M || col >= ncols) return;
+    const bool ok = row < g.M && col < ncols;
+    if constexpr (LN != 2) { if (!ok) return; }
+    if constexpr (LN == 1) {
+        const float mean = rowstats[2 * lrow], rstd = rowstats[2 * lrow + 1];
+        av = (av - mean * o.cs) * rstd;
+        if (EPI == EPI_GLU) gv = (gv - mean * o.cg) * rstd;
+    }
     f32x4 zpre;
     const f32x4 v = gemm_epilogue_compute<EPI>(g, av, gv, o, row, col, zpre);
-    if (EPI == EPI_SWISH && g.Zsave) epi_store4(g.Zsave, g.z_prec, row * g.ldc + col, zpre);
-    epi_store4(g.C, g.c_prec, crow * g.ldc + col, v);
+    if (ok) {
+        if (EPI == EPI_SWISH && g.Zsave) epi_store4(g.Zsave, g.z_prec, row * g.ldc + col, zpre);
+        epi_store4(g.C, g.c_prec, crow * g.ldc + col, v);
+    }
+    if constexpr (LN == 2) {
+        float s = (v[0] + v[1]) + (v[2] + v[3]);
+        s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
+        const float m = s * (1.0f / 32.0f);
+        const f32x4 dv = v - m;
+        float q = (dv[0] * dv[0] + dv[1] * dv[1]) + (dv[2] * dv[2] + dv[3] * dv[3]);
+        q += __shfl_xor(q, 1, 64); q += __shfl_xor(q, 2, 64); q += __shfl_xor(q, 4, 64);
+        if (ok && (col & 31) == 0)
+            *reinterpret_cast<float2*>(g.stats_out + (row * (int64_t)(g.N >> 5) + (col >> 5)) * 2) = float2{s, q};
+    }
 }
 // ... of two adjacent groups = 8 consecutive columns of one row: a 16-bit output is then one 16-byte store per lane.  The
 // write-out of a tile is bound by the NUMBER of store instructions (~42 CU-cycles each at 8 or at 16 bytes per lane: the
@@ -332,9 +365,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const f32x16 (&
 // CLS: the rows are transposed-conv class rows (CONV == 2) and are scattered to their dh1 positions.  A TEMPLATE flag: as a run-time
 // test of g.pA the (skipped) 64-bit divisions were still unrolled into every kernel's epilogue -- 60 % more code in the 256x256
 // kernels, which ran 12-20 % slower from instruction-cache misses alone.
-template <int BM, int BN, int EPI, int TM, int TN, int WM = 2, bool CLS = false>
+template <int BM, int BN, int EPI, int TM, int TN, int WM = 2, bool CLS = false, int LN = 0>
 __device__ __forceinline__ void gemm_epilogue_rows(const GemmArgs& g, const f32x16 (&acc)[TM][TN], int64_t m0, int n0,
-                                                   int wr, int wc, int lane, float* scratch) {
+                                                   int wr, int wc, int lane, float* scratch, const float* rowstats = nullptr) {
     static_assert(EPI != EPI_GLU || TN == 2, "GLU: n-tile 0 = values, n-tile 1 = gates of the same 32 output columns");
     // row pitch, lanes per row, rows per wave-instruction (GLU: a row of the LDS tile is 32 values | 32 gates -> 32 output columns)
     constexpr int P = 32 * TN + 4, LPR = EPI == EPI_GLU ? 8 : 8 * TN, RPI = 64 / LPR;
@@ -371,7 +404,7 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmArgs& g, const f32x
     };
 
     // ---- 16-bit C: 8 columns per lane, one 16-byte store per lane and output tensor (see gemm_epilogue_apply8)
-    if constexpr (EPI != EPI_RESID && EPI != EPI_GLU) {
+    if constexpr (EPI != EPI_RESID && EPI != EPI_GLU && LN == 0) {
         const bool wide = g.c_prec != 0 && ((g.N | (int)g.ldc) & 7) == 0 && (reinterpret_cast<uintptr_t>(g.C) & 15) == 0 &&
                           (EPI != EPI_SWISH || !g.Zsave || (reinterpret_cast<uintptr_t>(g.Zsave) & 15) == 0) &&
                           (EPI != EPI_DSWISH || (g.z_prec != 0 && (g.ldr & 7) == 0 && (reinterpret_cast<uintptr_t>(g.Zsave) & 15) == 0));
@@ -433,7 +466,7 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmArgs& g, const f32x
     // Every load is issued ahead of the stores it would otherwise queue behind (see EpiOps): the bias once (a lane's columns
     // are the same for all its rows), the residual / Z rows of batch i+1 before batch i is written out.
     EpiOps ob;
-    gemm_epilogue_fetch_bias<EPI>(g, col, ob);
+    gemm_epilogue_fetch_bias<EPI, LN>(g, col, ob);
     if constexpr (!ROWOPS) {
 #pragma unroll
         for (int mt = 0; mt < TM; ++mt) {
@@ -444,7 +477,7 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmArgs& g, const f32x
                 const f32x4 v = *reinterpret_cast<const f32x4*>(scratch + rl * P + c4);
                 const f32x4 gate = EPI == EPI_GLU ? *reinterpret_cast<const f32x4*>(scratch + rl * P + 32 + c4) : v;
                 const int64_t row = row_of(mt, it);
-                gemm_epilogue_apply<EPI>(g, v, gate, ob, row, col, CLS ? class_row(row) : row);
+                gemm_epilogue_apply<EPI, LN>(g, v, gate, ob, row, col, CLS ? class_row(row) : row, rowstats, (int)(row - m0));
             }
             slab_done();
         }
@@ -473,7 +506,7 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmArgs& g, const f32x
                     const int64_t row = row_of(mt, it);
                     EpiOps o = ob;
                     o.rr = ocur[j].rr; o.z16[0] = ocur[j].z16[0]; o.z16[1] = ocur[j].z16[1];
-                    gemm_epilogue_apply<EPI>(g, v, v, o, row, col, CLS ? class_row(row) : row);
+                    gemm_epilogue_apply<EPI, LN>(g, v, v, o, row, col, CLS ? class_row(row) : row, rowstats, (int)(row - m0));
                 }
 #pragma unroll
                 for (int j = 0; j < HB; ++j) ocur[j] = onxt[j];

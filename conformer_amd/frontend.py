@@ -66,14 +66,14 @@ class ConformerAudioFrontend:
         T = L // self.hop_length + 1
         Lp = (L + 2 * pad + 3) // 4 * 4
         lib = _lib.load()
-        xp = torch.empty(B, Lp, device=x.device, dtype=x.dtype)
+        xp = torch.empty(B, Lp, device=x.device, dtype=torch.float32)
         _lib.check(lib.cfm_reflect_pad_f32(x.data_ptr(), xp.data_ptr(), B, L, pad, Lp, ops._stream()), "cfm_reflect_pad_f32")
         nb2 = self.basis.shape[0]
         lds = (nb2 + 3) // 4 * 4
-        spec = torch.empty(B * T, lds, device=x.device, dtype=x.dtype)
+        spec = torch.empty(B * T, lds, device=x.device, dtype=torch.float32)
         ops.gemm_bwd(xp, False, self.basis, False, T, nb2, self.n_fft, out=spec, lda=self.hop_length, ldb=self.n_fft,
                      ldc=lds, nbatch=B, nb1=1, sa=(Lp, 0), sb=(0, 0), sc=(T * lds, 0))
-        out = torch.empty(B, self.n_mels, T, device=x.device, dtype=x.dtype)
+        out = torch.empty(B, self.n_mels, T, device=x.device, dtype=torch.float32)
         _lib.check(lib.cfm_power_mel_log_f32(spec.data_ptr(), lds, self.fb.data_ptr(), out.data_ptr(), B, T,
                                              self.n_fft // 2 + 1, self.n_mels, 1e-5, ops._stream()), "cfm_power_mel_log_f32")
         return out

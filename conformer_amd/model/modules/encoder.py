@@ -36,6 +36,7 @@ class Encoder(nn.Module):
         refuse_dropout(self, "Encoder")
         d = self.linear.out_features
         h = self.downsampling_conv.channel_last(x)                                   # (B, T', F'*C)
+        st = None
         out_len = ConvolutionSubsampling.out_lengths(lengths)
         if ag.needs_grad(self.linear):
             # differentiable re-layout of the weight (columns c*F'+f -> f*C+c) so .grad lands in the reference layout
@@ -44,7 +45,11 @@ class Encoder(nn.Module):
         else:
             wlp = self._packs.get("wlp", (self.linear.weight,),
                                   lambda: ops.pack_linear_weight(self.linear.weight, d, self.n_freq_out))
-            h = ops.linear(h, wlp, self.linear.bias)                                 # (B, T', d)
+            fold = ops.ln_fold_ok(d) and len(self.layers) > 0 and h.dtype == torch.float32 and self.layers[0]._ln_fold(h)
+            if fold:      # the statistics of the rows the input Linear stores feed the first block's folded LayerNorm
+                h, st = ops.linear(h, wlp, self.linear.bias, emit_stats=True)
+            else:
+                h = ops.linear(h, wlp, self.linear.bias)                             # (B, T', d)
         n_frames = h.shape[1]
         if out_len is not None:
             if out_len.device != h.device:
@@ -54,7 +59,8 @@ class Encoder(nn.Module):
         table = self.rel_pe.table(n_frames)
         pos_all = self._projected_positions(table)
         for i, layer in enumerate(self.layers):
-            h = layer.fused(h, table, out_len, None if pos_all is None else pos_all[:, i * d:(i + 1) * d])
+            h, st = layer.fused_chain(h, table, out_len, None if pos_all is None else pos_all[:, i * d:(i + 1) * d],
+                                      x_stats=st, want_stats=i + 1 < len(self.layers))
         return h, out_len
 
     def _projected_positions(self, table: torch.Tensor) -> Optional[torch.Tensor]:

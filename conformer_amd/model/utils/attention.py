@@ -52,24 +52,33 @@ class RelativeMultiHeadAttention(nn.Module):
         return w, b
 
     def context(self, x: torch.Tensor, pos_table: torch.Tensor, lengths: Optional[torch.Tensor],
-                pos_projected: Optional[torch.Tensor] = None, for_gemm: bool = False) -> torch.Tensor:
+                pos_projected: Optional[torch.Tensor] = None, for_gemm: bool = False, ln_fold=None) -> torch.Tensor:
         """x: (B,T,d) already layer-normed; pos_table: (2T-1,d) un-projected; returns concat-head context.
         `pos_projected` (a (2T-1,d) view, any row stride) is this layer's slice of the encoder-wide batched
         pos_proj GEMM (Encoder._projected_positions); without it the projection runs here."""
         w, b = self._qkv_params()
         # inference under autocast: the projections are written in the 16-bit type (what torch.autocast's nn.Linear returns; the
         # attention core rounds its operands to that type anyway -- q after the bias add, as the reference does)
-        qkv = ops.linear(x, w, b, for_gemm=for_gemm)
+        if ln_fold is not None:
+            # x is NOT layer-normed: (stats, LayerNorm module) -- the LayerNorm of attention.py:15 folded into the fused q|k|v GEMM
+            stats, ln = ln_fold
+            wf, bf, cs = self._packs.get("qkv_ln_fold", (w, b, ln.weight, ln.bias),
+                                         lambda: ops.fold_layernorm(w, b, ln.weight, ln.bias))
+            qkv = ops.linear_lnfold(x, stats, wf, bf, cs, ln.eps)
+        else:
+            qkv = ops.linear(x, w, b, for_gemm=for_gemm)
         pos = pos_projected if pos_projected is not None else \
             ops.linear(pos_table, self.pos_proj.weight, self.pos_proj.bias)
         return ops.relpos_attention(qkv, pos, self.content_bias, self.position_bias, lengths, self.n_heads, for_gemm=for_gemm)
 
     def fused(self, x, pos_table, lengths, residual: Optional[torch.Tensor] = None,
-              pos_projected: Optional[torch.Tensor] = None) -> torch.Tensor:
-        ctx = self.context(x, pos_table, lengths, pos_projected, for_gemm=True)      # (the context only feeds out_proj)
+              pos_projected: Optional[torch.Tensor] = None, ln_fold=None, emit_stats: bool = False):
+        ctx = self.context(x, pos_table, lengths, pos_projected, for_gemm=True, ln_fold=ln_fold)   # (the context only feeds out_proj)
         if residual is None:
+            if emit_stats:
+                return ops.linear(ctx, self.out_proj.weight, self.out_proj.bias, emit_stats=True)
             return ops.linear(ctx, self.out_proj.weight, self.out_proj.bias)
-        return ops.linear_residual(ctx, self.out_proj.weight, self.out_proj.bias, residual, 1.0)
+        return ops.linear_residual(ctx, self.out_proj.weight, self.out_proj.bias, residual, 1.0, emit_stats=emit_stats)
 
     # ---- reference-compatible entry (attention.py:74) ------------------------------------------
     def forward(self, q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, pos_embedding: torch.Tensor,
@@ -102,7 +111,8 @@ class MultiHeadSelfAttentionModule(nn.Module):
         self.dropout = nn.Dropout(p=dropout_rate)
 
     def fused(self, x, pos_table, lengths, residual: Optional[torch.Tensor] = None,
-              pos_projected: Optional[torch.Tensor] = None) -> torch.Tensor:
+              pos_projected: Optional[torch.Tensor] = None, stats: Optional[torch.Tensor] = None, emit_stats: bool = False):
+        """stats / emit_stats: see FeedForwardModule.fused (the LayerNorm of attention.py:15 folds into the q|k|v GEMM)."""
         refuse_dropout(self, "MultiHeadSelfAttentionModule")
         if ag.needs_grad(self, x, pos_projected):
             a = self.attention
@@ -116,8 +126,11 @@ class MultiHeadSelfAttentionModule(nn.Module):
                                            a.out_proj.weight, a.out_proj.bias, lengths, a.n_heads, self.layer_norm.eps,
                                            active_dropout(self.dropout))
             return out if residual is not None else out - x
+        if stats is not None:
+            return self.attention.fused(x, pos_table, lengths, residual, pos_projected, ln_fold=(stats, self.layer_norm),
+                                        emit_stats=emit_stats)
         xn = ops.layernorm(x, self.layer_norm.weight, self.layer_norm.bias, self.layer_norm.eps, for_gemm=True)
-        return self.attention.fused(xn, pos_table, lengths, residual, pos_projected)
+        return self.attention.fused(xn, pos_table, lengths, residual, pos_projected, emit_stats=emit_stats)
 
     def forward(self, x: torch.Tensor, pos_embedding: torch.Tensor, mask: Optional[torch.Tensor] = None):
         table = pos_embedding[0] if pos_embedding.dim() == 3 else pos_embedding

@@ -2,7 +2,8 @@
 
 Each of the four residual sub-layers ends in an MFMA GEMM whose epilogue applies `alpha*y + x`
 (alpha = 1/2 for the two FFNs, block.py:19,25), so no stand-alone add/scale kernels run; the closing
-LayerNorm (block.py:27) is the wave-per-row kernel.  16 launches per block in total.
+LayerNorm (block.py:27) is the wave-per-row kernel.  16 launches per block in total; 12 on the folded-LayerNorm
+inference path (fused_chain).
 """
 from typing import Optional
 
@@ -28,13 +29,38 @@ class ConformerBlock(nn.Module):
 
     def fused(self, x: torch.Tensor, pos_table: torch.Tensor, lengths: Optional[torch.Tensor],
               pos_projected: Optional[torch.Tensor] = None) -> torch.Tensor:
-        y = self.ffn_1.fused(x, residual=x, alpha=0.5)
-        y = self.attention.fused(y, pos_table, lengths, residual=y, pos_projected=pos_projected)
-        y = self.conv.fused(y, residual=y)
-        y = self.ffn_2.fused(y, residual=y, alpha=0.5)
-        if ag.needs_grad(self.layer_norm, y):
-            return ag.LayerNormFn.apply(y, self.layer_norm.weight, self.layer_norm.bias, self.layer_norm.eps)
-        return ops.layernorm(y, self.layer_norm.weight, self.layer_norm.bias, self.layer_norm.eps)
+        return self.fused_chain(x, pos_table, lengths, pos_projected)[0]
+
+    def _ln_fold(self, x: torch.Tensor) -> bool:
+        """The folded-LayerNorm path (ops.ln_fold_ok): fp32 inference with eval-mode BatchNorm and no gradients."""
+        bn = self.conv.batch_norm
+        return (x.dtype == torch.float32 and ops.ln_fold_ok(self.layer_norm.normalized_shape[0])
+                and not (bn.training or bn.running_mean is None) and not ag.needs_grad(self, x))
+
+    def fused_chain(self, x: torch.Tensor, pos_table: torch.Tensor, lengths: Optional[torch.Tensor],
+                    pos_projected: Optional[torch.Tensor] = None, x_stats: Optional[torch.Tensor] = None,
+                    want_stats: bool = False):
+        """Returns (block output, LayerNorm statistics partials of its rows or None).  On the folded path (fp32 inference) every
+        residual GEMM's epilogue emits the statistics of the rows it stores and the next sub-layer's first GEMM applies the
+        LayerNorm from them (ops.linear_lnfold): the LayerNorms of ffn.py:16, attention.py:15 and convolution.py:22 are not
+        launched; the closing LayerNorm (block.py:27) runs and hands the statistics of ITS output to the next block
+        (x_stats / want_stats).  12 launches per block instead of 16."""
+        if not self._ln_fold(x):
+            y = self.ffn_1.fused(x, residual=x, alpha=0.5)
+            y = self.attention.fused(y, pos_table, lengths, residual=y, pos_projected=pos_projected)
+            y = self.conv.fused(y, residual=y)
+            y = self.ffn_2.fused(y, residual=y, alpha=0.5)
+            if ag.needs_grad(self.layer_norm, y):
+                return ag.LayerNormFn.apply(y, self.layer_norm.weight, self.layer_norm.bias, self.layer_norm.eps), None
+            return ops.layernorm(y, self.layer_norm.weight, self.layer_norm.bias, self.layer_norm.eps), None
+        y, st = self.ffn_1.fused(x, residual=x, alpha=0.5, stats=x_stats, emit_stats=True)
+        y, st = self.attention.fused(y, pos_table, lengths, residual=y, pos_projected=pos_projected, stats=st, emit_stats=True)
+        y, st = self.conv.fused(y, residual=y, stats=st, emit_stats=True)
+        y = self.ffn_2.fused(y, residual=y, alpha=0.5, stats=st)
+        ln = self.layer_norm
+        if want_stats:
+            return ops.layernorm(y, ln.weight, ln.bias, ln.eps, emit_stats=True)
+        return ops.layernorm(y, ln.weight, ln.bias, ln.eps), None
 
     def forward(self, x: torch.Tensor, pos_embedding: torch.Tensor, mask: Optional[torch.Tensor] = None) -> torch.Tensor:
         table = pos_embedding[0] if pos_embedding.dim() == 3 else pos_embedding

@@ -34,8 +34,12 @@ class ConvolutionModule(nn.Module):
         self.swish = Swish()
         self.pointwise_conv_2 = nn.Conv1d(channels, channels, kernel_size=1)
         self.dropout = nn.Dropout(p=dropout_rate)
+        self._packs = PackCache()
 
-    def fused(self, x: torch.Tensor, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+    def fused(self, x: torch.Tensor, residual: Optional[torch.Tensor] = None, stats: Optional[torch.Tensor] = None,
+              emit_stats: bool = False):
+        """stats / emit_stats: see FeedForwardModule.fused (the LayerNorm of convolution.py:22 folds into the pointwise_conv_1 +
+        GLU GEMM; eval-mode BatchNorm only)."""
         refuse_dropout(self, "ConvolutionModule")
         bn = self.batch_norm
         train_bn = bn.training or bn.running_mean is None      # nn.BatchNorm1d semantics: the BN sub-module's own flag
@@ -66,13 +70,21 @@ class ConvolutionModule(nn.Module):
             if train_bn:
                 bn.num_batches_tracked += 1
             return out if residual is not None else out - x
-        h = ops.layernorm(x, self.layer_norm.weight, self.layer_norm.bias, self.layer_norm.eps, for_gemm=True)
-        g = ops.linear_glu(h, self.pointwise_conv_1.weight, self.pointwise_conv_1.bias)
+        if stats is not None:
+            ln, pw1 = self.layer_norm, self.pointwise_conv_1
+            wf, bf, cs = self._packs.get("ln_fold", (pw1.weight, pw1.bias, ln.weight, ln.bias),
+                                         lambda: ops.fold_layernorm(pw1.weight, pw1.bias, ln.weight, ln.bias))
+            g = ops.linear_lnfold(x, stats, wf, bf, cs, ln.eps, glu=True)
+        else:
+            h = ops.layernorm(x, self.layer_norm.weight, self.layer_norm.bias, self.layer_norm.eps, for_gemm=True)
+            g = ops.linear_glu(h, self.pointwise_conv_1.weight, self.pointwise_conv_1.bias)
         s = ops.dwconv_bn_swish(g, self.deepwise_conv.weight, self.deepwise_conv.bias, bn.weight, bn.bias,
                                 bn.running_mean, bn.running_var, bn.eps, for_gemm=True)
         if residual is None:
+            if emit_stats:
+                return ops.linear(s, self.pointwise_conv_2.weight, self.pointwise_conv_2.bias, emit_stats=True)
             return ops.linear(s, self.pointwise_conv_2.weight, self.pointwise_conv_2.bias)
-        return ops.linear_residual(s, self.pointwise_conv_2.weight, self.pointwise_conv_2.bias, residual, 1.0)
+        return ops.linear_residual(s, self.pointwise_conv_2.weight, self.pointwise_conv_2.bias, residual, 1.0, emit_stats=emit_stats)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         return self.fused(x)

@@ -11,7 +11,7 @@ import torch.nn as nn
 
 from ... import autograd as ag
 from ... import ops
-from ._guard import active_dropout, refuse_dropout
+from ._guard import PackCache, active_dropout, refuse_dropout
 from .activation import Swish
 
 
@@ -24,8 +24,13 @@ class FeedForwardModule(nn.Module):
         self.dropout_1 = nn.Dropout(p=dropout_rate)
         self.out_linear = nn.Linear(in_features=4 * dim, out_features=dim)
         self.dropout_2 = nn.Dropout(p=dropout_rate)
+        self._packs = PackCache()
 
-    def fused(self, x: torch.Tensor, residual: Optional[torch.Tensor] = None, alpha: float = 1.0) -> torch.Tensor:
+    def fused(self, x: torch.Tensor, residual: Optional[torch.Tensor] = None, alpha: float = 1.0,
+              stats: Optional[torch.Tensor] = None, emit_stats: bool = False):
+        """stats / emit_stats (fp32 inference, ops.ln_fold_ok): `stats` are the LayerNorm statistics partials of the rows of x
+        written by x's producer -- the LayerNorm of ffn.py:16 is then folded into the hidden GEMM (no LayerNorm launch);
+        emit_stats returns (y, stats of y) from the residual GEMM's epilogue for the next sub-layer's LayerNorm."""
         refuse_dropout(self, "FeedForwardModule")
         if ag.needs_grad(self, x, residual):
             if residual is not None and residual is not x:
@@ -36,11 +41,19 @@ class FeedForwardModule(nn.Module):
                                          float(alpha), self.layer_norm.eps, active_dropout(self.dropout_1))
             # the Function always folds `+ x`; a stand-alone call (no residual) removes it again
             return out if residual is not None else out - x
-        h = ops.layernorm(x, self.layer_norm.weight, self.layer_norm.bias, self.layer_norm.eps, for_gemm=True)
-        h = ops.linear(h, self.hidden_linear.weight, self.hidden_linear.bias, act="swish", for_gemm=True)
+        if stats is not None:
+            ln, lin = self.layer_norm, self.hidden_linear
+            wf, bf, cs = self._packs.get("ln_fold", (lin.weight, lin.bias, ln.weight, ln.bias),
+                                         lambda: ops.fold_layernorm(lin.weight, lin.bias, ln.weight, ln.bias))
+            h = ops.linear_lnfold(x, stats, wf, bf, cs, ln.eps, act="swish")
+        else:
+            h = ops.layernorm(x, self.layer_norm.weight, self.layer_norm.bias, self.layer_norm.eps, for_gemm=True)
+            h = ops.linear(h, self.hidden_linear.weight, self.hidden_linear.bias, act="swish", for_gemm=True)
         if residual is None:
+            if emit_stats:
+                return ops.linear(h, self.out_linear.weight, self.out_linear.bias, emit_stats=True)
             return ops.linear(h, self.out_linear.weight, self.out_linear.bias)
-        return ops.linear_residual(h, self.out_linear.weight, self.out_linear.bias, residual, alpha)
+        return ops.linear_residual(h, self.out_linear.weight, self.out_linear.bias, residual, alpha, emit_stats=emit_stats)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         return self.fused(x)

@@ -33,6 +33,13 @@ def _p(t: Optional[torch.Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
 
 
+def _f32_like(t: torch.Tensor) -> torch.Tensor:
+    """An fp32 kernel-output buffer with t's shape.  Every kernel output in this file states its dtype: an output that inherits
+    the dtype of an input (`empty_like`) is half the size its kernel writes as soon as that input is stored in a 16-bit type --
+    the ABI takes raw pointers, so nothing else would notice (the stem-backward fault of round 2)."""
+    return torch.empty(t.shape, device=t.device, dtype=torch.float32)
+
+
 PREC_F32, PREC_BF16, PREC_FP16 = 0, 1, 2          # CFM_PREC_* of include/conformer_hip.h (0 = the fp32 MFMA path)
 _DT16 = {PREC_BF16: torch.bfloat16, PREC_FP16: torch.float16}
 _tls = threading.local()       # .forced: precision pinned by `precision(...)` for the current thread (autograd runs the
@@ -243,20 +250,75 @@ def subsampled_length(n: int) -> int:
     return int(_lib.load().cfm_subsampled_length(int(n)))
 
 
+# ---- LayerNorm folded into the GEMMs either side of it (fp32 inference; csrc/gemm_f32.hip "LN fold") -------------------------
+_LN_FOLD = __import__("os").environ.get("CONFORMER_AMD_LN_FOLD", "1") != "0"
+
+
+def set_ln_fold(on: bool) -> bool:
+    """Enable / disable the folded-LayerNorm inference path (default on; CONFORMER_AMD_LN_FOLD=0 disables).  Returns the
+    previous setting.  Off = every LayerNorm is its own kernel launch, as in rounds 1-2."""
+    global _LN_FOLD
+    prev, _LN_FOLD = _LN_FOLD, bool(on)
+    return prev
+
+
+def ln_fold_ok(d: int) -> bool:
+    """The fold applies to the native fp32 matrix-pipe path (no autocast, no split mode) for rows of d = 32 * parts <= 512
+    values (the statistics travel as one partial per 32 columns; a workgroup merges at most 16 of them)."""
+    return bool(_LN_FOLD and not _fp32_planes and mfma16_prec() == PREC_F32 and d % 32 == 0 and d // 32 <= 16)
+
+
+def fold_layernorm(w: torch.Tensor, b: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor):
+    """One-time re-parametrisation (cached per weight version by the callers): LN(x).W^T + b with LN's affine part moved
+    into the Linear: Wf = W.diag(gamma), bias_f = b + W.beta, colsum[n] = sum_k Wf[n,k] (the sum of the fp32 values the
+    kernel multiplies, accumulated in float64).  Returns (Wf, bias_f, colsum)."""
+    w2 = w.detach().reshape(w.shape[0], -1)
+    wf = (w2 * gamma.detach()[None, :]).contiguous()
+    bf = (b.detach().double() + w2.double() @ beta.detach().double()).float().contiguous()
+    cs = wf.double().sum(dim=1).float().contiguous()
+    return wf, bf, cs
+
+
+def linear_lnfold(a, stats, wf, bf, cs, eps: float, act: str = "none", glu: bool = False) -> torch.Tensor:
+    """epi(LN(a) @ W.T + b) from the un-normalised rows `a` (..., K), their statistics partials `stats` (rows, parts, 2)
+    and the folded parameters of fold_layernorm.  act: none | swish; glu: W has 2N rows (values, gates)."""
+    a = _req(a, "A"); wf = _req(wf, "Wf"); bf = _req(bf, "bias_f"); cs = _req(cs, "colsum"); stats = _req(stats, "ln_stats")
+    k = a.shape[-1]
+    m = a.numel() // k
+    n = wf.shape[0] // 2 if glu else wf.shape[0]
+    if wf.shape[1] != k or stats.dim() != 3 or stats.shape[0] != m or stats.shape[2] != 2:
+        raise _lib.ConformerHipError(f"linear_lnfold: A(...,{k}), Wf{tuple(wf.shape)}, stats{tuple(stats.shape)} do not match")
+    c = torch.empty(*a.shape[:-1], n, device=a.device, dtype=torch.float32)
+    epi = 3 if glu else {"none": 0, "swish": 1}[act]
+    _lib.check(_lib.load().cfm_gemm_lnfold_f32(epi, a.data_ptr(), stats.data_ptr(), stats.shape[1], float(eps), wf.data_ptr(),
+                                               bf.data_ptr(), cs.data_ptr(), c.data_ptr(), m, n, k, k, n, _stream()),
+               "cfm_gemm_lnfold_f32")
+    return c
+
+
 def layernorm(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, eps: float = 1e-5,
-              out: Optional[torch.Tensor] = None, for_gemm: bool = False) -> torch.Tensor:
+              out: Optional[torch.Tensor] = None, for_gemm: bool = False, emit_stats: bool = False):
     """for_gemm: the result only feeds GEMM operands -- under autocast it is written in the 16-bit matrix-pipe type (the
-    GEMM would round it to that type anyway: identical results, half the bytes)."""
+    GEMM would round it to that type anyway: identical results, half the bytes).
+    emit_stats (fp32): returns (y, stats (rows, 1, 2)) -- the statistics partial of every OUTPUT row for a folded LayerNorm."""
     x = _req(x, "x"); weight = _req(weight, "weight"); bias = _req(bias, "bias")
     d = x.shape[-1]
     rows = x.numel() // d
+    if emit_stats:
+        y = torch.empty(x.shape, device=x.device, dtype=torch.float32)
+        stats = torch.empty(rows, 1, 2, device=x.device, dtype=torch.float32)
+        _lib.check(_lib.load().cfm_layernorm_fwd_stats_f32(x.data_ptr(), weight.data_ptr(), bias.data_ptr(), y.data_ptr(),
+                                                           stats.data_ptr(), rows, d, eps, _stream()), "cfm_layernorm_fwd_stats_f32")
+        return y, stats
     p16 = out16_ok(d) if for_gemm and out is None else 0
     if p16:
         y = torch.empty(x.shape, device=x.device, dtype=_DT16[p16])
         _lib.check(_lib.load().cfm_layernorm_fwd_out16_f32(p16, x.data_ptr(), weight.data_ptr(), bias.data_ptr(), y.data_ptr(),
                                                            None, None, rows, d, eps, _stream()), "cfm_layernorm_fwd_out16_f32")
         return y
-    y = torch.empty_like(x) if out is None else out
+    y = _f32_like(x) if out is None else _req(out, "out")
+    if y.shape != x.shape:
+        raise _lib.ConformerHipError(f"layernorm: out{tuple(y.shape)} does not match x{tuple(x.shape)}")
     st = _lib.load().cfm_layernorm_fwd_f32(x.data_ptr(), weight.data_ptr(), bias.data_ptr(), y.data_ptr(),
                                            None, None, rows, d, eps, _stream())
     _lib.check(st, "cfm_layernorm_fwd_f32")
@@ -274,9 +336,18 @@ def _gemm_common(a: torch.Tensor, w: torch.Tensor, b: torch.Tensor):
     return a, w2, b, m, w2.shape[0], k
 
 
-def linear(a, w, b, act: str = "none", for_gemm: bool = False) -> torch.Tensor:
-    """y = act(a @ w.T + b); act in {none, swish, relu}.  for_gemm: see layernorm (y feeds a GEMM of contraction length n)."""
+def linear(a, w, b, act: str = "none", for_gemm: bool = False, emit_stats: bool = False):
+    """y = act(a @ w.T + b); act in {none, swish, relu}.  for_gemm: see layernorm (y feeds a GEMM of contraction length n).
+    emit_stats (native fp32, act none, ln_fold_ok(n)): returns (y, stats (rows, n/32, 2)) for a folded LayerNorm of y."""
     a, w2, b, m, n, k = _gemm_common(a, w, b)
+    if emit_stats:
+        if act != "none" or not ln_fold_ok(n) or a.dtype != torch.float32:
+            raise _lib.ConformerHipError("linear(emit_stats=True) needs the native fp32 path, act='none' and ln_fold_ok(N)")
+        c = torch.empty(*a.shape[:-1], n, device=a.device, dtype=torch.float32)
+        stats = torch.empty(m, n // 32, 2, device=a.device, dtype=torch.float32)
+        _lib.check(_lib.load().cfm_gemm_bias_stats_f32(a.data_ptr(), w2.data_ptr(), b.data_ptr(), c.data_ptr(), stats.data_ptr(),
+                                                       m, n, k, k, n, _stream()), "cfm_gemm_bias_stats_f32")
+        return c, stats
     prec = mfma16_prec()
     p16 = out16_ok(n) if for_gemm else 0
     c = torch.empty(*a.shape[:-1], n, device=a.device, dtype=_DT16[p16] if p16 else torch.float32)
@@ -306,10 +377,19 @@ def linear_glu(a, w, b) -> torch.Tensor:
     return c
 
 
-def linear_residual(a, w, b, res: torch.Tensor, alpha: float = 1.0) -> torch.Tensor:
-    """alpha * (a @ w.T + b) + res."""
+def linear_residual(a, w, b, res: torch.Tensor, alpha: float = 1.0, emit_stats: bool = False):
+    """alpha * (a @ w.T + b) + res.  emit_stats: see linear."""
     a, w2, b, m, n, k = _gemm_common(a, w, b)
     res = _req(res, "residual")
+    if emit_stats:
+        if not ln_fold_ok(n) or a.dtype != torch.float32:
+            raise _lib.ConformerHipError("linear_residual(emit_stats=True) needs the native fp32 path and ln_fold_ok(N)")
+        c = torch.empty(*a.shape[:-1], n, device=a.device, dtype=torch.float32)
+        stats = torch.empty(m, n // 32, 2, device=a.device, dtype=torch.float32)
+        _lib.check(_lib.load().cfm_gemm_bias_residual_stats_f32(a.data_ptr(), w2.data_ptr(), b.data_ptr(), res.data_ptr(), alpha,
+                                                                c.data_ptr(), stats.data_ptr(), m, n, k, k, n, n, _stream()),
+                   "cfm_gemm_bias_residual_stats_f32")
+        return c, stats
     c = torch.empty(*a.shape[:-1], n, device=a.device, dtype=torch.float32)
     prec = mfma16_prec()
     if prec:
@@ -325,7 +405,7 @@ def linear_residual(a, w, b, res: torch.Tensor, alpha: float = 1.0) -> torch.Ten
 def relpos_table(div_term: torch.Tensor, t: int) -> torch.Tensor:
     dt = _req(div_term, "div_term").reshape(-1)
     d = 2 * dt.numel()
-    pe = torch.empty(2 * t - 1, d, device=dt.device, dtype=dt.dtype)
+    pe = torch.empty(2 * t - 1, d, device=dt.device, dtype=torch.float32)
     st = _lib.load().cfm_relpos_table_f32(dt.data_ptr(), pe.data_ptr(), t, d, _stream())
     _lib.check(st, "cfm_relpos_table_f32")
     return pe
@@ -363,7 +443,7 @@ def relpos_attention(qkv: torch.Tensor, pos: torch.Tensor, u: torch.Tensor, v: t
                                                               ctx.data_ptr(), int(c16), d, B, T, n_heads, dh, _stream())
         _lib.check(st, "cfm_relpos_attention_io16_mfma16_f32")
         return ctx
-    ctx = torch.empty(B, T, d, device=qkv.device, dtype=qkv.dtype)
+    ctx = torch.empty(B, T, d, device=qkv.device, dtype=torch.float32)
     if prec:
         st = _lib.load().cfm_relpos_attention_mfma16_f32(prec, base, base + 4 * d, base + 8 * d, d3, pos.data_ptr(), ldp,
                                                          u.data_ptr(), v.data_ptr(), _p(lengths), ctx.data_ptr(), d, None,
@@ -419,7 +499,7 @@ def dwconv_bn_swish(g, w, b, bn_w, bn_b, bn_mean, bn_var, eps: float = 1e-5, for
                                                            _stream())
         _lib.check(st, "cfm_dwconv_bn_swish_fwd_out16_f32")
         return y
-    y = torch.empty_like(g)
+    y = _f32_like(g)
     st = _lib.load().cfm_dwconv_bn_swish_fwd_f32(g.data_ptr(), w.data_ptr(), b.data_ptr(), _req(bn_w, "bn_w").data_ptr(),
                                                  _req(bn_b, "bn_b").data_ptr(), _req(bn_mean, "bn_mean").data_ptr(),
                                                  _req(bn_var, "bn_var").data_ptr(), eps, y.data_ptr(), B, T, C, K,
@@ -431,14 +511,14 @@ def dwconv_bn_swish(g, w, b, bn_w, bn_b, bn_mean, bn_var, eps: float = 1e-5, for
 def pack_conv2_weight(w2: torch.Tensor) -> torch.Tensor:
     w2 = _req(w2, "conv_2.weight")
     C = w2.shape[0]
-    out = torch.empty(C, 9 * C, device=w2.device, dtype=w2.dtype)
+    out = torch.empty(C, 9 * C, device=w2.device, dtype=torch.float32)
     _lib.check(_lib.load().cfm_pack_conv2_weight_f32(w2.data_ptr(), out.data_ptr(), C, _stream()), "cfm_pack_conv2_weight_f32")
     return out
 
 
 def pack_linear_weight(wl: torch.Tensor, C: int, F2: int) -> torch.Tensor:
     wl = _req(wl, "linear.weight")
-    out = torch.empty_like(wl)
+    out = _f32_like(wl)
     _lib.check(_lib.load().cfm_pack_linear_weight_f32(wl.data_ptr(), out.data_ptr(), wl.shape[0], C, F2, _stream()),
                "cfm_pack_linear_weight_f32")
     return out
@@ -460,10 +540,10 @@ def subsample_stem(x: torch.Tensor, w1, b1, w2p, b2) -> torch.Tensor:
                                                           T, C, _stream()), "cfm_subsample_conv1_relu_out16_f32")
         h2 = torch.empty(B, T2, F2 * C, device=x.device, dtype=_DT16[p16])
     else:
-        h1 = torch.empty(B, T1, F1, C, device=x.device, dtype=x.dtype)
+        h1 = torch.empty(B, T1, F1, C, device=x.device, dtype=torch.float32)
         _lib.check(lib.cfm_subsample_conv1_relu_f32(x.data_ptr(), w1.data_ptr(), b1.data_ptr(), h1.data_ptr(), B, F, T, C,
                                                     _stream()), "cfm_subsample_conv1_relu_f32")
-        h2 = torch.empty(B, T2, F2 * C, device=x.device, dtype=x.dtype)
+        h2 = torch.empty(B, T2, F2 * C, device=x.device, dtype=torch.float32)
     _conv2_relu(lib, h1, w2p, b2, h2, B, F1, T1, C)
     return h2
 
@@ -524,8 +604,8 @@ def layernorm_train(x, weight, bias, eps: float = 1e-5, for_gemm: bool = False):
     x = _req(x, "x"); weight = _req(weight, "weight"); bias = _req(bias, "bias")
     d = x.shape[-1]
     rows = x.numel() // d
-    mean = torch.empty(rows, device=x.device, dtype=x.dtype)
-    rstd = torch.empty(rows, device=x.device, dtype=x.dtype)
+    mean = torch.empty(rows, device=x.device, dtype=torch.float32)
+    rstd = torch.empty(rows, device=x.device, dtype=torch.float32)
     p16 = out16_ok(d) if for_gemm else 0
     if p16:
         y = torch.empty(x.shape, device=x.device, dtype=_DT16[p16])
@@ -533,7 +613,7 @@ def layernorm_train(x, weight, bias, eps: float = 1e-5, for_gemm: bool = False):
                                                            mean.data_ptr(), rstd.data_ptr(), rows, d, eps, _stream()),
                    "cfm_layernorm_fwd_out16_f32")
         return y, mean, rstd
-    y = torch.empty_like(x)
+    y = _f32_like(x)
     st = _lib.load().cfm_layernorm_fwd_f32(x.data_ptr(), weight.data_ptr(), bias.data_ptr(), y.data_ptr(),
                                            mean.data_ptr(), rstd.data_ptr(), rows, d, eps, _stream())
     _lib.check(st, "cfm_layernorm_fwd_f32")
@@ -546,7 +626,7 @@ def layernorm_bwd(x, weight, dy, mean, rstd, dres=None):
     d = x.shape[-1]
     rows = x.numel() // d
     lib = _lib.load()
-    dx = torch.empty_like(x)
+    dx = _f32_like(x)
     if dres is not None:
         dres = _req(dres, "dres")
     dw, db = _zeros_split(x.device, x.dtype, (d,), (d,))
@@ -570,8 +650,8 @@ def layernorm_bwd(x, weight, dy, mean, rstd, dres=None):
 def linear_swish_save(a, w, b):
     """Returns (swish(z), z) with z = a @ w.T + b."""
     a, w2, b, m, n, k = _gemm_common(a, w, b)
-    c = torch.empty(*a.shape[:-1], n, device=a.device, dtype=a.dtype)
-    z = torch.empty_like(c)
+    c = torch.empty(*a.shape[:-1], n, device=a.device, dtype=torch.float32)
+    z = _f32_like(c)
     st = _lib.load().cfm_gemm_bias_swish_save_f32(a.data_ptr(), w2.data_ptr(), b.data_ptr(), c.data_ptr(), z.data_ptr(),
                                                   m, n, k, k, n, _stream())
     _lib.check(st, "cfm_gemm_bias_swish_save_f32")
@@ -652,7 +732,7 @@ def dropout_apply(x, drop_p: float, seed: int, for_gemm: bool = False):
         return y
     if drop_p <= 0.0:
         return x
-    y = torch.empty_like(x)
+    y = _f32_like(x)
     _lib.check(_lib.load().cfm_dropout_f32(x.data_ptr(), y.data_ptr(), x.numel(), float(drop_p), int(seed), _stream()),
                "cfm_dropout_f32")
     return y
@@ -662,7 +742,7 @@ def glu_fwd(z):
     z = _req(z, "z")
     n = z.shape[-1] // 2
     rows = z.numel() // (2 * n)
-    y = torch.empty(*z.shape[:-1], n, device=z.device, dtype=z.dtype)
+    y = torch.empty(*z.shape[:-1], n, device=z.device, dtype=torch.float32)
     _lib.check(_lib.load().cfm_glu_fwd_f32(z.data_ptr(), y.data_ptr(), rows, n, _stream()), "cfm_glu_fwd_f32")
     return y
 
@@ -672,13 +752,14 @@ def glu_bwd(z, dy, for_gemm: bool = False):
     z = _req(z, "z"); dy = _req(dy, "dy")
     n = dy.shape[-1]
     rows = dy.numel() // n
-    p16 = out16_ok(2 * n) if for_gemm else 0
+    # (the consumer is linear_bwd(h0, w1 (2n, n), dz): its all-16-bit kernels need BOTH dimensions of w1 to be multiples of 8)
+    p16 = out16_ok(2 * n) if for_gemm and n % 8 == 0 else 0
     if p16:
         dz = torch.empty(z.shape, device=z.device, dtype=_DT16[p16])
         _lib.check(_lib.load().cfm_glu_bwd_out16_f32(p16, z.data_ptr(), dy.data_ptr(), dz.data_ptr(), rows, n, _stream()),
                    "cfm_glu_bwd_out16_f32")
         return dz
-    dz = torch.empty_like(z)
+    dz = _f32_like(z)
     _lib.check(_lib.load().cfm_glu_bwd_f32(z.data_ptr(), dy.data_ptr(), dz.data_ptr(), rows, n, _stream()),
                "cfm_glu_bwd_f32")
     return dz
@@ -741,8 +822,12 @@ def linear_bwd(x2d, w, dy2d, *, alpha: float = 1.0, Z=None, need_dx: bool = True
     prec = mfma16_prec()
     dy16 = dy2d.dtype != torch.float32
     z_ok = Z is not None and n % 8 == 0 and k % 8 == 0 and Z.stride(0) % 8 == 0      # the swish' product on the forward kernel
-    if dy16 and not (prec and dy2d.dtype == _DT16[prec] and n % 8 == 0 and k % 8 == 0 and (z_ok or (Z is None and alpha == 1.0))):
-        raise _lib.ConformerHipError("a 16-bit dY needs the matching precision mode, N % 8 == 0, K % 8 == 0 and alpha = 1 (or a saved Z)")
+    if dy16 and not (prec and dy2d.dtype == _DT16[prec]):
+        raise _lib.ConformerHipError("a 16-bit dY needs the matching 16-bit precision mode")
+    if dy16 and not (n % 8 == 0 and k % 8 == 0 and (z_ok or (Z is None and alpha == 1.0))):
+        # a producer wrote its gradient in the 16-bit type for a consumer whose shape the aligned 16-bit kernels do not cover
+        # (d % 8 == 4): widen it and take the general kernels rather than refuse (off the tuned shapes; one stock cast)
+        dy2d, dy16 = dy2d.float(), False
     if dy2d.stride(0) & 3:                        # e.g. the vocabulary projection (N = 370): rows must start 16-byte aligned
         padded = torch.zeros(m, (n + 3) // 4 * 4, device=dy2d.device, dtype=dy2d.dtype)
         padded[:, :n] = dy2d
@@ -764,7 +849,9 @@ def linear_bwd(x2d, w, dy2d, *, alpha: float = 1.0, Z=None, need_dx: bool = True
                                                    Z.stride(0), k, float(drop_p), int(drop_seed), _stream()), "cfm_gemm_mfma16_f32")
     elif need_dx:
         w16 = weight16(w2, prec) if prec else None              # the cast the forward made (same parameter version)
-        c16 = bool(dx16 and prec and Z is not None and k % 8 == 0)
+        # (a 16-bit dx feeds linear_bwd of the layer below, whose weight is (k, n'): it takes a 16-bit dY only when both k and
+        # its own contraction length are multiples of 8 -- for the FFN that length is this layer's n)
+        c16 = bool(dx16 and prec and Z is not None and k % 8 == 0 and n % 8 == 0)
         dx = gemm_bwd(dy2d, False, w2 if w16 is None else w16, True, m, k, n, alpha=alpha, Z=Z, drop_p=drop_p,
                       drop_seed=drop_seed, prec=prec, b16=w16 is not None, c16=c16)
     dw, db = _zeros_split(dy2d.device, torch.float32, (n, k), (n,))
@@ -792,7 +879,7 @@ def dwconv_bn_batch_stats(g, w, b, running_mean, running_var, momentum: float = 
     K = w.shape[-1]
     lib = _lib.load()
     nws = int(lib.cfm_dwconv_bn_stats_workspace_bytes(B, T, C))
-    buf = torch.empty(2 * C + (nws + 3) // 4, device=g.device, dtype=g.dtype)     # mean | var | per-workgroup partials
+    buf = torch.empty(2 * C + (nws + 3) // 4, device=g.device, dtype=torch.float32)     # mean | var | per-workgroup partials
     mean, var, ws = buf[:C], buf[C:2 * C], buf[2 * C:]
     st = lib.cfm_dwconv_bn_stats_f32(g.data_ptr(), w.data_ptr(), b.data_ptr(), mean.data_ptr(), var.data_ptr(),
                                      _p(running_mean), _p(running_var), momentum, B, T, C, K, ws.data_ptr(), nws, _stream())
@@ -805,8 +892,8 @@ def dwconv_bn_swish_bwd(g, dy, w, b, bn_w, bn_b, bn_mean, bn_var, eps: float = 1
     g = _req(g, "g"); dy = _req(dy, "dy")
     B, T, C = g.shape
     K = w.shape[-1]
-    dc = torch.empty_like(g)
-    dg = torch.empty_like(g)
+    dc = _f32_like(g)
+    dg = _f32_like(g)
     dw, db, dga, dbe = _zeros_split(g.device, g.dtype, tuple(w.shape), (C,), (C,), (C,))
     st = _lib.load().cfm_dwconv_bn_swish_bwd_f32(g.data_ptr(), dy.data_ptr(), w.data_ptr(), b.data_ptr(), bn_w.data_ptr(),
                                                  bn_b.data_ptr(), bn_mean.data_ptr(), bn_var.data_ptr(), eps,
@@ -819,18 +906,12 @@ def dwconv_bn_swish_bwd(g, dy, w, b, bn_w, bn_b, bn_mean, bn_var, eps: float = 1
 def relpos_attention_train(qkv, pos, u, v, lengths, n_heads, drop_p: float = 0.0, seed: int = 0):
     """Forward that also returns the per-row log-sum-exp (B,H,T) for the backward; optional weight dropout."""
     u = _req(u, "content_bias"); v = _req(v, "position_bias")
-    prec = mfma16_prec()
-    q16 = bool(prec) and isinstance(qkv, torch.Tensor) and qkv.dtype == _DT16[prec]      # autocast inference: 16-bit projections
-    if q16:
-        if not (qkv.is_cuda and qkv.is_contiguous() and qkv.shape[-1] % 24 == 0):
-            raise _lib.ConformerHipError("16-bit qkv: expected a contiguous HIP tensor with d % 8 == 0")
-    else:
-        qkv = _req(qkv, "qkv")
+    qkv = _req(qkv, "qkv")       # fp32 projections only: the training kernels (forward with log-sum-exp, flash backward) read fp32 q|k|v
     B, T, d3 = qkv.shape
     d = d3 // 3
     dh = d // n_heads
-    ctx = torch.empty(B, T, d, device=qkv.device, dtype=qkv.dtype)
-    lse = torch.empty(B, n_heads, T, device=qkv.device, dtype=qkv.dtype)
+    ctx = torch.empty(B, T, d, device=qkv.device, dtype=torch.float32)
+    lse = torch.empty(B, n_heads, T, device=qkv.device, dtype=torch.float32)
     base = qkv.data_ptr()
     prec = mfma16_prec()
     if prec:
@@ -893,10 +974,10 @@ def subsample_stem_train(x, w1, b1, w2p, b2):
         _lib.check(lib.cfm_subsample_conv1_relu_out16_f32(p16, x.data_ptr(), w1.data_ptr(), b1.data_ptr(), h1.data_ptr(), B, F,
                                                           T, C, _stream()), "cfm_subsample_conv1_relu_out16_f32")
     else:
-        h1 = torch.empty(B, T1, F1, C, device=x.device, dtype=x.dtype)
+        h1 = torch.empty(B, T1, F1, C, device=x.device, dtype=torch.float32)
         _lib.check(lib.cfm_subsample_conv1_relu_f32(x.data_ptr(), w1.data_ptr(), b1.data_ptr(), h1.data_ptr(), B, F, T, C,
                                                     _stream()), "cfm_subsample_conv1_relu_f32")
-    h2 = torch.empty(B, T2, F2 * C, device=x.device, dtype=x.dtype)
+    h2 = torch.empty(B, T2, F2 * C, device=x.device, dtype=torch.float32)
     _conv2_relu(lib, h1, w2p, b2, h2, B, F1, T1, C)
     return h2, h1
 
@@ -925,7 +1006,7 @@ def subsample_stem_bwd(x, w1, b1, w2, h1, h2, dh2):
                                                                      dw2p.data_ptr(), db2.data_ptr(), B, F1, T1, C, _stream()),
                    "cfm_subsample_conv2_bwd_weight_h16_mfma16_f32")
     else:
-        dz2 = torch.empty_like(dh2)
+        dz2 = _f32_like(dh2)
         _lib.check(lib.cfm_relu_bwd_f32(h2.data_ptr(), dh2.data_ptr(), dz2.data_ptr(), dz2.numel(), _stream()),
                    "cfm_relu_bwd_f32")
         colsum(dz2.view(-1, C), out=db2)
@@ -935,7 +1016,7 @@ def subsample_stem_bwd(x, w1, b1, w2, h1, h2, dh2):
         else:
             _lib.check(lib.cfm_subsample_conv2_bwd_weight_f32(dz2.data_ptr(), h1.data_ptr(), dw2p.data_ptr(), B, F1, T1, C,
                                                               _stream()), "cfm_subsample_conv2_bwd_weight_f32")
-    w2c = torch.empty(9 * C * C, device=x.device, dtype=x.dtype)
+    w2c = torch.empty(9 * C * C, device=x.device, dtype=torch.float32)
     _lib.check(lib.cfm_pack_conv2_weight_t_f32(w2.data_ptr(), w2c.data_ptr(), C, _stream()), "cfm_pack_conv2_weight_t_f32")
     # dh1: fp32, or -- all-16-bit stem of the autocast path -- in the 16-bit type: its only consumer is the conv1 parameter-gradient
     # reduction, and under torch.autocast conv1's incoming gradient is a 16-bit tensor.  (Never empty_like(h1) for the fp32 case:
@@ -971,10 +1052,10 @@ def lstm_forward(x, w_ih, w_hh, bias, lengths=None, save: bool = False):
     B, T, _ = x.shape
     H = w_hh.shape[1]
     gx = linear(x, w_ih, bias)                                        # (B,T,4H)
-    y = torch.empty(B, T, H, device=x.device, dtype=x.dtype)
-    c = torch.empty(B, H, device=x.device, dtype=x.dtype)
-    gates = torch.empty(B, T, 4 * H, device=x.device, dtype=x.dtype) if save else None
-    cells = torch.empty(B, T, H, device=x.device, dtype=x.dtype) if save else None
+    y = torch.empty(B, T, H, device=x.device, dtype=torch.float32)
+    c = torch.empty(B, H, device=x.device, dtype=torch.float32)
+    gates = torch.empty(B, T, 4 * H, device=x.device, dtype=torch.float32) if save else None
+    cells = torch.empty(B, T, H, device=x.device, dtype=torch.float32) if save else None
     if lengths is not None:
         lengths = _req(lengths, "lengths", torch.int64)
     prec = mfma16_prec()
@@ -993,7 +1074,7 @@ def lstm_forward(x, w_ih, w_hh, bias, lengths=None, save: bool = False):
         # fp32 recurrence with both operands in MFMA fragment order (bit-identical to the row-major kernel, fewer cache
         # lines per load): W_hh -> (H/4, H/16, kq 4, gate 4, unit 4, 4)
         wf = w_hh.view(4, H // 4, 4, H // 16, 4, 4).permute(1, 3, 4, 0, 2, 5).contiguous()
-        hf = torch.empty(2 * ((B + 15) // 16) * 16 * H, device=x.device, dtype=x.dtype)
+        hf = torch.empty(2 * ((B + 15) // 16) * 16 * H, device=x.device, dtype=torch.float32)
         _lib.check(_lib.load().cfm_lstm_fwd_frag_f32(gx.data_ptr(), wf.data_ptr(), _p(lengths), y.data_ptr(), c.data_ptr(),
                                                      hf.data_ptr(), _p(gates), _p(cells), B, T, H, _stream()),
                    "cfm_lstm_fwd_frag_f32")
@@ -1006,7 +1087,7 @@ def lstm_forward(x, w_ih, w_hh, bias, lengths=None, save: bool = False):
 def swish_bn_eval(h, bn_mean, bn_var, bn_weight, bn_bias, eps: float = 1e-5):
     h = _req(h, "h")
     C = h.shape[-1]
-    out = torch.empty_like(h)
+    out = _f32_like(h)
     _lib.check(_lib.load().cfm_swish_bn_eval_f32(h.data_ptr(), _req(bn_mean, "bn_mean").data_ptr(),
                                                  _req(bn_var, "bn_var").data_ptr(), _req(bn_weight, "bn_weight").data_ptr(),
                                                  _req(bn_bias, "bn_bias").data_ptr(), eps, out.data_ptr(), h.numel() // C, C,
@@ -1021,8 +1102,8 @@ def lstm_backward(x, w_ih, w_hh, y, gates, cells, dy, lengths=None, need_dx: boo
     B, T, D = x.shape
     H = w_hh.shape[1]
     dy = _req(dy, "dy")
-    dG = torch.empty(B, T, 4 * H, device=x.device, dtype=x.dtype)
-    dc = torch.empty(B, H, device=x.device, dtype=x.dtype)
+    dG = torch.empty(B, T, 4 * H, device=x.device, dtype=torch.float32)
+    dc = torch.empty(B, H, device=x.device, dtype=torch.float32)
     prec = mfma16_prec()
     wt16 = weight16(w_hh, prec, transposed=True) if prec and H % 16 == 0 else None
     if wt16 is not None:
@@ -1035,7 +1116,7 @@ def lstm_backward(x, w_ih, w_hh, y, gates, cells, dy, lengths=None, need_dx: boo
     elif H % 16 == 0:
         # fp32: W_hh^T (H,4H) -> (H/16, 4H/16, kq 4, unit 16, 4); dG_t exchanged between steps in the same order
         wtf = w_hh.t().reshape(H // 16, 16, 4 * H // 16, 4, 4).permute(0, 2, 3, 1, 4).contiguous()
-        dgf = torch.empty(2 * ((B + 15) // 16) * 16 * 4 * H, device=x.device, dtype=x.dtype)
+        dgf = torch.empty(2 * ((B + 15) // 16) * 16 * 4 * H, device=x.device, dtype=torch.float32)
         _lib.check(lib.cfm_lstm_bwd_frag_f32(dy.data_ptr(), gates.data_ptr(), cells.data_ptr(), wtf.data_ptr(), _p(lengths),
                                              dG.data_ptr(), dc.data_ptr(), dgf.data_ptr(), B, T, H, _stream()),
                    "cfm_lstm_bwd_frag_f32")
@@ -1044,7 +1125,7 @@ def lstm_backward(x, w_ih, w_hh, y, gates, cells, dy, lengths=None, need_dx: boo
         _lib.check(lib.cfm_lstm_bwd_f32(dy.data_ptr(), gates.data_ptr(), cells.data_ptr(), whh_t.data_ptr(), _p(lengths),
                                         dG.data_ptr(), dc.data_ptr(), B, T, H, _stream()), "cfm_lstm_bwd_f32")
     dG2, x2 = dG.view(B * T, 4 * H), x.reshape(B * T, D)
-    h_prev = torch.zeros_like(y)                                      # h_{t-1}: y shifted by one frame per utterance
+    h_prev = torch.zeros(y.shape, device=y.device, dtype=torch.float32)                                      # h_{t-1}: y shifted by one frame per utterance
     h_prev[:, 1:] = y[:, :-1]
     dx = gemm_bwd(dG2, False, w_ih, True, B * T, D, 4 * H, prec=prec).view(B, T, D) if need_dx else None
     dw_ih, dw_hh, db = _zeros_split(x.device, x.dtype, (4 * H, D), (4 * H, H), (4 * H,))
@@ -1058,8 +1139,8 @@ def swish_bn_batch_stats(h, running_mean, running_var, momentum: float = 0.1):
     """Train-mode BatchNorm statistics of swish(h) over all rows; updates the running buffers in place."""
     h = _req(h, "h")
     C = h.shape[-1]
-    mean = torch.empty(C, device=h.device, dtype=h.dtype)
-    var = torch.empty(C, device=h.device, dtype=h.dtype)
+    mean = torch.empty(C, device=h.device, dtype=torch.float32)
+    var = torch.empty(C, device=h.device, dtype=torch.float32)
     _lib.check(_lib.load().cfm_swish_bn_stats_f32(h.data_ptr(), mean.data_ptr(), var.data_ptr(), _p(running_mean),
                                                   _p(running_var), momentum, h.numel() // C, C, _stream()),
                "cfm_swish_bn_stats_f32")
@@ -1070,7 +1151,7 @@ def swish_bn_bwd(h, dz, bn_mean, bn_var, bn_weight, eps: float = 1e-5, train_sta
     """Returns (dh, dgamma, dbeta)."""
     h = _req(h, "h"); dz = _req(dz, "dz")
     C = h.shape[-1]
-    dh = torch.empty_like(h)
+    dh = _f32_like(h)
     dga, dbe = _zeros_split(h.device, h.dtype, (C,), (C,))
     _lib.check(_lib.load().cfm_swish_bn_bwd_f32(h.data_ptr(), dz.data_ptr(), bn_mean.data_ptr(), bn_var.data_ptr(),
                                                 bn_weight.data_ptr(), eps, int(train_stats), dh.data_ptr(), dga.data_ptr(),
@@ -1125,7 +1206,7 @@ def ctc_loss_backward(ctx, grad_out):
     logits, targets, off, stride, in_len, tg_len, lmax, blank, ws = ctx
     B, T, V = logits.shape
     g = _req(grad_out.reshape(1), "grad_out")
-    dlogits = torch.empty_like(logits)
+    dlogits = _f32_like(logits)
     _lib.check(_lib.load().cfm_ctc_loss_bwd_f32(logits.data_ptr(), targets.data_ptr(), _p(off), stride, targets.numel(),
                                                 in_len.data_ptr(), tg_len.data_ptr(), B, T, V, lmax, blank, ws.data_ptr(),
                                                 g.data_ptr(), dlogits.data_ptr(), _stream()), "cfm_ctc_loss_bwd_f32")

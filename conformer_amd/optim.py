@@ -61,8 +61,8 @@ class FusedAdam(torch.optim.Optimizer):
                 st = self.state[p]
                 if not st:
                     st["step"] = torch.tensor(0.0)
-                    st["exp_avg"] = torch.zeros_like(p)
-                    st["exp_avg_sq"] = torch.zeros_like(p)
+                    st["exp_avg"] = torch.zeros(p.shape, device=p.device, dtype=torch.float32)
+                    st["exp_avg_sq"] = torch.zeros(p.shape, device=p.device, dtype=torch.float32)
             # all parameters of a group step together
             if gi not in self._steps:
                 self._steps[gi] = int(self.state[plist[0]]["step"])

@@ -36,7 +36,10 @@ enum cfm_status {
 };
 
 /* ---- library ------------------------------------------------------------------------------- */
-int cfm_version(void);                  /* ABI version, currently 1 */
+int cfm_version(void);                  /* library version, currently 1 */
+int cfm_abi_version(void);              /* CFM_ABI_VERSION this library was built against: bumped whenever an entry point's
+                                           argument list changes or an entry point is removed; a binding refuses a mismatch */
+#define CFM_ABI_VERSION 3
 const char* cfm_strerror(int status);   /* static string */
 int cfm_device_check(void);             /* CFM_OK iff the current HIP device is gfx950 */
 
@@ -70,6 +73,28 @@ int cfm_gemm_bias_glu_f32(const float* A, const float* W, const float* bias, flo
 int cfm_gemm_bias_residual_f32(const float* A, const float* W, const float* bias, const float* R,
                                float alpha, float* C, int64_t M, int N, int K,
                                int64_t lda, int64_t ldr, int64_t ldc, cfm_stream_t stream);
+
+/* ---- LayerNorm folded into the GEMMs either side of it (inference, fp32 MFMA): the LayerNorms in front of the FFN, the
+ *      attention projections and pointwise_conv_1 (ffn.py:16, attention.py:15, convolution.py:22) leave the launch list.
+ *      Producer side: the GEMM (or LayerNorm) that WRITES a residual-stream row also writes its statistics partials,
+ *        stats[row][part] = (sum, M2 about the partial's own mean) of `d / parts` consecutive stored values:
+ *        cfm_gemm_bias_stats_f32 / cfm_gemm_bias_residual_stats_f32: one partial per 32 columns (N % 32 == 0, stats (M, N/32, 2));
+ *        cfm_layernorm_fwd_stats_f32 (block.py:27 followed by the next block's ffn.py:16): one partial per row of its OUTPUT.
+ *      Consumer side: cfm_gemm_lnfold_f32 computes epi(LN(A).W^T + b) from the UN-normalised A as
+ *        rstd * (A.Wf^T - mean * colsum) + bias_f with Wf = W.diag(gamma), bias_f = b + W.beta, colsum[n] = sum_k Wf[n,k]
+ *        (folded once per weight version by the caller); mean / rstd are merged from the partials (Chan's formula, fixed
+ *        order) by each workgroup for its rows.  epi: 0 bias | 1 +swish | 3 +GLU (N = n_out; Wf, bias_f, colsum have 2N
+ *        rows: values then gates).  ln_parts <= 16, K % ln_parts == 0; N, ldc % 4 == 0; 16-byte aligned C / bias_f / colsum. */
+int cfm_gemm_bias_stats_f32(const float* A, const float* W, const float* bias, float* C, float* stats_out,
+                            int64_t M, int N, int K, int64_t lda, int64_t ldc, cfm_stream_t stream);
+int cfm_gemm_bias_residual_stats_f32(const float* A, const float* W, const float* bias, const float* R,
+                                     float alpha, float* C, float* stats_out, int64_t M, int N, int K,
+                                     int64_t lda, int64_t ldr, int64_t ldc, cfm_stream_t stream);
+int cfm_gemm_lnfold_f32(int epi, const float* A, const float* ln_stats, int ln_parts, float ln_eps,
+                        const float* Wf, const float* bias_f, const float* colsum, float* C,
+                        int64_t M, int N, int K, int64_t lda, int64_t ldc, cfm_stream_t stream);
+int cfm_layernorm_fwd_stats_f32(const float* x, const float* gamma, const float* beta, float* y,
+                                float* stats_out, int64_t rows, int d, float eps, cfm_stream_t stream);
 
 /* ---- relative positional encoding table (RelativePositionalEncoding.forward, position.py:11-27,
  *      WITHOUT the batch repeat of position.py:26).  pe: (2T-1, d); row j encodes r = T-1-j:

@@ -60,3 +60,17 @@ def test_dropout_seeds_are_per_rank_and_leave_the_default_generator_alone(monkey
     ops._SEED_GEN.clear()
     assert ops.new_seeds(4) == s0                               # torch.manual_seed still reproduces a run
     assert ops.new_seeds(4) != s0                               # and the stream advances from step to step
+
+
+def test_kernel_outputs_state_their_dtype():
+    """no kernel-output buffer inherits an input's dtype (`empty_like` / `zeros_like`): the C ABI takes
+    raw pointers, so a 16-bit input would silently halve an fp32 output's allocation."""
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pat = re.compile(r"torch\.(empty|zeros|ones)_like\(")
+    for rel in ("ops.py", "autograd.py", "streaming.py", "frontend.py", "decode.py", "optim.py", "evaluation.py", "pipeline.py",
+                "graph.py"):
+        src = open(os.path.join(root, "conformer_amd", rel)).read()
+        code = "\n".join(line.split("#", 1)[0] for line in src.splitlines())
+        assert not pat.search(code), f"conformer_amd/{rel} allocates an output with *_like"

@@ -298,3 +298,45 @@ def test_attention_16bit_projections_and_context_in_inference(dev, dt16):
     assert torch.equal(c_b, c_a.to(dt16))
     assert torch.isfinite(got).all() and torch.equal(got, want)
     assert rel_l2(c_a, c_0) < (6e-3 if dt16 == torch.bfloat16 else 1e-3)
+
+
+@pytest.mark.parametrize("dt16", DT)
+@pytest.mark.parametrize("d,H", [(100, 5), (36, 1), (20, 1)])
+def test_autocast_backward_at_d_not_multiple_of_8(dev, d, H, dt16):
+    """d % 8 == 4: producers must not hand a 16-bit gradient to a consumer whose aligned 16-bit kernels do
+    not cover its shape.  A block's autocast training step runs and its gradients track the fp32 path's (3e-2: bf16 drift)."""
+    from model.utils.block import ConformerBlock
+    from model.utils.position import RelativePositionalEncoding
+    P = O.make_params(vocab=8, n_mel=80, n_blocks=1, d=d, n_heads=H, ksize=7, lstm_hidden=8, seed=9, with_decoder=False)
+    blk = "encoder.layers.0."
+    m = ConformerBlock(d, H, 7).to(dev).eval()
+    m.load_state_dict({k[len(blk):]: v for k, v in P.items() if k.startswith(blk)})
+    x = rnd(2, 33, d, seed=4).to(dev)
+    L = torch.tensor([33, 20], device=dev)
+    table = RelativePositionalEncoding(d).to(dev).table(33)
+    grads = {}
+    for name, amp in (("f32", None), ("amp", dt16)):
+        m.zero_grad(set_to_none=True)
+        xi = x.clone().requires_grad_(True)
+        import contextlib
+        with (torch.autocast("cuda", dtype=amp) if amp else contextlib.nullcontext()):
+            y = m.fused(xi, table, L)
+        (y.float() * torch.cos(torch.arange(y.numel(), device=dev).view_as(y) * 0.1)).sum().backward()
+        grads[name] = {"x": xi.grad.clone(), **{n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}}
+    assert len(grads["amp"]) == len(grads["f32"]) > 30
+    for n, gref in grads["f32"].items():
+        if float(gref.norm()) < 1e-3:
+            continue                                   # (zero-by-construction gradients: graded elsewhere in absolute terms)
+        assert rel_l2(grads["amp"][n], gref) < (3e-2 if dt16 == torch.bfloat16 else 8e-3), n
+
+
+def test_training_attention_refuses_16bit_projections(dev):
+    """relpos_attention_train reads fp32 q|k|v (a 16-bit tensor used to slip through to fp32 kernels)."""
+    from conformer_amd import ops
+    from conformer_amd._lib import ConformerHipError
+    qkv = rnd(2, 9, 3 * 32, seed=1).to(dev)
+    pos, u, v = rnd(17, 32, seed=2).to(dev), rnd(4, 8, seed=3).to(dev), rnd(4, 8, seed=4).to(dev)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        ops.relpos_attention_train(qkv, pos, u, v, None, 4)
+        with pytest.raises(ConformerHipError):
+            ops.relpos_attention_train(qkv.to(torch.bfloat16), pos, u, v, None, 4)
