@@ -223,12 +223,24 @@ def selftest_cpu(args, env):
     from conformer_amd import parallel
     import torch.distributed as dist
     started = parallel.init_distributed(env, torch.device("cpu"), backend="gloo")
-    a = torch.ones(64, 64)
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(64, 64), torch.nn.Tanh(), torch.nn.Linear(64, 8))
+    ddp = parallel.wrap_ddp(net, None, args.bucket_cap_mb, args.gradient_as_bucket_view, args.static_graph)
+    probe = parallel.DdpCommProbe(ddp)
+    a = torch.ones(16, 64) * (1 + env.rank)
+    step_ms = []
 
     def step():
-        (a @ a).sum().item()
+        t0 = time.perf_counter()
+        probe.begin_step()
+        net.zero_grad(set_to_none=True)
+        ddp(a).pow(2).mean().backward()
+        step_ms.append((time.perf_counter() - t0) * 1e3)
 
     dt = parallel.timed_steps(step, args.steps, args.warmup, lambda: None)
+    comm = probe.summary(skip=args.warmup)
+    per_rank = parallel.gather_to_rank0(sum(step_ms[args.warmup:]) / max(1, args.steps))
+    comms = parallel.gather_to_rank0(comm)
     ranks = dist.get_world_size() if started else 1
     seen = torch.zeros(ranks, dtype=torch.int64)
     seen[env.rank] = 1 + env.local_rank
@@ -239,10 +251,24 @@ def selftest_cpu(args, env):
                           "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
                           "scaling": "weak", "vs_baseline": None, "dtype": "none", "data": "plumbing-selftest (no kernels)",
                           "ranks": ranks, "collective_backend": "gloo" if started else None,
-                          "local_ranks_plus_one": seen.tolist(), "config": {"workload": "none"}}), flush=True)
+                          "local_ranks_plus_one": seen.tolist(), "config": {"workload": "none"},
+                          **comm_fields(comms, per_rank, args)}), flush=True)
     if started:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def comm_fields(comms, per_rank_step_ms, args):
+    """The data-parallel part of the --train JSON line: what the gradient exchange cost (DdpCommProbe; worst rank), what every
+    rank's step took, and DDP's settings -- so that the first multi-GPU run explains itself."""
+    vals = [c["exposed_comm_ms"] for c in comms if c.get("exposed_comm_ms") is not None]
+    spans = [c["comm_span_ms"] for c in comms if c.get("comm_span_ms") is not None]
+    return {"exposed_comm_ms": max(vals) if vals else None, "comm_span_ms": max(spans) if spans else None,
+            "exposed_comm_ms_per_rank": [c.get("exposed_comm_ms") for c in comms],
+            "allreduce_bytes_per_step": comms[0]["allreduce_bytes_per_step"], "allreduce_buckets": comms[0]["allreduce_buckets"],
+            "per_rank_step_ms": [round(float(v), 4) for v in per_rank_step_ms],
+            "ddp": {"bucket_cap_mb": args.bucket_cap_mb, "gradient_as_bucket_view": bool(args.gradient_as_bucket_view),
+                    "static_graph": bool(args.static_graph)}}
 
 
 def train_bench(args, env, dev, dist):
@@ -257,7 +283,8 @@ def train_bench(args, env, dev, dist):
     B, T = 64, CFG["T"]
     torch.manual_seed(0)
     model = Conformer(370, CFG["n_mel"], CFG["n_blocks"], CFG["d"], CFG["n_heads"], CFG["ksize"], 640, 1, args.dropout).to(dev).train()
-    ddp = parallel.wrap_ddp(model, dev)
+    ddp = parallel.wrap_ddp(model, dev, args.bucket_cap_mb, args.gradient_as_bucket_view, args.static_graph)
+    probe = parallel.DdpCommProbe(ddp)       # the default exchange (divide + all-reduce per bucket), time-stamped
     opt = FusedAdam(model.parameters(), lr=2e-5)
     g = torch.Generator().manual_seed(100 + env.rank)
     x = torch.randn(B, CFG["n_mel"], T, generator=g).to(dev)
@@ -266,8 +293,12 @@ def train_bench(args, env, dev, dist):
     tlen = torch.full((B,), 40, dtype=torch.int64, device=dev)
     crit = ConformerCriterion(blank_id=0)
     last = {}
+    marks = []                                # one HIP event per step start (+ one at the end): per-rank step times, no syncs
 
     def step():
+        marks.append(torch.cuda.Event(enable_timing=True))
+        marks[-1].record()
+        probe.begin_step()
         with torch.autocast("cuda", dtype=torch.bfloat16):
             logits, out_len = ddp(x, lengths)
             with torch.autocast("cuda", enabled=False):
@@ -278,6 +309,12 @@ def train_bench(args, env, dev, dist):
         last["loss"] = loss
 
     dt = parallel.timed_steps(step, args.steps, args.warmup, torch.cuda.synchronize, dev)
+    marks.append(torch.cuda.Event(enable_timing=True))
+    marks[-1].record()
+    torch.cuda.synchronize()
+    mine = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.warmup, args.warmup + args.steps)]
+    per_rank = parallel.gather_to_rank0(sum(mine) / len(mine))
+    comms = parallel.gather_to_rank0(probe.summary(skip=args.warmup))
     loss = float(last["loss"])
     if not loss == loss:
         raise SystemExit("non-finite training loss")
@@ -293,6 +330,7 @@ def train_bench(args, env, dev, dist):
             "config": {"workload": "cfg3/cfg4 Conformer-L training step: per-GPU B=64, T=1000 mel frames, 40 target tokens, "
                                    f"dropout {args.dropout}, BatchNorm train, CTC fp32, FusedAdam, DDP gradient all-reduce",
                        "per_gpu_batch": B, "global_batch": B * env.world, "mel_frames": T},
+            **comm_fields(comms, per_rank, args),
             "encoder_fwd_bwd_tflops": 3 * fwd / (ms * 1e-3) / 1e12, "loss": loss,
             "max_mem_gib": torch.cuda.max_memory_allocated() / 2 ** 30}), flush=True)
     if dist:
@@ -307,6 +345,9 @@ def main():
                     help="BASELINE cfg-3 (1 GPU) / cfg-4 (N GPUs): Conformer-L training step under bf16 autocast, B=64 per GPU, "
                          "forward + CTC + backward + Adam, gradients all-reduced by DDP over RCCL")
     ap.add_argument("--dropout", type=float, default=0.1, help="--train only (train.py default 0.1)")
+    ap.add_argument("--bucket-cap-mb", type=int, default=25, help="--train: DDP bucket size (train.py:186 uses the default 25)")
+    ap.add_argument("--gradient-as-bucket-view", action="store_true", help="--train: DDP gradient_as_bucket_view")
+    ap.add_argument("--static-graph", action="store_true", help="--train: DDP static_graph")
     ap.add_argument("--selftest-cpu", action="store_true",
                     help="plumbing test only (tests/test_parallel_cpu.py): ranks rendezvous over gloo on the CPU and time a "
                          "no-kernel step; the JSON line says so and carries value 0")

@@ -29,9 +29,19 @@ namespace {
 //   LN == 1, consumer: A is the UN-normalised row, W / bias are the folded W.diag(gamma) / b + W.beta; a prologue merges the
 //            partials of the tile's rows into (mean, rstd) in LDS (Chan's formula, fixed order) while the first K-tiles are
 //            in flight and the epilogue applies rstd * (acc - mean * colsum).  The K-loop is untouched.
-template <int BM, int BN, int EPI, bool CONV, int LN = 0>
-__global__ __launch_bounds__(256, (BM == 128 && BN == 128) ? 3 : 4) void gemm_f32_kernel(const GemmArgs g) {
-    constexpr int TM = BM / 64, TN = BN / 64, BK = 16, LDSR = BK + 4;   // 80-byte rows: conflict-free b128 reads
+// BK = 16: the round-1/2 loop (two register staging sets, loads two K-tiles ahead).  BK = 32 (round 3): a K-tile row is a whole
+// 128-byte cache line -- with BK = 16 every wave-level staging load touches 16 half lines and the two halves of a line are
+// fetched by different instructions a K-tile apart (L1 is 32 KB per CU: the line is usually gone, so L2 serves it twice) --
+// one register staging set, loads one (twice as deep) K-tile ahead, one barrier per 32 contraction steps; 144-byte LDS rows.
+// F: epilogue flags (gemm_shared.h EPF_*): the LN-fold role, and what the epilogue does NOT need to carry -- the inference entry
+// points compile the dropout mask generation and the 16-bit-output paths out (a bias / Swish / residual kernel was 46-58 KB of
+// code, 2.4x its ReLU sibling, almost all of it epilogue that runs once per tile and is fetched cold).
+template <int BM, int BN, int EPI, bool CONV, int F = 0, int BK = 16>
+__global__ __launch_bounds__(256, (BM == 128 && BN == 128) ? (BK == 32 ? 2 : 3) : (BK == 32 && BM + BN > 128 ? 2 : 4))
+void gemm_f32_kernel(const GemmArgs g) {
+    static_assert(BK == 16 || BK == 32, "K-tile 16 or 32");
+    constexpr int LN = F & EPF_LN_MASK;
+    constexpr int TM = BM / 64, TN = BN / 64, LDSR = BK + 4;   // 80- / 144-byte rows: conflict-free ds_read_b128
     static_assert(EPI != EPI_GLU || TN == 2, "GLU keeps value and gate tiles in one wave");
     // staging double buffer; the row-major epilogue re-uses it as 4 per-wave transposition tiles (a little larger for the 64x128 tile)
     constexpr int LDS_STAGE = 2 * (BM + BN) * LDSR, LDS_EPI = 4 * 32 * (32 * TN + 4);
@@ -59,34 +69,35 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 128) ? 3 : 4) void gemm_f3
     }
 
     // ---- staging assignment: thread -> (row, 16-byte chunk) for TM rows of A and TN rows of W
-    const int chunk = tid & 3, srow = tid >> 2;
-    const float* a_ptr[TM];
-    const float* w_ptr[TN];
+    constexpr int CPR = BK / 4, RPP = 256 / CPR, PA = BM / RPP, PB = BN / RPP;   // chunks per row, rows per pass, passes per operand
+    const int chunk = tid & (CPR - 1), srow = tid / CPR;
+    const float* a_ptr[PA];
+    const float* w_ptr[PB];
 #pragma unroll
-    for (int i = 0; i < TM; ++i) a_ptr[i] = a_row_ptr<CONV>(g, m0 + srow + 64 * i);
+    for (int i = 0; i < PA; ++i) a_ptr[i] = a_row_ptr<CONV>(g, m0 + srow + RPP * i);
 #pragma unroll
-    for (int i = 0; i < TN; ++i) w_ptr[i] = w_row_ptr<EPI, BN>(g, n0, srow + 64 * i);
+    for (int i = 0; i < PB; ++i) w_ptr[i] = w_row_ptr<EPI, BN>(g, n0, srow + RPP * i);
 
     const int nkt = (g.K + BK - 1) / BK;
-    f32x4 ra0[TM], rb0[TN], ra1[TM], rb1[TN];          // two staging sets: tiles t+1 and t+2 in flight
-    auto load_tile = [&](f32x4 (&ra)[TM], f32x4 (&rb)[TN], int kt) {
+    f32x4 ra0[PA], rb0[PB], ra1[BK == 16 ? PA : 1], rb1[BK == 16 ? PB : 1];   // BK = 16: two staging sets (tiles t+1 and t+2 in flight)
+    auto load_tile = [&](auto& ra, auto& rb, int kt) {
         const int k = kt * BK + chunk * 4;
         const int64_t aoff = a_k_offset<CONV>(g, kt * BK) + chunk * 4;
         const bool ok = k < g.K;
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+        for (int i = 0; i < PA; ++i)
             ra[i] = ok ? *reinterpret_cast<const f32x4*>(a_ptr[i] + aoff) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int i = 0; i < TN; ++i)
+        for (int i = 0; i < PB; ++i)
             rb[i] = ok ? *reinterpret_cast<const f32x4*>(w_ptr[i] + k) : f32x4{0.f, 0.f, 0.f, 0.f};
     };
-    auto store_tile = [&](const f32x4 (&ra)[TM], const f32x4 (&rb)[TN], int buf) {
+    auto store_tile = [&](const auto& ra, const auto& rb, int buf) {
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
-            *reinterpret_cast<f32x4*>(As + (buf * BM + srow + 64 * i) * LDSR + chunk * 4) = ra[i];
+        for (int i = 0; i < PA; ++i)
+            *reinterpret_cast<f32x4*>(As + (buf * BM + srow + RPP * i) * LDSR + chunk * 4) = ra[i];
 #pragma unroll
-        for (int i = 0; i < TN; ++i)
-            *reinterpret_cast<f32x4*>(Bs + (buf * BN + srow + 64 * i) * LDSR + chunk * 4) = rb[i];
+        for (int i = 0; i < PB; ++i)
+            *reinterpret_cast<f32x4*>(Bs + (buf * BN + srow + RPP * i) * LDSR + chunk * 4) = rb[i];
     };
 
     f32x16 acc[TM][TN];
@@ -108,43 +119,92 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 128) ? 3 : 4) void gemm_f3
             fb[t] = *reinterpret_cast<const f32x4*>(Bs + (buf * BN + b_row + 32 * t) * LDSR + 8 * c + 4 * hf);
     };
 
-    // LN == 1: the statistics partials of this tile's rows are requested FIRST (their wait then leaves the K-tile loads in
-    // flight); thread r < BM owns row m0 + r; at most 16 partials per row (d <= 512 at 32 columns per partial)
-    [[maybe_unused]] float2 lnp[LN == 1 ? 16 : 1];
+    // LN == 1: the statistics partials of this tile's BM rows are ONE contiguous block of stats (BM * parts * 8 bytes): it is
+    // requested FIRST with coalesced 16-byte loads (two partials each; at most 4 per thread) so that its wait leaves the K-tile
+    // loads in flight.  (First version: thread r read the 16 partials of row r with 16 eight-byte loads -- 64 cache lines per
+    // wave instruction: +5.5 us on every consumer GEMM, as much as the LayerNorm launch it replaced.)
+    constexpr int LN_NL = (BM * 16 / 2 + 255) / 256;                   // float4 loads per thread at 16 partials per row
+    [[maybe_unused]] f32x4 lnq[LN == 1 ? LN_NL : 1];
+    [[maybe_unused]] float2 ln1 = {0.f, 0.f};
     if constexpr (LN == 1) {
-        // (every thread loads -- threads >= BM repeat a row: a load inside a divergent block would make the compiler's wait
-        // bookkeeping drain the K-tile prefetch at the join)
-        const float2* sp = reinterpret_cast<const float2*>(g.ln_stats) + min(m0 + (tid & (BM - 1)), g.M - 1) * g.ln_parts;
+        const int64_t rows_here = min((int64_t)BM, g.M - m0);          // (the last row tile is ragged: clamp inside the block)
+        if (g.ln_parts >= 2) {
+            const int nf4 = (int)rows_here * (g.ln_parts >> 1);
+            const f32x4* sp = reinterpret_cast<const f32x4*>(g.ln_stats + m0 * g.ln_parts * 2);
 #pragma unroll
-        for (int i = 0; i < 16; ++i) lnp[i] = sp[i < g.ln_parts ? i : 0];
+            for (int i = 0; i < LN_NL; ++i) lnq[i] = sp[min(tid + 256 * i, nf4 - 1)];
+        } else {
+            ln1 = reinterpret_cast<const float2*>(g.ln_stats)[m0 + min((int64_t)tid, rows_here - 1)];
+        }
     }
     load_tile(ra0, rb0, 0);
     store_tile(ra0, rb0, 0);
-    if (nkt > 1) load_tile(ra1, rb1, 1);
-    if (nkt > 2) load_tile(ra0, rb0, 2);
+    if constexpr (BK == 16) {
+        if (nkt > 1) load_tile(ra1, rb1, 1);
+        if (nkt > 2) load_tile(ra0, rb0, 2);
+    } else {
+        if (nkt > 1) load_tile(ra0, rb0, 1);
+    }
     if constexpr (LN == 1) {
-        {
-            // Chan's merge of equal-sized partials in a fixed order: after i+1 partials the running count is (i+1)*ni
-            const float ni = (float)(g.K / g.ln_parts), inv_ni = 1.0f / ni;
-            float mean = lnp[0].x * inv_ni, m2 = lnp[0].y;
+        // Merge (Chan, equal counts at every level, fixed tree order): a float4 holds two partials of ni = K / parts values; the
+        // parts / 2 consecutive lanes that hold one row's float4s combine with xor-shuffles; the group's first lane writes
+        // (mean, rstd).  parts is a power of two <= 16 (checked by the entry point).
+        const float ni = (float)(g.K / g.ln_parts), inv_ni = 1.0f / ni, inv_k = 1.0f / (float)g.K;
+        if (g.ln_parts >= 2) {
+            const int lpr = g.ln_parts >> 1;                             // lanes per row: 1, 2, 4 or 8
 #pragma unroll
-            for (int i = 1; i < 16; ++i) {
-                if (i < g.ln_parts) {
-                    const float delta = lnp[i].x * inv_ni - mean;
-                    mean += delta * (1.0f / (float)(i + 1));
-                    m2 += lnp[i].y + delta * delta * (ni * (float)i / (float)(i + 1));
+            for (int i = 0; i < LN_NL; ++i) {
+                const float ma = lnq[i][0] * inv_ni, mb = lnq[i][2] * inv_ni, d0 = mb - ma;
+                float mean = 0.5f * (ma + mb), m2 = lnq[i][1] + lnq[i][3] + d0 * d0 * (0.5f * ni), cnt = 2.0f * ni;
+                for (int st = 1; st < lpr; st <<= 1) {                    // (kernel-uniform trip count)
+                    const float mo = __shfl_xor(mean, st, 64), m2o = __shfl_xor(m2, st, 64), dl = mo - mean;
+                    mean = 0.5f * (mean + mo);
+                    m2 = m2 + m2o + dl * dl * (0.5f * cnt);
+                    cnt *= 2.0f;
+                }
+                const int f = tid + 256 * i, row = f / lpr;
+                if ((f & (lpr - 1)) == 0 && row < BM) {
+                    rowstats[2 * row] = mean;
+                    rowstats[2 * row + 1] = 1.0f / sqrtf(m2 * inv_k + g.ln_eps);
                 }
             }
-            const float var = m2 / (float)g.K;
-            if (tid < BM) {
-                rowstats[2 * tid] = mean;
-                rowstats[2 * tid + 1] = 1.0f / sqrtf(var + g.ln_eps);
-            }
+        } else if (tid < BM) {
+            rowstats[2 * tid] = ln1.x * inv_k;
+            rowstats[2 * tid + 1] = 1.0f / sqrtf(ln1.y * inv_k + g.ln_eps);
         }
     }
     __syncthreads();
     read_frags(fa0, fb0, 0, 0);
-    auto k_step = [&](int kt, f32x4 (&ra)[TM], f32x4 (&rb)[TN]) {   // (ra, rb) holds tile kt+1 on entry
+    if constexpr (BK == 32) {
+        // four 8-deep slices per K-tile, fragments of slice s+1 in flight from LDS under the MFMAs of slice s; the staged registers
+        // (tile kt+1) go to the other LDS buffer behind slice 2 and are re-loaded with tile kt+2 at once
+        for (int kt = 0; kt < nkt; ++kt) {
+            const int cur = kt & 1;
+            const bool more = kt + 1 < nkt;
+            read_frags(fa1, fb1, cur, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            GEMM_MFMA_SLICE(fa0, fb0);
+            __builtin_amdgcn_sched_barrier(0);
+            read_frags(fa0, fb0, cur, 2);
+            __builtin_amdgcn_sched_barrier(0);
+            GEMM_MFMA_SLICE(fa1, fb1);
+            __builtin_amdgcn_sched_barrier(0);
+            read_frags(fa1, fb1, cur, 3);
+            __builtin_amdgcn_sched_barrier(0);
+            GEMM_MFMA_SLICE(fa0, fb0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (more) {
+                store_tile(ra0, rb0, cur ^ 1);
+                if (kt + 2 < nkt) load_tile(ra0, rb0, kt + 2);
+            }
+            __syncthreads();
+            if (more) read_frags(fa0, fb0, cur ^ 1, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            GEMM_MFMA_SLICE(fa1, fb1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    auto k_step = [&](int kt, auto& ra, auto& rb) {   // (ra, rb) holds tile kt+1 on entry
         const int cur = kt & 1;
         const bool more = kt + 1 < nkt;
         read_frags(fa1, fb1, cur, 1);
@@ -161,21 +221,23 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 128) ? 3 : 4) void gemm_f3
         GEMM_MFMA_SLICE(fa1, fb1);
         __builtin_amdgcn_sched_barrier(0);
     };
-    int kt = 0;
-    for (; kt + 1 < nkt; kt += 2) {
-        k_step(kt, ra1, rb1);
-        k_step(kt + 1, ra0, rb0);
+    if constexpr (BK == 16) {
+        int kt = 0;
+        for (; kt + 1 < nkt; kt += 2) {
+            k_step(kt, ra1, rb1);
+            k_step(kt + 1, ra0, rb0);
+        }
+        if (kt < nkt) k_step(kt, ra1, rb1);
     }
-    if (kt < nkt) k_step(kt, ra1, rb1);
     if (g.trace && tid == 0) g.trace[8 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();   // main loop done
 
     // row-major write-out through a per-wave LDS tile (whole 256-byte row segments per store instruction) where the dead
     // staging buffers can hold it; the GLU tile pairs value and gate columns in one wave and stores straight from the accumulators
     if constexpr (ROWS) {
         __syncthreads();                                   // every wave is done reading the staging buffers
-        gemm_epilogue_rows<BM, BN, EPI, TM, TN, 2, false, LN>(g, acc, m0, n0, wr, wc, lane, lds + wave * 32 * (32 * TN + 4), rowstats);
+        gemm_epilogue_rows<BM, BN, EPI, TM, TN, 2, false, F>(g, acc, m0, n0, wr, wc, lane, lds + wave * 32 * (32 * TN + 4), rowstats);
     } else {
-        gemm_epilogue<BM, BN, EPI, TM, TN>(g, acc, m0, n0, wr, wc, li, hf);
+        gemm_epilogue<BM, BN, EPI, TM, TN, F>(g, acc, m0, n0, wr, wc, li, hf);
     }
     if (g.trace && tid == 0) {
         g.trace[8 * blockIdx.x + 4] = __builtin_amdgcn_s_memrealtime();                        // epilogue issued
@@ -202,7 +264,7 @@ inline int choose_tile(int64_t M, int ncols, bool glu, int K) {
     return 3;
 }
 
-template <int BM, int BN, int EPI, bool CONV, int LN = 0>
+template <int BM, int BN, int EPI, bool CONV, int LN = 0, int BK = 16>
 int launch_cfg(GemmArgs g, hipStream_t s) {
     const int ncols = EPI == EPI_GLU ? g.n_out : g.N;
     const int bn = EPI == EPI_GLU ? BN / 2 : BN;
@@ -210,28 +272,29 @@ int launch_cfg(GemmArgs g, hipStream_t s) {
     g.tiles_n = (unsigned)((ncols + bn - 1) / bn);
     // Occupancy control: a CU has 160 KiB of LDS; asking for extra (unused) dynamic LDS caps the resident blocks per
     // CU so that tiles / (256 * blocks_per_CU) lands just under an integer number of rounds (no half-empty last round).
-    constexpr int kStatic = 2 * (BM + BN) * 20 * 4;
+    constexpr int kStatic = 2 * (BM + BN) * (BK + 4) * 4;
     size_t pad = 0;
     if (g.occ_cap > 0) {
         const int per = (160 * 1024) / g.occ_cap;
         pad = per > kStatic ? (size_t)((per - kStatic) & ~255) : 0;
     }
-    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, EPI, CONV, LN>), dim3(g.tiles_m * g.tiles_n), dim3(256), pad, s, g);
+    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, EPI, CONV, LN, BK>), dim3(g.tiles_m * g.tiles_n), dim3(256), pad, s, g);
     return cfm_launch_status();
 }
 
-template <int EPI, bool CONV, int LN = 0>
+// (BK = 32 is only reachable through cfm_debug_gemm_cfg_f32: measured slower at every hot-path shape but one)
+template <int EPI, bool CONV, int F = 0, int BK = 16>
 int launch(const GemmArgs& g, hipStream_t s, int force_cfg = -1) {
     const int ncols = EPI == EPI_GLU ? g.n_out : g.N;
     const int tile = force_cfg >= 0 ? force_cfg : choose_tile(g.M, ncols, EPI == EPI_GLU, g.K);
     if constexpr (EPI == EPI_GLU) {
-        return (tile == 0 || tile == 1) ? launch_cfg<128, 128, EPI, CONV, LN>(g, s) : launch_cfg<64, 128, EPI, CONV, LN>(g, s);
+        return (tile == 0 || tile == 1) ? launch_cfg<128, 128, EPI, CONV, F, BK>(g, s) : launch_cfg<64, 128, EPI, CONV, F, BK>(g, s);
     } else {
         switch (tile) {
-            case 0: return launch_cfg<128, 128, EPI, CONV, LN>(g, s);
-            case 1: return launch_cfg<128, 64, EPI, CONV, LN>(g, s);
-            case 2: return launch_cfg<64, 128, EPI, CONV, LN>(g, s);
-            default: return launch_cfg<64, 64, EPI, CONV, LN>(g, s);
+            case 0: return launch_cfg<128, 128, EPI, CONV, F, BK>(g, s);
+            case 1: return launch_cfg<128, 64, EPI, CONV, F, BK>(g, s);
+            case 2: return launch_cfg<64, 128, EPI, CONV, F, BK>(g, s);
+            default: return launch_cfg<64, 64, EPI, CONV, F, BK>(g, s);
         }
     }
 }
@@ -247,8 +310,9 @@ int check_ln(const GemmArgs& g, int ncols) {
     if (g.ln_stats) {
         CFM_REQUIRE(g.ln_colsum != nullptr, CFM_ERR_NULL);
         CFM_REQUIRE(g.ln_parts >= 1 && g.K % g.ln_parts == 0, CFM_ERR_BAD_SHAPE);
-        CFM_REQUIRE(g.ln_parts <= 16, CFM_ERR_UNSUPPORTED);
-        CFM_REQUIRE((reinterpret_cast<uintptr_t>(g.ln_stats) & 7u) == 0 && CFM_ALIGNED16(g.ln_colsum), CFM_ERR_ALIGN);
+        CFM_REQUIRE(g.ln_parts <= 16 && (g.ln_parts & (g.ln_parts - 1)) == 0, CFM_ERR_UNSUPPORTED);     // 1, 2, 4, 8, 16
+        CFM_REQUIRE((reinterpret_cast<uintptr_t>(g.ln_stats) & (g.ln_parts >= 2 ? 15u : 7u)) == 0 && CFM_ALIGNED16(g.ln_colsum),
+                    CFM_ERR_ALIGN);
     }
     return CFM_OK;
 }
@@ -272,7 +336,7 @@ extern "C" int cfm_gemm_bias_f32(const float* A, const float* W, const float* bi
     GEMM_ARGS_PLAIN(N);
     int st = check(g); if (st) return st;
     CFM_REQUIRE(ldc >= N, CFM_ERR_BAD_SHAPE);
-    return launch<EPI_BIAS, false>(g, static_cast<hipStream_t>(stream));
+    return launch<EPI_BIAS, false, EPF_INFER>(g, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int cfm_gemm_bias_swish_f32(const float* A, const float* W, const float* bias, float* C, int64_t M,
@@ -280,7 +344,7 @@ extern "C" int cfm_gemm_bias_swish_f32(const float* A, const float* W, const flo
     GEMM_ARGS_PLAIN(N);
     int st = check(g); if (st) return st;
     CFM_REQUIRE(ldc >= N, CFM_ERR_BAD_SHAPE);
-    return launch<EPI_SWISH, false>(g, static_cast<hipStream_t>(stream));
+    return launch<EPI_SWISH, false, EPF_INFER>(g, static_cast<hipStream_t>(stream));
 }
 
 // training forward of ffn.py:17-18: C = swish(Z), Z = A.W^T + bias is stored too (needed by swish' in the backward)
@@ -291,7 +355,7 @@ extern "C" int cfm_gemm_bias_swish_save_f32(const float* A, const float* W, cons
     int st = check(g); if (st) return st;
     CFM_REQUIRE(Z != nullptr, CFM_ERR_NULL);
     CFM_REQUIRE(ldc >= N, CFM_ERR_BAD_SHAPE);
-    return launch<EPI_SWISH, false>(g, static_cast<hipStream_t>(stream));
+    return launch<EPI_SWISH, false, EPF_INFER>(g, static_cast<hipStream_t>(stream));
 }
 
 // Training forward with dropout fused into the epilogue (element index = row*N + col, regenerated in the backward):
@@ -306,12 +370,13 @@ extern "C" int cfm_gemm_train_f32(int epi, const float* A, const float* W, const
     int st = check(g); if (st) return st;
     CFM_REQUIRE(ldc >= N && drop_p >= 0.f && drop_p < 1.f, CFM_ERR_BAD_SHAPE);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (epi == EPI_BIAS) return launch<EPI_BIAS, false>(g, s);
-    if (epi == EPI_SWISH) return launch<EPI_SWISH, false>(g, s);
+    // (the dropout-free instantiations are the inference kernels: a training step with p = 0 runs the same code as eval)
+    if (epi == EPI_BIAS) return drop_p > 0.f ? launch<EPI_BIAS, false, EPF_F32_OUT>(g, s) : launch<EPI_BIAS, false, EPF_INFER>(g, s);
+    if (epi == EPI_SWISH) return drop_p > 0.f ? launch<EPI_SWISH, false, EPF_F32_OUT>(g, s) : launch<EPI_SWISH, false, EPF_INFER>(g, s);
     if (epi == EPI_RESID) {
         CFM_REQUIRE(R_or_null != nullptr, CFM_ERR_NULL);
         CFM_REQUIRE(ldr >= N, CFM_ERR_BAD_SHAPE);
-        return launch<EPI_RESID, false>(g, s);
+        return drop_p > 0.f ? launch<EPI_RESID, false, EPF_F32_OUT>(g, s) : launch<EPI_RESID, false, EPF_INFER>(g, s);
     }
     return CFM_ERR_UNSUPPORTED;
 }
@@ -321,7 +386,7 @@ extern "C" int cfm_gemm_bias_relu_f32(const float* A, const float* W, const floa
     GEMM_ARGS_PLAIN(N);
     int st = check(g); if (st) return st;
     CFM_REQUIRE(ldc >= N, CFM_ERR_BAD_SHAPE);
-    return launch<EPI_RELU, false>(g, static_cast<hipStream_t>(stream));
+    return launch<EPI_RELU, false, EPF_INFER>(g, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int cfm_gemm_bias_glu_f32(const float* A, const float* W, const float* bias, float* C, int64_t M,
@@ -330,7 +395,7 @@ extern "C" int cfm_gemm_bias_glu_f32(const float* A, const float* W, const float
     g.n_out = n_out;
     int st = check(g); if (st) return st;
     CFM_REQUIRE(n_out > 0 && ldc >= n_out, CFM_ERR_BAD_SHAPE);
-    return launch<EPI_GLU, false>(g, static_cast<hipStream_t>(stream));
+    return launch<EPI_GLU, false, EPF_INFER>(g, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int cfm_gemm_bias_residual_f32(const float* A, const float* W, const float* bias, const float* R,
@@ -341,7 +406,7 @@ extern "C" int cfm_gemm_bias_residual_f32(const float* A, const float* W, const 
     int st = check(g); if (st) return st;
     CFM_REQUIRE(R != nullptr, CFM_ERR_NULL);
     CFM_REQUIRE(ldc >= N && ldr >= N, CFM_ERR_BAD_SHAPE);
-    return launch<EPI_RESID, false>(g, static_cast<hipStream_t>(stream));
+    return launch<EPI_RESID, false, EPF_INFER>(g, static_cast<hipStream_t>(stream));
 }
 
 // ---- LayerNorm folded into its neighbours (inference) ---------------------------------------------------------------
@@ -354,7 +419,7 @@ extern "C" int cfm_gemm_bias_stats_f32(const float* A, const float* W, const flo
     CFM_REQUIRE(stats_out != nullptr, CFM_ERR_NULL);
     CFM_REQUIRE(ldc >= N, CFM_ERR_BAD_SHAPE);
     st = check_ln(g, N); if (st) return st;
-    return launch<EPI_BIAS, false, 2>(g, static_cast<hipStream_t>(stream));
+    return launch<EPI_BIAS, false, EPF_INFER | EPF_LN_PRODUCE>(g, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int cfm_gemm_bias_residual_stats_f32(const float* A, const float* W, const float* bias, const float* R,
@@ -366,7 +431,7 @@ extern "C" int cfm_gemm_bias_residual_stats_f32(const float* A, const float* W, 
     CFM_REQUIRE(R != nullptr && stats_out != nullptr, CFM_ERR_NULL);
     CFM_REQUIRE(ldc >= N && ldr >= N, CFM_ERR_BAD_SHAPE);
     st = check_ln(g, N); if (st) return st;
-    return launch<EPI_RESID, false, 2>(g, static_cast<hipStream_t>(stream));
+    return launch<EPI_RESID, false, EPF_INFER | EPF_LN_PRODUCE>(g, static_cast<hipStream_t>(stream));
 }
 
 // consumer: C = epi(LN(A).W^T + b) computed from the UN-normalised A, its statistics partials and the folded parameters
@@ -383,9 +448,9 @@ extern "C" int cfm_gemm_lnfold_f32(int epi, const float* A, const float* ln_stat
     CFM_REQUIRE(N > 0 && ldc >= N && ln_eps >= 0.f, CFM_ERR_BAD_SHAPE);
     st = check_ln(g, N); if (st) return st;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (epi == EPI_BIAS) return launch<EPI_BIAS, false, 1>(g, s);
-    if (epi == EPI_SWISH) return launch<EPI_SWISH, false, 1>(g, s);
-    if (epi == EPI_GLU) return launch<EPI_GLU, false, 1>(g, s);
+    if (epi == EPI_BIAS) return launch<EPI_BIAS, false, EPF_INFER | EPF_LN_CONSUME>(g, s);
+    if (epi == EPI_SWISH) return launch<EPI_SWISH, false, EPF_INFER | EPF_LN_CONSUME>(g, s);
+    if (epi == EPI_GLU) return launch<EPI_GLU, false, EPF_INFER | EPF_LN_CONSUME>(g, s);
     return CFM_ERR_UNSUPPORTED;
 }
 
@@ -401,7 +466,7 @@ extern "C" int cfm_subsample_conv2_relu_f32(const float* h1, const float* w2p, c
     g.cT1 = T1; g.cF1 = F1; g.cC = C; g.cT2 = (T1 - 1) / 2; g.cF2 = (F1 - 1) / 2;
     g.A = h1; g.W = w2p; g.bias = b2; g.C = h2;
     g.M = (int64_t)B * g.cT2 * g.cF2; g.N = C; g.K = 9 * C; g.lda = 0; g.ldc = C; g.alpha = 1.f;
-    return launch<EPI_RELU, true>(g, static_cast<hipStream_t>(stream));
+    return launch<EPI_RELU, true, EPF_INFER>(g, static_cast<hipStream_t>(stream));
 }
 
 // Tuning / diagnostics: the residual-epilogue GEMM with a forced block-tile shape
@@ -417,9 +482,15 @@ extern "C" int cfm_debug_gemm_cfg_f32(int cfg, const float* A, const float* W, c
     CFM_REQUIRE(R != nullptr, CFM_ERR_NULL);
     g.occ_cap = cfg >= 0 ? (cfg >> 8) : 0;            // cfg + 256*cap: blocks/CU cap
     if (cfg >= 0) cfg &= 255;
-    CFM_REQUIRE(cfg >= -1 && (cfg < 0 || (cfg & 15) <= 3) && cfg < 48, CFM_ERR_BAD_SHAPE);
+    CFM_REQUIRE(cfg >= -1 && (cfg < 0 || (cfg & 15) <= 3) && cfg < 128, CFM_ERR_BAD_SHAPE);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (cfg >= 32) return launch<EPI_SWISH, false>(g, s, cfg & 15);     // cfg + 32: swish epilogue (no residual read)
-    if (cfg >= 16) return launch<EPI_BIAS, false>(g, s, cfg & 15);      // cfg + 16: bias epilogue
-    return launch<EPI_RESID, false>(g, s, cfg);
+    if (cfg >= 64) {                                                     // cfg + 64: K-tile 32 (whole cache lines per staged row)
+        cfg &= 63;
+        if (cfg >= 32) return launch<EPI_SWISH, false, EPF_INFER, 32>(g, s, cfg & 15);
+        if (cfg >= 16) return launch<EPI_BIAS, false, EPF_INFER, 32>(g, s, cfg & 15);
+        return launch<EPI_RESID, false, EPF_INFER, 32>(g, s, cfg);
+    }
+    if (cfg >= 32) return launch<EPI_SWISH, false, EPF_INFER>(g, s, cfg & 15);     // cfg + 32: swish epilogue (no residual read)
+    if (cfg >= 16) return launch<EPI_BIAS, false, EPF_INFER>(g, s, cfg & 15);      // cfg + 16: bias epilogue
+    return launch<EPI_RESID, false, EPF_INFER>(g, s, cfg);
 }

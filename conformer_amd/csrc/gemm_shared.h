@@ -6,6 +6,12 @@
 namespace {
 
 enum Epi { EPI_BIAS = 0, EPI_SWISH = 1, EPI_RELU = 2, EPI_GLU = 3, EPI_RESID = 4, EPI_DSWISH = 5 };
+// Epilogue flags (template parameter F of the epilogue routines; 0 = everything, what the 16-bit kernels use):
+//   EPF_LN_CONSUME / EPF_LN_PRODUCE  the folded-LayerNorm roles (see gemm_epilogue_apply);
+//   EPF_NO_DROPOUT                   no dropout mask code (g.drop_p is ignored: the entry point guarantees it is 0);
+//   EPF_F32_OUT                      C (and Z) are fp32: the 8-column 16-bit write-out path is not compiled.
+enum EpiFlags { EPF_LN_CONSUME = 1, EPF_LN_PRODUCE = 2, EPF_LN_MASK = 3, EPF_NO_DROPOUT = 4, EPF_F32_OUT = 8,
+                EPF_INFER = EPF_NO_DROPOUT | EPF_F32_OUT };
 // EPI_DSWISH (16-bit kernels, backward): C = alpha * acc * swish'(Z) [* the forward's dropout mask]; Z = g.Zsave (READ, leading
 // dimension g.ldr, type g.z_prec), no bias.  Vectorised epilogue only (the entry point checks the alignment conditions).
 
@@ -101,8 +107,9 @@ struct EpiOps {
     unsigned z16[2];                // EPI_DSWISH: four 16-bit Z values, converted when they are used
     f32x4 cs, cg;                   // LN fold (consumer): column sums of the folded weight (values, GLU gates)
 };
-template <int EPI, int LN = 0>
+template <int EPI, int F = 0>
 __device__ __forceinline__ void gemm_epilogue_fetch_bias(const GemmArgs& g, int col, EpiOps& o) {
+    constexpr int LN = F & EPF_LN_MASK;
     const int ncols = EPI == EPI_GLU ? g.n_out : g.N;
     const int cc = col < ncols ? col : 0;                              // (groups beyond the last column are never stored)
     if (EPI != EPI_DSWISH) o.bb = *reinterpret_cast<const f32x4*>(g.bias + cc);
@@ -129,7 +136,7 @@ __device__ __forceinline__ void gemm_epilogue_fetch_row(const GemmArgs& g, int64
 
 // gemm_epilogue_compute: activation / dropout / residual of one fetched 4-column group; returns the values to store,
 // zpre = the pre-activation (what EPI_SWISH saves as Z)
-template <int EPI>
+template <int EPI, int F = 0>
 __device__ __forceinline__ f32x4 gemm_epilogue_compute(const GemmArgs& g, const f32x4 av, const f32x4 gv, const EpiOps& o, int64_t row,
                                                        int col, f32x4& zpre) {
     if constexpr (EPI == EPI_DSWISH) {
@@ -149,7 +156,7 @@ __device__ __forceinline__ f32x4 gemm_epilogue_compute(const GemmArgs& g, const 
             const float sg = sigmoidf_acc(z4[e]);
             r[e] = g.alpha * av[e] * (sg * (1.0f + z4[e] * (1.0f - sg)));
         }
-        if (g.drop_p > 0.f) {                                          // (vectorised path: N % 4 == 0 and col % 4 == 0 -- an aligned group)
+        if (!(F & EPF_NO_DROPOUT) && g.drop_p > 0.f) {                 // (vectorised path: N % 4 == 0 and col % 4 == 0 -- an aligned group)
             float keep[4];
             dropout_keep4(g.drop_seed, (unsigned long long)row * (unsigned long long)g.N + (unsigned)col, g.drop_p, 1.0f / (1.0f - g.drop_p), keep);
 #pragma unroll
@@ -161,7 +168,7 @@ __device__ __forceinline__ f32x4 gemm_epilogue_compute(const GemmArgs& g, const 
     float v[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) v[e] = av[e] + o.bb[e];
-    const bool drop = g.drop_p > 0.f && EPI != EPI_GLU && EPI != EPI_RELU;
+    const bool drop = !(F & EPF_NO_DROPOUT) && g.drop_p > 0.f && EPI != EPI_GLU && EPI != EPI_RELU;
     const float inv_keep = drop ? 1.0f / (1.0f - g.drop_p) : 1.0f;
     const unsigned long long e0 = (unsigned long long)row * (unsigned long long)g.N + (unsigned)col;
     float keep[4] = {1.f, 1.f, 1.f, 1.f};
@@ -219,9 +226,10 @@ __device__ __forceinline__ void epi_store8(void* base, int prec, int64_t off, co
 // LN == 2 (producer): every lane takes part (no early exit); the 8 lanes that hold 32 consecutive columns of a row reduce
 //   (sum, M2 about their own mean) of the STORED values and lane 0 of the group writes the partial (Chan-mergeable: no
 //   sum-of-squares cancellation).  Needs N % 32 == 0 (a group is all in or all out).
-template <int EPI, int LN = 0>
+template <int EPI, int F = 0>
 __device__ __forceinline__ void gemm_epilogue_apply(const GemmArgs& g, f32x4 av, f32x4 gv, const EpiOps& o, int64_t row,
                                                     int col, int64_t crow, const float* rowstats = nullptr, int lrow = 0) {
+    constexpr int LN = F & EPF_LN_MASK;
     const int ncols = EPI == EPI_GLU ? g.n_out : g.N;
     const bool ok = row < g.M && col < ncols;
     if constexpr (LN != 2) { if (!ok) return; }
@@ -231,10 +239,10 @@ __device__ __forceinline__ void gemm_epilogue_apply(const GemmArgs& g, f32x4 av,
         if (EPI == EPI_GLU) gv = (gv - mean * o.cg) * rstd;
     }
     f32x4 zpre;
-    const f32x4 v = gemm_epilogue_compute<EPI>(g, av, gv, o, row, col, zpre);
+    const f32x4 v = gemm_epilogue_compute<EPI, F>(g, av, gv, o, row, col, zpre);
     if (ok) {
-        if (EPI == EPI_SWISH && g.Zsave) epi_store4(g.Zsave, g.z_prec, row * g.ldc + col, zpre);
-        epi_store4(g.C, g.c_prec, crow * g.ldc + col, v);
+        if (EPI == EPI_SWISH && g.Zsave) epi_store4(g.Zsave, (F & EPF_F32_OUT) ? 0 : g.z_prec, row * g.ldc + col, zpre);
+        epi_store4(g.C, (F & EPF_F32_OUT) ? 0 : g.c_prec, crow * g.ldc + col, v);
     }
     if constexpr (LN == 2) {
         float s = (v[0] + v[1]) + (v[2] + v[3]);
@@ -263,7 +271,7 @@ __device__ __forceinline__ void gemm_epilogue_apply8(const GemmArgs& g, const f3
 }
 
 // gemm_epilogue_at: fetch + apply of one group (scalar path for odd leading dimensions / widths)
-template <int EPI>
+template <int EPI, int F = 0>
 __device__ __forceinline__ void gemm_epilogue_at(const GemmArgs& g, const f32x4 av, const f32x4 gv, int64_t row, int col,
                                                  bool vec_ok, int64_t crow = -1) {
     if (crow < 0) crow = row;
@@ -273,7 +281,7 @@ __device__ __forceinline__ void gemm_epilogue_at(const GemmArgs& g, const f32x4 
         EpiOps o;
         gemm_epilogue_fetch_bias<EPI>(g, col, o);
         gemm_epilogue_fetch_row<EPI>(g, row, col, o);
-        gemm_epilogue_apply<EPI>(g, av, gv, o, row, col, crow);
+        gemm_epilogue_apply<EPI, F & ~EPF_LN_MASK>(g, av, gv, o, row, col, crow);
         return;
     }
     if constexpr (EPI == EPI_DSWISH) return;                           // (excluded by the entry point)
@@ -282,7 +290,7 @@ __device__ __forceinline__ void gemm_epilogue_at(const GemmArgs& g, const f32x4 
         for (int e = 0; e < 4; ++e) {
             if (col + e >= ncols) continue;
             float x = av[e] + g.bias[col + e];
-            const bool drop = g.drop_p > 0.f && EPI != EPI_GLU && EPI != EPI_RELU;
+            const bool drop = !(F & EPF_NO_DROPOUT) && g.drop_p > 0.f && EPI != EPI_GLU && EPI != EPI_RELU;
             const float keep = drop ? dropout_keep(g.drop_seed, (unsigned long long)row * (unsigned long long)g.N +
                                                    (unsigned)(col + e), g.drop_p, 1.0f / (1.0f - g.drop_p)) : 1.0f;
             if (EPI != EPI_SWISH) x *= keep;
@@ -291,7 +299,7 @@ __device__ __forceinline__ void gemm_epilogue_at(const GemmArgs& g, const f32x4 
             if (EPI == EPI_SWISH && g.Zsave) g.Zsave[row * g.ldc + col + e] = x;
             if (EPI == EPI_SWISH) x = swishf_acc(x) * keep;
             if (EPI == EPI_RELU) x = fmaxf(x, 0.f);
-            if (g.c_prec == 0) g.C[row * g.ldc + col + e] = x;
+            if ((F & EPF_F32_OUT) || g.c_prec == 0) g.C[row * g.ldc + col + e] = x;
             else if (g.c_prec == CFM_PREC_BF16) reinterpret_cast<__bf16*>(g.C)[row * g.ldc + col + e] = (__bf16)x;
             else reinterpret_cast<_Float16*>(g.C)[row * g.ldc + col + e] = (_Float16)x;
         }
@@ -307,9 +315,10 @@ __device__ __forceinline__ bool gemm_epilogue_vec_ok(const GemmArgs& g, int epi)
 
 // Straight from the accumulators: every memory instruction of a wave touches 32 rows x 32 bytes.  Kept for the GLU tile
 // (value and gate tiles of one column range live in one wave) and as the fallback for odd leading dimensions.
-template <int BM, int BN, int EPI, int TM, int TN>
+template <int BM, int BN, int EPI, int TM, int TN, int F = 0>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const f32x16 (&acc)[TM][TN], int64_t m0, int n0,
                                               int wr, int wc, int li, int hf) {
+    static_assert((F & EPF_LN_MASK) == 0 || true, "the LN fold is only wired through gemm_epilogue_rows (entry points guarantee vec_ok)");
     const bool vec_ok = gemm_epilogue_vec_ok(g, EPI);
     constexpr int NTN = EPI == EPI_GLU ? 1 : TN;
     auto col_of = [&](int nt, int q) { return n0 + (EPI == EPI_GLU ? wc * 32 : wc * (BN / 2) + nt * 32) + 8 * q + 4 * hf; };
@@ -343,8 +352,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const f32x16 (&
             for (int nt = 0; nt < NTN; ++nt)
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
-                    gemm_epilogue_apply<EPI>(g, av_of(mt, nt, q), av_of(mt, TN - 1, q), ROWOPS ? orow[ROWOPS ? mt : 0][ROWOPS ? nt : 0][ROWOPS ? q : 0] : ob[nt][q],
-                                             row_of(mt), col_of(nt, q), row_of(mt));
+                    gemm_epilogue_apply<EPI, F & ~EPF_LN_MASK>(g, av_of(mt, nt, q), av_of(mt, TN - 1, q), ROWOPS ? orow[ROWOPS ? mt : 0][ROWOPS ? nt : 0][ROWOPS ? q : 0] : ob[nt][q],
+                                                                row_of(mt), col_of(nt, q), row_of(mt));
         return;
     }
 #pragma unroll
@@ -353,7 +362,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const f32x16 (&
         for (int nt = 0; nt < NTN; ++nt)
 #pragma unroll
             for (int q = 0; q < 4; ++q)
-                gemm_epilogue_at<EPI>(g, av_of(mt, nt, q), av_of(mt, TN - 1, q), row_of(mt), col_of(nt, q), false);
+                gemm_epilogue_at<EPI, F>(g, av_of(mt, nt, q), av_of(mt, TN - 1, q), row_of(mt), col_of(nt, q), false);
 }
 
 // ROW-MAJOR epilogue: each 32-row slab of the wave's accumulators goes through a per-wave LDS tile (the K-loop's staging
@@ -365,7 +374,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const f32x16 (&
 // CLS: the rows are transposed-conv class rows (CONV == 2) and are scattered to their dh1 positions.  A TEMPLATE flag: as a run-time
 // test of g.pA the (skipped) 64-bit divisions were still unrolled into every kernel's epilogue -- 60 % more code in the 256x256
 // kernels, which ran 12-20 % slower from instruction-cache misses alone.
-template <int BM, int BN, int EPI, int TM, int TN, int WM = 2, bool CLS = false, int LN = 0>
+template <int BM, int BN, int EPI, int TM, int TN, int WM = 2, bool CLS = false, int F = 0>
 __device__ __forceinline__ void gemm_epilogue_rows(const GemmArgs& g, const f32x16 (&acc)[TM][TN], int64_t m0, int n0,
                                                    int wr, int wc, int lane, float* scratch, const float* rowstats = nullptr) {
     static_assert(EPI != EPI_GLU || TN == 2, "GLU: n-tile 0 = values, n-tile 1 = gates of the same 32 output columns");
@@ -374,7 +383,7 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmArgs& g, const f32x
     const int li = lane & 31, hf = lane >> 5;
     if constexpr (WM == 2) {                                          // (8-wave tiles: the launcher guarantees vec_ok)
         if (!gemm_epilogue_vec_ok(g, EPI)) {                          // (kernel-uniform)
-            gemm_epilogue<BM, BN, EPI, TM, TN>(g, acc, m0, n0, wr, wc, li, hf);
+            gemm_epilogue<BM, BN, EPI, TM, TN, F>(g, acc, m0, n0, wr, wc, li, hf);
             return;
         }
     }
@@ -404,7 +413,7 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmArgs& g, const f32x
     };
 
     // ---- 16-bit C: 8 columns per lane, one 16-byte store per lane and output tensor (see gemm_epilogue_apply8)
-    if constexpr (EPI != EPI_RESID && EPI != EPI_GLU && LN == 0) {
+    if constexpr (EPI != EPI_RESID && EPI != EPI_GLU && (F & (EPF_LN_MASK | EPF_F32_OUT)) == 0) {
         const bool wide = g.c_prec != 0 && ((g.N | (int)g.ldc) & 7) == 0 && (reinterpret_cast<uintptr_t>(g.C) & 15) == 0 &&
                           (EPI != EPI_SWISH || !g.Zsave || (reinterpret_cast<uintptr_t>(g.Zsave) & 15) == 0) &&
                           (EPI != EPI_DSWISH || (g.z_prec != 0 && (g.ldr & 7) == 0 && (reinterpret_cast<uintptr_t>(g.Zsave) & 15) == 0));
@@ -466,7 +475,7 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmArgs& g, const f32x
     // Every load is issued ahead of the stores it would otherwise queue behind (see EpiOps): the bias once (a lane's columns
     // are the same for all its rows), the residual / Z rows of batch i+1 before batch i is written out.
     EpiOps ob;
-    gemm_epilogue_fetch_bias<EPI, LN>(g, col, ob);
+    gemm_epilogue_fetch_bias<EPI, F>(g, col, ob);
     if constexpr (!ROWOPS) {
 #pragma unroll
         for (int mt = 0; mt < TM; ++mt) {
@@ -477,7 +486,7 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmArgs& g, const f32x
                 const f32x4 v = *reinterpret_cast<const f32x4*>(scratch + rl * P + c4);
                 const f32x4 gate = EPI == EPI_GLU ? *reinterpret_cast<const f32x4*>(scratch + rl * P + 32 + c4) : v;
                 const int64_t row = row_of(mt, it);
-                gemm_epilogue_apply<EPI, LN>(g, v, gate, ob, row, col, CLS ? class_row(row) : row, rowstats, (int)(row - m0));
+                gemm_epilogue_apply<EPI, F>(g, v, gate, ob, row, col, CLS ? class_row(row) : row, rowstats, (int)(row - m0));
             }
             slab_done();
         }
@@ -506,7 +515,7 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmArgs& g, const f32x
                     const int64_t row = row_of(mt, it);
                     EpiOps o = ob;
                     o.rr = ocur[j].rr; o.z16[0] = ocur[j].z16[0]; o.z16[1] = ocur[j].z16[1];
-                    gemm_epilogue_apply<EPI, LN>(g, v, v, o, row, col, CLS ? class_row(row) : row, rowstats, (int)(row - m0));
+                    gemm_epilogue_apply<EPI, F>(g, v, v, o, row, col, CLS ? class_row(row) : row, rowstats, (int)(row - m0));
                 }
 #pragma unroll
                 for (int j = 0; j < HB; ++j) ocur[j] = onxt[j];

@@ -263,9 +263,9 @@ def set_ln_fold(on: bool) -> bool:
 
 
 def ln_fold_ok(d: int) -> bool:
-    """The fold applies to the native fp32 matrix-pipe path (no autocast, no split mode) for rows of d = 32 * parts <= 512
-    values (the statistics travel as one partial per 32 columns; a workgroup merges at most 16 of them)."""
-    return bool(_LN_FOLD and not _fp32_planes and mfma16_prec() == PREC_F32 and d % 32 == 0 and d // 32 <= 16)
+    """The fold applies to the native fp32 matrix-pipe path (no autocast, no split mode) for rows of d = 32, 64, 128, 256 or 512
+    values (the statistics travel as one partial per 32 columns; a workgroup merges the 1..16 partials of a row in a binary tree)."""
+    return bool(_LN_FOLD and not _fp32_planes and mfma16_prec() == PREC_F32 and d in (32, 64, 128, 256, 512))
 
 
 def fold_layernorm(w: torch.Tensor, b: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor):

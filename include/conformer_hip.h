@@ -84,7 +84,8 @@ int cfm_gemm_bias_residual_f32(const float* A, const float* W, const float* bias
  *        rstd * (A.Wf^T - mean * colsum) + bias_f with Wf = W.diag(gamma), bias_f = b + W.beta, colsum[n] = sum_k Wf[n,k]
  *        (folded once per weight version by the caller); mean / rstd are merged from the partials (Chan's formula, fixed
  *        order) by each workgroup for its rows.  epi: 0 bias | 1 +swish | 3 +GLU (N = n_out; Wf, bias_f, colsum have 2N
- *        rows: values then gates).  ln_parts <= 16, K % ln_parts == 0; N, ldc % 4 == 0; 16-byte aligned C / bias_f / colsum. */
+ *        rows: values then gates).  ln_parts in {1, 2, 4, 8, 16}, K % ln_parts == 0; N, ldc % 4 == 0; 16-byte aligned C / bias_f /
+ *        colsum / ln_stats. */
 int cfm_gemm_bias_stats_f32(const float* A, const float* W, const float* bias, float* C, float* stats_out,
                             int64_t M, int N, int K, int64_t lda, int64_t ldc, cfm_stream_t stream);
 int cfm_gemm_bias_residual_stats_f32(const float* A, const float* W, const float* bias, const float* R,
@@ -374,6 +375,8 @@ int cfm_debug_gemm_mfma16_trace(void* trace_or_null);     /* per-K-tile stamps o
 int cfm_debug_gemm_cfg_f32(int cfg, const float* A, const float* W, const float* bias, const float* R,
                            float alpha, float* C, int64_t M, int N, int K, void* trace_or_null,
                            cfm_stream_t stream);
+/*      cfg + 16: bias epilogue; cfg + 32: swish epilogue; cfg + 64: K-tile 32 (a staged row = one whole 128-byte line;
+ *      measured slower than the K-tile 16 loop at every hot-path shape but one: kept for tools/gemm_tune.py bk). */
 
 /* Backward of the conv-subsampling stem (convolution.py:42-52).  With dz2 = relu'(h2) * dh2 (cfm_relu_bwd_f32):
  *   conv2_bwd_weight: dw2p (C, 9C) in the PACKED (co,kf,kt,ci) layout += dz2^T . im2col(h1)   (zero-filled by caller;

@@ -105,6 +105,20 @@ def test_bench_gpus_n_starts_its_own_ranks():
     assert j["n_gpus"] == 2 and j["ranks"] == 2 and j["collective_backend"] == "gloo"
     assert j["local_ranks_plus_one"] == [1, 2]              # rank r ran with LOCAL_RANK r
     assert j["steps"] == 3 and j["warmup"] == 1 and j["scaling"] == "weak"
+    # the data-parallel fields of the --train line, exercised over gloo by the selftest's DDP step
+    assert len(j["per_rank_step_ms"]) == 2 and all(v > 0 for v in j["per_rank_step_ms"])
+    assert j["allreduce_bytes_per_step"] == 4 * (64 * 64 + 64 + 8 * 64 + 8) and j["allreduce_buckets"] >= 1
+    assert j["exposed_comm_ms"] is not None and j["exposed_comm_ms"] >= 0 and j["comm_span_ms"] >= j["exposed_comm_ms"] - 1e-6
+    assert len(j["exposed_comm_ms_per_rank"]) == 2
+    assert j["ddp"] == {"bucket_cap_mb": 25, "gradient_as_bucket_view": False, "static_graph": False}
+
+
+def test_bench_ddp_knobs_reach_ddp():
+    rc, js, err = _run_bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--selftest-cpu", "--bucket-cap-mb", "1",
+                              "--gradient-as-bucket-view", "--static-graph"])
+    assert rc == 0, err
+    assert js[0]["ddp"] == {"bucket_cap_mb": 1, "gradient_as_bucket_view": True, "static_graph": True}
+    assert js[0]["allreduce_bytes_per_step"] == 4 * (64 * 64 + 64 + 8 * 64 + 8)
 
 
 def test_bench_under_a_launcher_and_mismatch():

@@ -144,7 +144,54 @@ def bwd_sweep(prec=0):
         print(line, flush=True)
 
 
+def bk_sweep():
+    """K-tile 16 vs 32 (whole 128-byte lines per staged row) at the hot-path shapes with their own epilogues, every block tile,
+    interleaved rounds in one process (median of 7 rounds x 20 launches)."""
+    import statistics
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    st = torch.cuda.current_stream().cuda_stream
+    M = int(os.environ.get("TUNE_M", "7968"))
+    sites = [("FFN hidden swish", M, 2048, 512, 32), ("FFN out resid", M, 512, 2048, 0), ("QKV bias", M, 1536, 512, 16),
+             ("attn-out/pw2 resid", M, 512, 512, 0), ("pw1 (bias stand-in)", M, 1024, 512, 16), ("input linear bias", M, 512, 9728, 16)]
+    for name, m, n, k, epi in sites:
+        a = torch.randn(m, k, device=dev); w = torch.randn(n, k, device=dev) / k ** 0.5
+        b = torch.randn(n, device=dev); r = torch.randn(m, n, device=dev); c = torch.empty(m, n, device=dev)
+        variants = [(tile, bk) for tile in (0, 1, 2, 3) for bk in (16, 32)]
+        times = {v: [] for v in variants}
+
+        def run(v):
+            cfg = v[0] + epi + (64 if v[1] == 32 else 0)
+            s_ = lib.cfm_debug_gemm_cfg_f32(cfg, a.data_ptr(), w.data_ptr(), b.data_ptr(), r.data_ptr(), 0.5, c.data_ptr(), m, n, k,
+                                            None, st)
+            assert s_ == 0, s_
+        ref = None
+        for v in variants:
+            run(v); torch.cuda.synchronize()
+            if ref is None:
+                ref = c.clone()
+            else:
+                err = float((c - ref).norm() / ref.norm())
+                assert err < 1e-5, (v, err)
+        for rnd_ in range(7):
+            for v in variants:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(20):
+                    run(v)
+                e1.record()
+                torch.cuda.synchronize()
+                times[v].append(e0.elapsed_time(e1) / 20)
+        line = f"{name:>22s} {m}x{n}x{k}: "
+        for v in variants:
+            med = statistics.median(times[v])
+            line += f"| {CFG[v[0]]}/k{v[1]} {med * 1e3:6.1f}us {2.0 * m * n * k / med / 1e9:5.1f} "
+        print(line, flush=True)
+
+
 def main():
+    if len(sys.argv) == 2 and sys.argv[1] == "bk":
+        return bk_sweep()
     if len(sys.argv) == 2 and sys.argv[1] in ("bwd", "bwd16"):
         return bwd_sweep(1 if sys.argv[1] == "bwd16" else 0)
     if len(sys.argv) == 2 and sys.argv[1] == "occ":
