@@ -27,6 +27,7 @@ SIGNATURES = {
     "cfm_strerror": (c_char_p, [_I]),
     "cfm_device_check": (c_int, []),
     "cfm_subsampled_length": (c_int64, [_L]),
+    "cfm_subsampled_lengths_i64": (c_int, [_P, _P, _I, _P]),
     "cfm_layernorm_fwd_f32": (c_int, [_P, _P, _P, _P, _P, _P, _L, _I, _F, _P]),
     "cfm_gemm_bias_f32": (c_int, [_P, _P, _P, _P, _L, _I, _I, _L, _L, _P]),
     "cfm_gemm_bias_swish_f32": (c_int, [_P, _P, _P, _P, _L, _I, _I, _L, _L, _P]),
@@ -112,6 +113,7 @@ SIGNATURES = {
     "cfm_relpos_attention_rows_f32": (c_int, [_P, _P, _P, _L, _P, _L, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
     "cfm_debug_attention_trace_f32": (c_int, [_P, _P, _P, _L, _P, _L, _P, _P, _P, _P, _L, _I, _I, _I, _I, _P, _P]),
     "cfm_debug_set_bwd_tile": (c_int, [_I]),
+    "cfm_debug_set_attention_waves": (c_int, [_I]),
     "cfm_debug_gemm_cfg_f32": (c_int, [_I, _P, _P, _P, _P, _F, _P, _L, _I, _I, _P, _P]),
     "cfm_relpos_table_f32": (c_int, [_P, _P, _I, _I, _P]),
     "cfm_relpos_attention_fwd_f32": (c_int, [_P, _P, _P, _L, _P, _L, _P, _P, _P, _P, _L, _P, _I, _I, _I, _I, _P]),

@@ -27,3 +27,16 @@ extern "C" int cfm_device_check(void) {
 }
 
 extern "C" int64_t cfm_subsampled_length(int64_t n) { return ((n - 1) / 2 - 1) / 2; }
+
+// The same on a device array (convolution.py:55 applied to `lengths`): floor division, as torch.div(rounding_mode="floor")
+// -- an arithmetic shift also for negative values.  One launch instead of four stock elementwise kernels per forward.
+__global__ void subsampled_lengths_kernel(const int64_t* __restrict__ in, int64_t* __restrict__ out, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (((in[i] - 1) >> 1) - 1) >> 1;
+}
+extern "C" int cfm_subsampled_lengths_i64(const int64_t* lengths, int64_t* out, int n, cfm_stream_t stream) {
+    CFM_REQUIRE(lengths && out, CFM_ERR_NULL);
+    CFM_REQUIRE(n > 0, CFM_ERR_BAD_SHAPE);
+    hipLaunchKernelGGL(subsampled_lengths_kernel, dim3((n + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), lengths, out, n);
+    return cfm_launch_status();
+}

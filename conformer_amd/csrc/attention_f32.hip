@@ -40,21 +40,34 @@ struct AttnArgs {
     unsigned long long* trace;                      // diagnostics (cfm_debug_attention_trace_f32): phase stamps of one wave
 };
 
-template <int NC, int ND>
-__global__ __launch_bounds__(256, 2) void relpos_attn_fwd_kernel(const AttnArgs a) {
-    __shared__ __attribute__((aligned(16))) float smem[2 * 32 * KROW + 2 * 32 * 64 + 4 * 32 * 32];
+// NW = 4: a workgroup is 4 waves = 128 query rows; a key tile is staged, then every wave runs phase 1 (content + band products)
+//         and phase 2 (skew, softmax, P.V), one barrier per key tile (rounds 1-2).
+// NW = 8 (round 3): 8 waves = 256 query rows = a whole (batch, head) of the T' = 249 workload, so K / V are staged ONCE per
+//         (batch, head) instead of twice, and the two halves of the workgroup run HALF A KEY TILE APART: while waves 0-3 are in
+//         phase 1 of tile t (64 MFMAs), waves 4-7 -- their partners on the same SIMDs -- are in phase 2 of tile t-1 (the VALU /
+//         LDS section + 32 MFMAs), and vice versa in the next interval; one barrier per interval.  The round-2 kernel put two
+//         independent 4-wave workgroups on a CU: both ran the same program in the same phase (MFMA pipe contended, then idle
+//         under the softmax): matrix pipe 0.53 busy (profiles/r03_pmc_mfma.json).
+template <int NC, int ND, int NW>
+__global__ __launch_bounds__(64 * NW, 2) void relpos_attn_fwd_kernel(const AttnArgs a) {
+    constexpr int RING = NW == 8 ? 9 : 0;        // NW = 8: 32-row blocks of the positional table kept in LDS (see below)
+    __shared__ __attribute__((aligned(16))) float smem[2 * 32 * KROW + 2 * 32 * 64 + NW * 32 * 32 + RING * 32 * KROW];
     float* Ksb = smem;                           // [2][32][KROW]
     float* Vsb = Ksb + 2 * 32 * KROW;            // [2][32][64]
     float* gs = Vsb + 2 * 32 * 64 + (threadIdx.x >> 6) * 1024;   // per-wave skew tile [32][32]
+    [[maybe_unused]] float* ring = Vsb + 2 * 32 * 64 + NW * 32 * 32;   // [RING][32][KROW]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, hf = lane >> 5;
     const int bh = blockIdx.y, b = bh / a.H, h = bh % a.H;
     const int T = a.T, dh = a.dh;
+    constexpr int QB = 32 * NW;                                          // query rows per workgroup
     const int split = a.nsplit > 1 ? (int)(blockIdx.x % (unsigned)a.nsplit) : 0;
-    const int q0 = a.q_begin + (int)(a.nsplit > 1 ? blockIdx.x / (unsigned)a.nsplit : blockIdx.x) * 128;
+    const int q0 = a.q_begin + (int)(a.nsplit > 1 ? blockIdx.x / (unsigned)a.nsplit : blockIdx.x) * QB;
     const int i0 = q0 + wave * 32;
     const bool active = i0 < a.q_end;                                    // wave-uniform; idle waves still stage + barrier
+    const bool tracer = NW == 4 && a.trace && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0;
+    if (tracer) a.trace[9] = __builtin_amdgcn_s_memrealtime();           // kernel entry
 
     int klen = T;
     bool uniform = false;
@@ -74,15 +87,16 @@ __global__ __launch_bounds__(256, 2) void relpos_attn_fwd_kernel(const AttnArgs 
     const float* pbase = a.pos + h * dh;
     const int jmax = 2 * T - 2;
 
-    // ---- cooperative staging: thread -> (row srow + 16*pass, 16-byte chunk sch) of a 32-row x 256-byte tile
+    // ---- cooperative staging: thread -> (row srow + RPP*pass, 16-byte chunk sch) of a 32-row x 256-byte tile
+    constexpr int RPP = 4 * NW, SP = 32 / RPP;                     // rows per pass (16 | 32), passes (2 | 1)
     const int srow = tid >> 4, sch = tid & 15;
     const bool sok = sch * 4 < dh;
-    f32x4 pk[2], pv[2];
+    f32x4 pk[SP], pv[SP];
     auto prefetch = [&](int kt) {                                  // K/V tile kt -> registers
         const int k0 = kt * 32;
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            const int r = srow + 16 * p;
+        for (int p = 0; p < SP; ++p) {
+            const int r = srow + RPP * p;
             const int key = min(k0 + r, T - 1);
             const f32x4 z = {0.f, 0.f, 0.f, 0.f};
             pk[p] = sok ? *reinterpret_cast<const f32x4*>(kbase + (int64_t)key * a.ld + sch * 4) : z;
@@ -91,15 +105,40 @@ __global__ __launch_bounds__(256, 2) void relpos_attn_fwd_kernel(const AttnArgs 
     };
     auto commit = [&](int buf) {                                   // registers -> LDS buffer `buf`
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            const int r = srow + 16 * p;
+        for (int p = 0; p < SP; ++p) {
+            const int r = srow + RPP * p;
             *reinterpret_cast<f32x4*>(Ksb + buf * 32 * KROW + r * KROW + sch * 4) = pk[p];
             *reinterpret_cast<f32x4*>(Vsb + buf * 32 * 64 + r * 64 + sch * 4) = pv[p];
         }
     };
+    // NW = 8: the positional band as a RING of 32-row table blocks in LDS.  Wave w (queries q0 + 32w ..) needs, for key tile t,
+    // table rows R0 + 32 (t - w) + (31 - li), R0 = T - 1 - q0: "block" t - w.  The 8 waves of a workgroup therefore read 8
+    // CONSECUTIVE blocks, and a key tile brings in exactly ONE new block (32 rows x 256 B, one coalesced 16-byte load per thread,
+    // requested a key tile ahead like K / V); the 4-wave form's per-wave global reads of its band rows -- 8 loads of 64 different
+    // cache lines each, per wave and key tile, waited for in front of the band MFMAs -- were 1.3-1.7 us of a 7.5 us key tile
+    // (profiles/r03_attn_fwd_trace.txt).  Block b lives in slot b mod 9 from the interval it is committed in until wave 7 of
+    // the lagging half has read it (tile b + 7): blocks -8 .. 0 are loaded in the prologue (block -w - 1 = wave w's band tile 1 of
+    // the first key tile).
+    const int R0 = T - 1 - q0;
+    [[maybe_unused]] f32x4 pr;
+    [[maybe_unused]] auto ring_slot = [](int blk) { return ((blk % 9) + 9) % 9; };
+    [[maybe_unused]] auto ring_load = [&](int blk) {              // thread (row srow, chunk sch) of block blk -> register
+        const int j = max(0, min(R0 + 32 * blk + srow, jmax));     // (rows outside the table belong to pairs that do not exist)
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        pr = sok ? *reinterpret_cast<const f32x4*>(pbase + (int64_t)j * a.ldp + sch * 4) : z;
+    };
+    [[maybe_unused]] auto ring_commit = [&](int blk) {
+        *reinterpret_cast<f32x4*>(ring + (ring_slot(blk) * 32 + srow) * KROW + sch * 4) = pr;
+    };
     prefetch(kt_begin);
     commit(0);
-    if (kt_begin + 1 < ntiles) prefetch(kt_begin + 1);
+    if constexpr (NW == 8) {
+        for (int blk = -8; blk <= 0; ++blk) { ring_load(blk); ring_commit(blk); }
+    }
+    if (kt_begin + 1 < ntiles) {
+        prefetch(kt_begin + 1);
+        if constexpr (NW == 8) ring_load(1);
+    }
     __syncthreads();
 
     // ---- (Q+u)^T and (Q+v)^T as MFMA B operands: lane (query li, half hf) holds dims 8c+4hf+e at step 4c+e
@@ -128,7 +167,6 @@ __global__ __launch_bounds__(256, 2) void relpos_attn_fwd_kernel(const AttnArgs 
         for (int r = 0; r < 16; ++r) o[n][r] = 0.f;
     float mrow = -INFINITY, lrow = 0.f;
 
-    const bool tracer = a.trace && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0;
 #define ATT_STAMP(i) do { if (tracer) a.trace[16 * kt + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
     // ---- positional band G^T[jj][query], jj = 32*mt + row <-> table row j = jbase - jj (jbase = T-1-i0+k0+31), and the
     // "relative shift": lane (query li) needs G^T[li - kk + 31][li] for its 16 keys kk -- a per-lane column skew through the
@@ -160,6 +198,27 @@ __global__ __launch_bounds__(256, 2) void relpos_attn_fwd_kernel(const AttnArgs 
             for (int e = 0; e < 4; ++e) ga = __builtin_amdgcn_mfma_f32_32x32x2f32(pf[c][e], qv[4 * c + e], ga, 0, 0, 0);
         return ga;
     };
+    // NW = 8: band tile of ring block `blk`: A-operand row li <-> block row 31 - li, fragments by ds_read_b128 (272-byte rows)
+    [[maybe_unused]] auto band_mma_ring = [&](int blk) {
+        const float* rp = ring + (ring_slot(blk) * 32 + (31 - li)) * KROW + 4 * hf;
+        f32x16 ga, gb;                       // two independent accumulation chains (even / odd 8-dim slices), summed at the end
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { ga[r] = 0.f; gb[r] = 0.f; }
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const f32x4 f = *reinterpret_cast<const f32x4*>(rp + 8 * c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (e & 1) gb = __builtin_amdgcn_mfma_f32_32x32x2f32(f[e], qv[4 * c + e], gb, 0, 0, 0);
+                else ga = __builtin_amdgcn_mfma_f32_32x32x2f32(f[e], qv[4 * c + e], ga, 0, 0, 0);
+            }
+        }
+        if constexpr (NC > 1) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ga[r] += gb[r];
+        }
+        return ga;
+    };
     auto spill_band = [&](const f32x16& ga) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) gs[((r & 3) + 8 * (r >> 2) + 4 * hf) * 32 + li] = ga[r];
@@ -177,112 +236,178 @@ __global__ __launch_bounds__(256, 2) void relpos_attn_fwd_kernel(const AttnArgs 
     float skp[16];                                                   // band tile 1 of the current key tile, skewed (carried)
     f32x4 pf[NC];                                                    // table rows of a band tile in the A-operand layout
     if (active) {                                                    // first key tile: its band tile 1 is computed explicitly
-        band_load(T - 1 - i0 + 32 * kt_begin + 31, 1, pf);
-        const f32x16 g1 = band_mma(pf);
+        f32x16 g1;
+        if constexpr (NW == 8) {
+            g1 = band_mma_ring(-wave - 1);
+        } else {
+            band_load(T - 1 - i0 + 32 * kt_begin + 31, 1, pf);
+            g1 = band_mma(pf);
+        }
         spill_band(g1);
         skew_reads(skp);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // the reads have landed before the tile is rewritten
         __builtin_amdgcn_wave_barrier();
     }
-    for (int kt = kt_begin; kt < ntiles; ++kt) {
+    f32x16 sc;                                                       // content scores of the tile in flight (phase 1 -> phase 2)
+
+    // ---- phase 1 of key tile kt: content scores S^T[key][query] and band tile 0, spilled to the wave's skew tile
+    auto phase1 = [&](int kt) {
         const int k0 = kt * 32;
-        const int buf = (kt - kt_begin) & 1;
-        const float* Ks = Ksb + buf * 32 * KROW;
-        const float* Vs = Vsb + buf * 32 * 64;
-        ATT_STAMP(0);
-        // ---- stage the NEXT key tile into the other buffer (its last readers passed the barrier that ended tile kt-1), then
-        //      request the one after it
-        if (kt + 1 < ntiles) {
-            commit(buf ^ 1);
-            if (kt + 2 < ntiles) prefetch(kt + 2);
-        }
-        ATT_STAMP(1);
-        if (active) {
-            const int jbase = T - 1 - i0 + k0 + 31;
-            // the band tile's table rows land behind the content MFMAs.  (Requesting them a key tile ahead -- before P.V or right
-            // after the band product -- was measured: the 32 extra live VGPRs spill at dh = 64 and the kernel is slower, 97 vs 80 us;
-            // the band phase is not waiting on these loads anyway but on the matrix pipe it shares with the CU's other workgroup.)
-            band_load(jbase, 0, pf);
-            // ---- content scores S^T[key][query]
-            f32x16 sc;
+        const float* Ks = Ksb + ((kt - kt_begin) & 1) * 32 * KROW;
+        const int jbase = T - 1 - i0 + k0 + 31;
+        // the band tile's table rows land behind the content MFMAs.  (Requesting them a key tile ahead -- before P.V or right
+        // after the band product -- was measured: the 32 extra live VGPRs spill at dh = 64 and the kernel is slower, 97 vs 80 us.)
+        if constexpr (NW == 4) band_load(jbase, 0, pf);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) sc[r] = 0.f;
+        for (int r = 0; r < 16; ++r) sc[r] = 0.f;
+        if constexpr (NW == 8) {
+            f32x16 sb;                                     // second accumulation chain (odd contraction steps)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sb[r] = 0.f;
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
                 const f32x4 kf = *reinterpret_cast<const f32x4*>(Ks + li * KROW + 8 * c + 4 * hf);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) sc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[e], qu[4 * c + e], sc, 0, 0, 0);
-            }
-            ATT_STAMP(2);
-            {
-                const f32x16 g0 = band_mma(pf);
-                spill_band(g0);
-            }
-            ATT_STAMP(3);
-            float skn[16];
-            skew_reads(skn);
-            ATT_STAMP(4);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();                        // the tile is rewritten by the next key tile
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int jj = li - ((r & 3) + 8 * (r >> 2) + 4 * hf) + 31;
-                sc[r] += (jj >> 5) ? skp[r] : skn[r];
-                skp[r] = skn[r];
-            }
-            ATT_STAMP(5);
-            // ---- scale + mask, online softmax (query = lane column; keys = registers x 2 halves)
-            float p[16];
-            float tmax = -INFINITY;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int kk = (r & 3) + 8 * (r >> 2) + 4 * hf;
-                float s = sc[r] * a.inv_sqrt_dh;
-                if (uniform) s = 0.f;
-                if (k0 + kk >= klen) s = -INFINITY;
-                p[r] = s;
-                tmax = fmaxf(tmax, s);
-            }
-            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-            const float mnew = fmaxf(mrow, tmax);                   // finite: key k0 (< klen) is always valid
-            const float alpha = exp_fast(mrow - mnew);
-            float psum = 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { p[r] = exp_fast(p[r] - mnew); psum += p[r]; }
-            psum += __shfl_xor(psum, 32, 64);
-            lrow = lrow * alpha + psum;
-            mrow = mnew;
-            ATT_STAMP(6);
-            if (a.drop_p > 0.f) {                                     // weights are dropped AFTER normalisation: l stays unmasked
-                const float inv_keep = 1.0f / (1.0f - a.drop_p);
-                const unsigned long long rowbase = ((unsigned long long)bh * T + (unsigned)(i0 + li)) * (unsigned long long)T;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {                         // registers 4q .. 4q+3: four consecutive keys (any alignment: T is odd)
-                    float keep[4];
-                    dropout_keep4u(a.drop_seed, rowbase + (unsigned)(k0 + 8 * q + 4 * hf), a.drop_p, inv_keep, keep);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) p[4 * q + e] *= keep[e];
+                for (int e = 0; e < 4; ++e) {
+                    if (e & 1) sb = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[e], qu[4 * c + e], sb, 0, 0, 0);
+                    else sc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[e], qu[4 * c + e], sc, 0, 0, 0);
                 }
             }
 #pragma unroll
-            for (int n = 0; n < ND; ++n)
+            for (int r = 0; r < 16; ++r) sc[r] += sb[r];
+        } else {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) o[n][r] *= alpha;
-            // ---- O^T += V^T . P^T ; MFMA step s contracts key (s&3)+8*(s>>2)+4*hf = the key held in register s
+        for (int c = 0; c < NC; ++c) {
+            const f32x4 kf = *reinterpret_cast<const f32x4*>(Ks + li * KROW + 8 * c + 4 * hf);
 #pragma unroll
-            for (int n = 0; n < ND; ++n)
-#pragma unroll
-                for (int s = 0; s < 16; ++s) {
-                    const float vv = Vs[((s & 3) + 8 * (s >> 2) + 4 * hf) * 64 + ((32 * n + li) & 63)];
-                    o[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv, p[s], o[n], 0, 0, 0);
-                }
-            ATT_STAMP(7);
+            for (int e = 0; e < 4; ++e) sc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[e], qu[4 * c + e], sc, 0, 0, 0);
         }
-        // ---- one barrier per key tile: tile kt+1 (written above) is visible, tile kt's buffer may be overwritten next round
-        if (kt + 1 < ntiles) __syncthreads();
-        ATT_STAMP(8);
+        }
+        ATT_STAMP(2);
+        if constexpr (NW == 8) {
+            const f32x16 g0 = band_mma_ring((kt - kt_begin) - wave);
+            spill_band(g0);
+        } else {
+            const f32x16 g0 = band_mma(pf);
+            spill_band(g0);
+        }
+        ATT_STAMP(3);
+    };
+    // ---- phase 2 of key tile kt: relative shift, scale + mask, online softmax, O^T += V^T . P^T
+    auto phase2 = [&](int kt) {
+        const int k0 = kt * 32;
+        const float* Vs = Vsb + ((kt - kt_begin) & 1) * 32 * 64;
+        float skn[16];
+        skew_reads(skn);
+        ATT_STAMP(4);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();                        // the tile is rewritten by the next key tile
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int jj = li - ((r & 3) + 8 * (r >> 2) + 4 * hf) + 31;
+            sc[r] += (jj >> 5) ? skp[r] : skn[r];
+            skp[r] = skn[r];
+        }
+        ATT_STAMP(5);
+        // scale + mask, online softmax (query = lane column; keys = registers x 2 halves)
+        float p[16];
+        float tmax = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int kk = (r & 3) + 8 * (r >> 2) + 4 * hf;
+            float s = sc[r] * a.inv_sqrt_dh;
+            if (uniform) s = 0.f;
+            if (k0 + kk >= klen) s = -INFINITY;
+            p[r] = s;
+            tmax = fmaxf(tmax, s);
+        }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        const float mnew = fmaxf(mrow, tmax);                   // finite: key k0 (< klen) is always valid
+        const float alpha = exp_fast(mrow - mnew);
+        float psum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { p[r] = exp_fast(p[r] - mnew); psum += p[r]; }
+        psum += __shfl_xor(psum, 32, 64);
+        lrow = lrow * alpha + psum;
+        mrow = mnew;
+        ATT_STAMP(6);
+        if (a.drop_p > 0.f) {                                     // weights are dropped AFTER normalisation: l stays unmasked
+            const float inv_keep = 1.0f / (1.0f - a.drop_p);
+            const unsigned long long rowbase = ((unsigned long long)bh * T + (unsigned)(i0 + li)) * (unsigned long long)T;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {                         // registers 4q .. 4q+3: four consecutive keys (any alignment: T is odd)
+                float keep[4];
+                dropout_keep4u(a.drop_seed, rowbase + (unsigned)(k0 + 8 * q + 4 * hf), a.drop_p, inv_keep, keep);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) p[4 * q + e] *= keep[e];
+            }
+        }
+#pragma unroll
+        for (int n = 0; n < ND; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[n][r] *= alpha;
+        // O^T += V^T . P^T ; MFMA step s contracts key (s&3)+8*(s>>2)+4*hf = the key held in register s
+#pragma unroll
+        for (int n = 0; n < ND; ++n)
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                const float vv = Vs[((s & 3) + 8 * (s >> 2) + 4 * hf) * 64 + ((32 * n + li) & 63)];
+                o[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv, p[s], o[n], 0, 0, 0);
+            }
+        ATT_STAMP(7);
+    };
+
+    if (tracer) a.trace[10] = __builtin_amdgcn_s_memrealtime();          // prologue done (Q, first K/V tile, first band tile)
+    if constexpr (NW == 4) {
+        for (int kt = kt_begin; kt < ntiles; ++kt) {
+            const int buf = (kt - kt_begin) & 1;
+            ATT_STAMP(0);
+            // stage the NEXT key tile into the other buffer (its last readers passed the barrier that ended tile kt-1), then
+            // request the one after it
+            if (kt + 1 < ntiles) {
+                commit(buf ^ 1);
+                if (kt + 2 < ntiles) prefetch(kt + 2);
+            }
+            ATT_STAMP(1);
+            if (active) {
+                phase1(kt);
+                phase2(kt);
+            }
+            // one barrier per key tile: tile kt+1 (written above) is visible, tile kt's buffer may be overwritten next round
+            if (kt + 1 < ntiles) __syncthreads();
+            ATT_STAMP(8);
+        }
+    } else {
+        // Interval iv: group A (waves 0-3) runs step iv, group B (waves 4-7) step iv-1; step 2j = phase 1 of tile j, step 2j+1 =
+        // phase 2.  Tile j's K is read in intervals 2j (A) and 2j+1 (B), its V in 2j+1 (A) and 2j+2 (B); tile j+1 is committed
+        // at the start of interval 2j+1 into the buffer tile j-1 left free after interval 2j.
+        const int nt = ntiles - kt_begin, grp = wave >> 2;
+        // (s_setprio 1 for waves 4-7, or around phase 2's softmax section, measured: 72.2 / 71.9 us against 71.4 without)
+        const bool tr8 = a.trace && blockIdx.x == 0 && blockIdx.y == 0 && (tid & 255) == 0 && nt <= 15;   // waves 0 and 4
+        for (int iv = 0; iv <= 2 * nt; ++iv) {
+            if (tr8) a.trace[4 * iv + 2 * grp] = __builtin_amdgcn_s_memrealtime();                        // interval start
+            if (iv & 1) {
+                const int j = (iv + 1) >> 1;                       // tile (relative) to stage now
+                if (j < nt) {
+                    commit(j & 1);
+                    ring_commit(j);
+                    if (j + 1 < nt) {
+                        prefetch(kt_begin + j + 1);
+                        ring_load(j + 1);
+                    }
+                }
+            }
+            const int st = iv - grp;
+            if (active && st >= 0 && st < 2 * nt) {
+                const int kt = kt_begin + (st >> 1);
+                if (st & 1) phase2(kt); else phase1(kt);
+            }
+            if (tr8) a.trace[4 * iv + 2 * grp + 1] = __builtin_amdgcn_s_memrealtime();                    // this wave's phase done
+            if (iv < 2 * nt) __syncthreads();
+        }
     }
 #undef ATT_STAMP
+    if (tracer) a.trace[11] = __builtin_amdgcn_s_memrealtime();          // key loop done
 
     // ---- normalise and store: lane = query row, registers = head dims (4 consecutive dims per r>>2 group)
     if (active && i0 + li < a.q_end) {
@@ -305,6 +430,10 @@ __global__ __launch_bounds__(256, 2) void relpos_attn_fwd_kernel(const AttnArgs 
         } else if (a.lse && hf == 0) {
             a.lse[((int64_t)b * a.H + h) * T + i0 + li] = mrow + logf(lrow);
         }
+    }
+    if (tracer) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        a.trace[12] = __builtin_amdgcn_s_memrealtime();                  // output stores drained
     }
 }
 
@@ -344,14 +473,27 @@ static int attention_launch(const float* q, const float* k, const float* v, int6
                             cfm_stream_t stream, void* trace = nullptr, int q_begin = 0, int q_count = -1, int nsplit = 1,
                             float* workspace = nullptr);
 
+// diagnostics (tools/attn_probe.py): force the workgroup shape of the fp32 attention forward (0 = built-in choice | 4 | 8 waves);
+// returns the previous setting.  The two shapes agree to fp32 rounding (the 8-wave form sums its score products in two chains).
+static int g_attn_force_nw = 0;
+extern "C" int cfm_debug_set_attention_waves(int nw) {
+    const int prev = g_attn_force_nw;
+    if (nw == 0 || nw == 4 || nw == 8) g_attn_force_nw = nw;
+    return prev;
+}
+
 // diagnostics only (tools/attn_probe.py trace): as cfm_relpos_attention_fwd_f32, plus s_memrealtime (100 MHz) stamps of
 // wave 0 of workgroup (0,0) at 9 phase boundaries of every key tile: trace[16*tile + phase], 16*ceil(T/32) uint64.
 extern "C" int cfm_debug_attention_trace_f32(const float* q, const float* k, const float* v, int64_t ld, const float* pos,
                                              int64_t ldp, const float* u, const float* vbias,
                                              const int64_t* lengths_or_null, float* ctx, int64_t ldo, int B, int T, int H,
                                              int dh, void* trace, cfm_stream_t stream) {
-    return attention_launch(q, k, v, ld, pos, ldp, u, vbias, lengths_or_null, ctx, ldo, nullptr, B, T, H, dh, 0.f, 0, stream,
-                            trace);
+    const int prev = g_attn_force_nw;
+    if (prev != 8) g_attn_force_nw = 4;                // per-phase stamps: the 4-wave form; cfm_debug_set_attention_waves(8): per-interval stamps
+    const int st = attention_launch(q, k, v, ld, pos, ldp, u, vbias, lengths_or_null, ctx, ldo, nullptr, B, T, H, dh, 0.f, 0, stream,
+                                    trace);
+    g_attn_force_nw = prev;
+    return st;
 }
 
 extern "C" int cfm_relpos_attention_fwd_f32(const float* q, const float* k, const float* v, int64_t ld,
@@ -407,9 +549,13 @@ static int attention_launch(const float* q, const float* k, const float* v, int6
                q_begin, q_begin + q_count, nsplit, workspace,
                workspace ? workspace + (int64_t)nsplit * B * q_count * ldo : nullptr, drop_p, drop_seed,
                static_cast<unsigned long long*>(trace)};
-    const dim3 grid((unsigned)((q_count + 127) / 128) * nsplit, (unsigned)(B * H)), block(256);
+    // 8-wave workgroups (256 query rows, the two halves half a key tile apart) once a launch has more than 128 query rows and
+    // no key split; g_attn_force_nw (diagnostics) overrides
+    const int nw = g_attn_force_nw ? g_attn_force_nw : ((q_count > 128 && nsplit == 1) ? 8 : 4);
+    const dim3 grid((unsigned)((q_count + 32 * nw - 1) / (32 * nw)) * nsplit, (unsigned)(B * H)), block(64 * nw);
     hipStream_t s = static_cast<hipStream_t>(stream);
-#define ATT_LAUNCH(NC, ND) hipLaunchKernelGGL((relpos_attn_fwd_kernel<NC, ND>), grid, block, 0, s, a)
+#define ATT_LAUNCH(NC, ND) do { if (nw == 8) hipLaunchKernelGGL((relpos_attn_fwd_kernel<NC, ND, 8>), grid, block, 0, s, a); \
+                                else hipLaunchKernelGGL((relpos_attn_fwd_kernel<NC, ND, 4>), grid, block, 0, s, a); } while (0)
     if (dh <= 8) ATT_LAUNCH(1, 1);
     else if (dh <= 16) ATT_LAUNCH(2, 1);
     else if (dh <= 32) ATT_LAUNCH(4, 1);

@@ -103,6 +103,8 @@ class ConvolutionSubsampling(nn.Module):
     def out_lengths(lengths: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
         if lengths is None:
             return None
+        if lengths.is_cuda and lengths.dtype == torch.int64:
+            return ops.subsampled_lengths(lengths)          # one launch (four stock elementwise kernels otherwise)
         return torch.div(torch.div(lengths - 1, 2, rounding_mode="floor") - 1, 2, rounding_mode="floor")
 
     def channel_last(self, x: torch.Tensor) -> torch.Tensor:

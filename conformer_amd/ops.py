@@ -250,6 +250,16 @@ def subsampled_length(n: int) -> int:
     return int(_lib.load().cfm_subsampled_length(int(n)))
 
 
+def subsampled_lengths(lengths: torch.Tensor) -> torch.Tensor:
+    """((L-1)//2-1)//2 of an int64 device array (convolution.py:55) in one launch."""
+    lengths = _req(lengths, "lengths", torch.int64)
+    out = torch.empty(lengths.shape, device=lengths.device, dtype=torch.int64)
+    if lengths.numel():
+        _lib.check(_lib.load().cfm_subsampled_lengths_i64(lengths.data_ptr(), out.data_ptr(), lengths.numel(), _stream()),
+                   "cfm_subsampled_lengths_i64")
+    return out
+
+
 # ---- LayerNorm folded into the GEMMs either side of it (fp32 inference; csrc/gemm_f32.hip "LN fold") -------------------------
 _LN_FOLD = __import__("os").environ.get("CONFORMER_AMD_LN_FOLD", "1") != "0"
 

@@ -500,12 +500,18 @@ int cfm_relpos_attention_rows_f32(const float* q, const float* k, const float* v
 int cfm_debug_attention_trace_f32(const float* q, const float* k, const float* v, int64_t ld, const float* pos,
                                   int64_t ldp, const float* u, const float* vbias, const int64_t* lengths_or_null,
                                   float* ctx, int64_t ldo, int B, int T, int H, int dh, void* trace, cfm_stream_t stream);
+/*      force the workgroup shape of the fp32 attention forward: 0 = built-in choice (8 waves = 256 query rows with the two
+ *      halves half a key tile apart once a launch has > 128 query rows; else 4 waves) | 4 | 8; returns the previous setting.
+ *      The two shapes agree to fp32 rounding. */
+int cfm_debug_set_attention_waves(int nw);
 /* diagnostics only (process-global, not thread-safe): force the block tile of cfm_gemm_bwd* (-1 = heuristic) */
 int cfm_debug_set_bwd_tile(int tile);
 
 /* ---- integer helpers of the path (host-side, no device work) ---------------------------------
  *      frames after the stem: ((n-1)/2-1)/2, convolution.py:55 */
 int64_t cfm_subsampled_length(int64_t n);
+/*      the same applied to a device array of B lengths (floor division, negative values included), one launch */
+int cfm_subsampled_lengths_i64(const int64_t* lengths, int64_t* out, int n, cfm_stream_t stream);
 
 #ifdef __cplusplus
 }

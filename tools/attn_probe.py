@@ -30,10 +30,62 @@ if len(sys.argv) > 1 and sys.argv[1] == "trace":
                                                  v.data_ptr(), L.data_ptr(), ctx.data_ptr(), d, B, T, H, d // H, tr.data_ptr(),
                                                  torch.cuda.current_stream().cuda_stream), "trace")
     torch.cuda.synchronize()
-    s = tr.cpu().view(ntiles, 16)[:, :9]
+    raw = tr.cpu().view(ntiles, 16)
+    t_in, t_pro, t_loop, t_out = (int(raw[0, i]) for i in (9, 10, 11, 12))
+    print(f"wave 0 of workgroup (0,0): prologue {(t_pro - t_in) * 10} ns | key loop {(t_loop - t_pro) * 10} ns | "
+          f"normalise + store {(t_out - t_loop) * 10} ns | total {(t_out - t_in) * 10} ns")
+    s = raw[:, :9]
     names = ["stage next K/V", "content mfma", "band mfma+spill", "skew reads", "select+add", "softmax", "PV", "barrier"]
     print("tile | " + " | ".join(names) + " | total   (ns, 100 MHz clock)")
     for kt in range(ntiles):
         dts = [(int(s[kt, i + 1]) - int(s[kt, i])) * 10 for i in range(8)]
         print(f"{kt:4d} | " + " | ".join(f"{x:6d}" for x in dts) + f" | {sum(dts)}")
+if len(sys.argv) > 1 and sys.argv[1] == "trace8":
+    # 8-wave staggered form: per interval, when wave 0 (group A) / wave 4 (group B) start and finish their phase
+    from conformer_amd import _lib
+    lib = _lib.load()
+    lib.cfm_debug_set_attention_waves(8)
+    ntiles = (T + 31) // 32
+    tr = torch.zeros(16 * ntiles, dtype=torch.int64, device=dev)
+    ctx = torch.empty(B, T, d, device=dev)
+    base = qkv.data_ptr()
+    _lib.check(lib.cfm_debug_attention_trace_f32(base, base + 4 * d, base + 8 * d, 3 * d, pos.data_ptr(), d, u.data_ptr(),
+                                                 v.data_ptr(), L.data_ptr(), ctx.data_ptr(), d, B, T, H, d // H, tr.data_ptr(),
+                                                 torch.cuda.current_stream().cuda_stream), "trace")
+    torch.cuda.synchronize()
+    lib.cfm_debug_set_attention_waves(0)
+    t = tr.cpu().tolist()
+    t0 = t[0]
+    print("interval | A: start  phase-end (what) | B: start  phase-end (what)   [ns from the first stamp]")
+    for iv in range(2 * ntiles + 1):
+        a0, a1, b0, b1 = (10 * (t[4 * iv + k] - t0) for k in range(4))
+        wa = ("P1" if iv % 2 == 0 else "P2") + f"(t{iv // 2})" if iv < 2 * ntiles else "-"
+        wb = ("P1" if (iv - 1) % 2 == 0 else "P2") + f"(t{(iv - 1) // 2})" if 1 <= iv else "-"
+        print(f"{iv:3d} | {a0:7d} {a1:7d} {a1 - a0:6d} {wa:8s} | {b0:7d} {b1:7d} {b1 - b0:6d} {wb}")
+if len(sys.argv) > 1 and sys.argv[1] == "ab":
+    # 4-wave (rounds 1-2) vs 8-wave staggered workgroups, interleaved rounds in one process; results must be bit-identical
+    import statistics
+    from conformer_amd import _lib
+    lib = _lib.load()
+    variants = [(4, 0), (8, 0)]                              # (waves, -)
+    outs, times = {}, {vv: [] for vv in variants}
+    for nw in (4, 8):
+        lib.cfm_debug_set_attention_waves(nw)
+        outs[nw] = ops.relpos_attention(qkv, pos, u, v, L, H).clone()
+    print("bit-identical:", bool(torch.equal(outs[4], outs[8])), " rel-L2 difference:", float((outs[4] - outs[8]).norm() / outs[4].norm()))
+    for rnd in range(9):
+        for vv in variants:
+            lib.cfm_debug_set_attention_waves(vv[0])
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(20):
+                ops.relpos_attention(qkv, pos, u, v, L, H)
+            e1.record()
+            torch.cuda.synchronize()
+            times[vv].append(e0.elapsed_time(e1) / 20 * 1e3)
+    lib.cfm_debug_set_attention_waves(0)
+    fl = 6.0 * B * T * T * d
+    for vv in variants:
+        med = statistics.median(times[vv])
+        print(f"{vv[0]} waves: median {med:.1f} us  min {min(times[vv]):.1f} us  {fl / med / 1e6:.1f} TFLOP/s = {fl / med / 1e6 / 157.3:.3f} of the fp32 MFMA peak")
 print("done")

@@ -44,6 +44,12 @@ def main(d, out):
         if w > 0:
             entry["wave_cycle_split"] = {"waiting (s_waitcnt / barrier)": mean("SQ_WAIT_ANY") / w,
                                          "issue stall": mean("SQ_WAIT_INST_ANY") / w, "issuing": mean("SQ_ACTIVE_INST_ANY") / w}
+        known = {"GRBM_GUI_ACTIVE", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY"}
+        extra = sorted({c for v in rows for c in v} - known)
+        if extra:                                  # any further counters of the pass: mean per dispatch (and per wave-cycle)
+            entry["other_counters"] = {c: mean(c) for c in extra}
+            if w > 0:
+                entry["other_counters_per_wave_cycle"] = {c: mean(c) / w for c in extra}
         res[name] = entry
     json.dump(res, open(out, "w"), indent=1)
     for k, v in sorted(res.items(), key=lambda kv: -kv[1].get("avg_us", 0) * kv[1]["launches"])[:14]:
