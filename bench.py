@@ -99,7 +99,30 @@ def gemm_site_table(enc, x, iters):
 
     qkvw, qkvb = att._qkv_params()
     wl = enc.linear.weight
-    sites = [
+    fold = ops.ln_fold_ok(d)
+    posw, posb = torch.cat([att.pos_proj.weight.detach()] * L, 0).contiguous(), torch.cat([att.pos_proj.bias.detach()] * L, 0).contiguous()
+    if fold:
+        # the folded-LayerNorm forms the forward really launches (ops.linear_lnfold consumers, emit_stats producers)
+        _, st = ops.linear_residual(a_d, att.out_proj.weight, att.out_proj.bias, res, 1.0, emit_stats=True)
+        f1, fq, fc = (ops.fold_layernorm(w_, b_, ln.weight, ln.bias) for w_, b_, ln in (
+            (lay.ffn_1.hidden_linear.weight, lay.ffn_1.hidden_linear.bias, lay.ffn_1.layer_norm), (qkvw, qkvb, lay.attention.layer_norm),
+            (lay.conv.pointwise_conv_1.weight, lay.conv.pointwise_conv_1.bias, lay.conv.layer_norm)))
+        sites = [
+            ("gemm<relu,conv>  stem conv2 implicit GEMM", (B * Tp * Fp, d, 9 * d), 1, conv2),
+            ("gemm<bias+stats> input linear", (N, d, Fp * d), 1, lambda: ops.linear(h2, wl, enc.linear.bias, emit_stats=True)),
+            ("gemm<LN,swish>   FFN hidden (LayerNorm folded)", (N, 4 * d, d), 2 * L, lambda: ops.linear_lnfold(a_d, st, *f1, 1e-5, act="swish")),
+            ("gemm<resid+stats> FFN-1 out", (N, d, 4 * d), L,
+             lambda: ops.linear_residual(a_4d, lay.ffn_1.out_linear.weight, lay.ffn_1.out_linear.bias, res, 0.5, emit_stats=True)),
+            ("gemm<residual>   FFN-2 out", (N, d, 4 * d), L,
+             lambda: ops.linear_residual(a_4d, lay.ffn_1.out_linear.weight, lay.ffn_1.out_linear.bias, res, 0.5)),
+            ("gemm<LN,bias>    fused QKV (LayerNorm folded)", (N, 3 * d, d), L, lambda: ops.linear_lnfold(a_d, st, *fq, 1e-5)),
+            ("gemm<bias>       pos proj (all layers, one launch)", (P, L * d, d), 1, lambda: ops.linear(pe, posw, posb)),
+            ("gemm<resid+stats> attn out / pw2", (N, d, d), 2 * L,
+             lambda: ops.linear_residual(a_d, att.out_proj.weight, att.out_proj.bias, res, 1.0, emit_stats=True)),
+            ("gemm<LN,glu>     pw1+GLU (LayerNorm folded)", (N, 2 * d, d), L, lambda: ops.linear_lnfold(a_d, st, *fc, 1e-5, glu=True)),
+        ]
+    else:
+      sites = [
         ("gemm<relu,conv>  stem conv2 implicit GEMM", (B * Tp * Fp, d, 9 * d), 1, conv2),   # pmc: gemm_f32_kernel<128, 128, 2, true>
         ("gemm<bias>       input linear", (N, d, Fp * d), 1, lambda: ops.linear(h2, wl, enc.linear.bias)),
         ("gemm<swish>      FFN hidden", (N, 4 * d, d), 2 * L,
@@ -112,7 +135,7 @@ def gemm_site_table(enc, x, iters):
          lambda: ops.linear_residual(a_d, att.out_proj.weight, att.out_proj.bias, res, 1.0)),
         ("gemm<glu>        pw1+GLU", (N, 2 * d, d), L,
          lambda: ops.linear_glu(a_d, lay.conv.pointwise_conv_1.weight, lay.conv.pointwise_conv_1.bias)),
-    ]
+      ]
     rows = []
     for name, (m, n, k), per_step, fn in sites:
         avg, med = time_events(fn, max(3, iters // 3), inner=2 if "conv2" in name else 10)
@@ -121,7 +144,7 @@ def gemm_site_table(enc, x, iters):
         row = dict(kernel=name, M=m, N=n, K=k, launches_per_step=per_step, avg_ms=avg, med_ms=med,
                    tflops=fl / (avg * 1e-3) / 1e12, flops=fl)
         if "conv2" in name:
-            row["pmc_name"] = "gemm_f32_kernel<128, 128, 2, true>"
+            row["pmc_name"] = "gemm_f32_kernel<128, 128, 2, true"
             # h1 read once + packed weight + h2 written (the stem's ideal traffic)
             row["alg_bytes"] = 4.0 * (B * T1 * F1 * d + 9 * d * d + B * Tp * Fp * d)
         rows.append(row)
@@ -152,14 +175,14 @@ def cpu_baseline(enc, sample_b):
     log(f"[bench] cpu_baseline: oracle on {cores} threads (os.cpu_count()={os.cpu_count()}), B={sample_b}")
     ts = []
     with torch.no_grad():
-        for i in range(3):
+        for i in range(4):                                  # 1 warm-up + 3 timed runs, median
             t0 = time.perf_counter()
             O.encoder_forward(x, L, P, CFG["n_blocks"], CFG["n_heads"])
             ts.append(time.perf_counter() - t0)
-    t = sorted(ts[1:])[0] if len(ts) > 1 else ts[0]
+    t = sorted(ts[1:])[1]
     return dict(value=sample_b * CFG["T"] / t, unit="audio-frames/sec", cores=cores, kind="port",
-                sample=f"oracle Encoder.forward fp32 on the same weights, B={sample_b} of 32, T=1000, 16 blocks, best of 2 after 1 warm-up "
-                       f"({t:.2f} s/run, torch {torch.get_num_threads()} threads)")
+                sample=f"oracle Encoder.forward fp32 on the same weights, B={sample_b} of 32, T=1000, 16 blocks, median of 3 after 1 warm-up "
+                       f"({t:.2f} s/run; runs {', '.join(f'{v:.2f}' for v in ts[1:])} s; torch {torch.get_num_threads()} threads)")
 
 
 def pmc_traffic_bytes(kernel_substr: str):
@@ -175,6 +198,23 @@ def pmc_traffic_bytes(kernel_substr: str):
     for name, v in table.items():
         if kernel_substr in name:
             return v["hbm_bytes_per_launch"]
+    return None
+
+
+def pmc_mfma_row(kernel_substr: str):
+    """Matrix-pipe utilisation of a kernel from the committed counter pass of the latest round (tools/pmc_mfma.py ->
+    profiles/rNN_pmc_mfma.json: SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8) and the wave-cycle split)."""
+    import glob
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_mfma.json")))
+    try:
+        table = json.load(open(paths[-1]))
+    except (OSError, ValueError, IndexError):
+        return None
+    for name, v in table.items():
+        if kernel_substr in name:
+            return {"mfma_util": round(v["mfma_util"], 4), "effective_clock_ghz": round(v.get("effective_clock_ghz", 0.0), 3),
+                    "avg_us_under_counters": round(v.get("avg_us", 0.0), 1),
+                    "wave_cycle_split": {k: round(x, 3) for k, x in v.get("wave_cycle_split", {}).items()}, "source": os.path.basename(paths[-1])}
     return None
 
 
@@ -426,6 +466,11 @@ def main():
     y = last["y"]
     if not torch.isfinite(y).all():
         raise SystemExit("non-finite encoder output")
+    n0 = _lib.CALLS[0]
+    with torch.no_grad(), amp():
+        enc(x, lengths)                                        # one eager forward, untimed: how many kernels the path launches
+    torch.cuda.synchronize()
+    launches = _lib.CALLS[0] - n0
 
     frames = world * CFG["B"] * CFG["T"] * args.steps
     ms = dt / args.steps * 1e3
@@ -443,6 +488,7 @@ def main():
         "config": {"workload": "cfg2 Conformer-L Encoder.forward: B=32/GPU, T=1000 mel frames (T'=249), d=512, 16 blocks, "
                                "8 heads, k=31, fp32, eval, random-init weights, batch-sharded replicas",
                    "per_gpu_batch": CFG["B"], "mel_frames": CFG["T"]},
+        "kernel_launches_per_forward": launches, "layernorm_folded_into_gemms": bool(ops.ln_fold_ok(CFG["d"])) and args.dtype == "f32",
         "path_tflops": flops / (ms * 1e-3) / 1e12,
         "path_frac_of_mfma_f32_peak": flops / (ms * 1e-3) / 1e12 / PEAK_MFMA_F32_TFLOPS,
     }
@@ -458,6 +504,10 @@ def main():
             "traffic": pmc_traffic_bytes(dom["pmc_name"]) if dom.get("pmc_name") else None,
             "traffic_unit": "HBM bytes per launch (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE, latest profiles/rNN_pmc_traffic.json)",
             "algorithmic_bytes": dom.get("alg_bytes"),
+            "mfma_util": (pmc_mfma_row(dom["pmc_name"]) or {}).get("mfma_util") if dom.get("pmc_name") else None,
+            "pmc": {"dominant": pmc_mfma_row(dom["pmc_name"]) if dom.get("pmc_name") else None,
+                    "attention_forward": pmc_mfma_row("relpos_attn_fwd_kernel"),
+                    "ffn_hidden_gemm": pmc_mfma_row("gemm_f32_kernel<128, 64, 1, false")},
             "avg_launch_ms": dom["avg_ms"], "launches_per_step": dom["launches_per_step"],
             "gemm_ms_per_step": tot, "gemm_share_of_step": tot / ms,
             "all_gemm_sites": [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in r.items()

@@ -167,7 +167,11 @@ class CastItem(ctypes.Structure):
                 ("transpose", ctypes.c_int)]
 
 
+CALLS = [0]          # C-ABI calls checked so far (bench.py reports the count of one forward: one call = one kernel launch there)
+
+
 def check(status: int, what: str) -> None:
+    CALLS[0] += 1
     if status != 0:
         msg = load().cfm_strerror(status).decode()
         raise ConformerHipError(f"{what} failed: {msg} (status {status})")

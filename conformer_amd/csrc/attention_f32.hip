@@ -213,10 +213,8 @@ __global__ __launch_bounds__(64 * NW, 2) void relpos_attn_fwd_kernel(const AttnA
                 else ga = __builtin_amdgcn_mfma_f32_32x32x2f32(f[e], qv[4 * c + e], ga, 0, 0, 0);
             }
         }
-        if constexpr (NC > 1) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) ga[r] += gb[r];
-        }
+        for (int r = 0; r < 16; ++r) ga[r] += gb[r];
         return ga;
     };
     auto spill_band = [&](const f32x16& ga) {

@@ -25,7 +25,9 @@ namespace {
 // CONV: 0 plain rows; 1 the stem's 3x3 / stride-2 im2col gather (forward conv2); 2 a parity class of its transposed conv (the
 // input gradient of conv2): row = class position (b, a, c), K-tile = a tap (dt, df) of dz2 -- rows whose tap falls outside dz2
 // are zero (per-row validity, re-derived when the tap changes), output rows are scattered to the class's dh1 positions.
-template <typename T16, int BM, int BN, int EPI, int CONV, bool W16, bool A16 = false, int WM = 2>
+// F: epilogue flags (gemm_shared.h EPF_*).  EPF_NO_DROPOUT: the launcher picks the mask-free instantiation whenever drop_p == 0
+// (inference, and training without dropout) -- the mask generation was most of a 30-55 KB kernel whose epilogue is fetched cold.
+template <typename T16, int BM, int BN, int EPI, int CONV, bool W16, bool A16 = false, int WM = 2, int F = 0>
 __global__ __launch_bounds__(WM * 128, 2) void gemm_mfma16_kernel(const GemmArgs g) {
     static_assert(!A16 || W16, "16-bit A operand comes together with 16-bit weights");
     using x8 = typename Lowp<T16>::x8;
@@ -249,7 +251,7 @@ __global__ __launch_bounds__(WM * 128, 2) void gemm_mfma16_kernel(const GemmArgs
     static_assert(EPI != EPI_GLU || WM == 2, "GLU tiles: 2x2 waves");
     {                                                        // (the K-loop ended on a __syncthreads: the staging buffers are free)
         static_assert(2 * WM * 32 * (32 * TN + 4) * 4 <= 2 * (BM + BN) * ROWB * 2, "row-major epilogue scratch must fit the staging LDS");
-        gemm_epilogue_rows<BM, BN, EPI, TM, TN, WM, CONV == 2>(g, acc, m0, n0, wr, wc, lane, reinterpret_cast<float*>(lds) + wave * 32 * (32 * TN + 4));
+        gemm_epilogue_rows<BM, BN, EPI, TM, TN, WM, CONV == 2, F>(g, acc, m0, n0, wr, wc, lane, reinterpret_cast<float*>(lds) + wave * 32 * (32 * TN + 4));
     }
     if (tracer) {
         tr[62] = __builtin_amdgcn_s_memrealtime();                       // epilogue issued
@@ -265,9 +267,21 @@ int launch_cfg(GemmArgs g, int src16, hipStream_t s) {          // src16: 0 = fp
     g.tiles_m = (unsigned)((g.M + BM - 1) / BM);
     g.tiles_n = (unsigned)((ncols + bn - 1) / bn);
     const dim3 grid(g.tiles_m * g.tiles_n);
-    if (src16 == 2) hipLaunchKernelGGL((gemm_mfma16_kernel<T16, BM, BN, EPI, CONV, true, true>), grid, dim3(256), 0, s, g);
-    else if (src16 == 1) hipLaunchKernelGGL((gemm_mfma16_kernel<T16, BM, BN, EPI, CONV, true>), grid, dim3(256), 0, s, g);
-    else if (src16 == 0) hipLaunchKernelGGL((gemm_mfma16_kernel<T16, BM, BN, EPI, CONV, false>), grid, dim3(256), 0, s, g);
+    // dropout only exists for the bias / Swish / residual epilogues of the training forward (and, as a mask replay, in EPI_DSWISH)
+    constexpr bool CAN_DROP = EPI == EPI_BIAS || EPI == EPI_SWISH || EPI == EPI_RESID;
+    constexpr int FN = EPI == EPI_DSWISH ? 0 : EPF_NO_DROPOUT;
+    if (CAN_DROP && g.drop_p > 0.f) {
+        if constexpr (CAN_DROP) {
+            if (src16 == 2) hipLaunchKernelGGL((gemm_mfma16_kernel<T16, BM, BN, EPI, CONV, true, true, 2, 0>), grid, dim3(256), 0, s, g);
+            else if (src16 == 1) hipLaunchKernelGGL((gemm_mfma16_kernel<T16, BM, BN, EPI, CONV, true, false, 2, 0>), grid, dim3(256), 0, s, g);
+            else if (src16 == 0) hipLaunchKernelGGL((gemm_mfma16_kernel<T16, BM, BN, EPI, CONV, false, false, 2, 0>), grid, dim3(256), 0, s, g);
+            else return CFM_ERR_UNSUPPORTED;
+        }
+        return cfm_launch_status();
+    }
+    if (src16 == 2) hipLaunchKernelGGL((gemm_mfma16_kernel<T16, BM, BN, EPI, CONV, true, true, 2, FN>), grid, dim3(256), 0, s, g);
+    else if (src16 == 1) hipLaunchKernelGGL((gemm_mfma16_kernel<T16, BM, BN, EPI, CONV, true, false, 2, FN>), grid, dim3(256), 0, s, g);
+    else if (src16 == 0) hipLaunchKernelGGL((gemm_mfma16_kernel<T16, BM, BN, EPI, CONV, false, false, 2, FN>), grid, dim3(256), 0, s, g);
     else return CFM_ERR_UNSUPPORTED;
     return cfm_launch_status();
 }
@@ -283,12 +297,21 @@ int launch_big(GemmArgs g, int src16, hipStream_t s) {          // 512-thread wo
     g.tiles_m = (unsigned)((g.M + BM - 1) / BM);
     g.tiles_n = (unsigned)((g.N + BN - 1) / BN);
     const dim3 grid(g.tiles_m * g.tiles_n);
+    constexpr bool CAN_DROP = EPI == EPI_BIAS || EPI == EPI_SWISH || EPI == EPI_RESID;
+    constexpr int FN = EPI == EPI_DSWISH ? 0 : EPF_NO_DROPOUT;
     if constexpr (CONV != 0) {
-        if (src16 == 2) hipLaunchKernelGGL((gemm_mfma16_kernel<T16, BM, BN, EPI, CONV, true, true, 4>), grid, dim3(512), 0, s, g);
-        else hipLaunchKernelGGL((gemm_mfma16_kernel<T16, BM, BN, EPI, CONV, true, false, 4>), grid, dim3(512), 0, s, g);
+        if (src16 == 2) hipLaunchKernelGGL((gemm_mfma16_kernel<T16, BM, BN, EPI, CONV, true, true, 4, FN>), grid, dim3(512), 0, s, g);
+        else hipLaunchKernelGGL((gemm_mfma16_kernel<T16, BM, BN, EPI, CONV, true, false, 4, FN>), grid, dim3(512), 0, s, g);
     } else {
-        if (src16 == 2) hipLaunchKernelGGL((gemm_mfma16_kernel<T16, BM, BN, EPI, 0, true, true, 4>), grid, dim3(512), 0, s, g);
-        else hipLaunchKernelGGL((gemm_mfma16_kernel<T16, BM, BN, EPI, 0, true, false, 4>), grid, dim3(512), 0, s, g);
+        if (CAN_DROP && g.drop_p > 0.f) {
+            if constexpr (CAN_DROP) {
+                if (src16 == 2) hipLaunchKernelGGL((gemm_mfma16_kernel<T16, BM, BN, EPI, 0, true, true, 4, 0>), grid, dim3(512), 0, s, g);
+                else hipLaunchKernelGGL((gemm_mfma16_kernel<T16, BM, BN, EPI, 0, true, false, 4, 0>), grid, dim3(512), 0, s, g);
+            }
+            return cfm_launch_status();
+        }
+        if (src16 == 2) hipLaunchKernelGGL((gemm_mfma16_kernel<T16, BM, BN, EPI, 0, true, true, 4, FN>), grid, dim3(512), 0, s, g);
+        else hipLaunchKernelGGL((gemm_mfma16_kernel<T16, BM, BN, EPI, 0, true, false, 4, FN>), grid, dim3(512), 0, s, g);
     }
     return cfm_launch_status();
 }
