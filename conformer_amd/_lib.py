@@ -22,6 +22,7 @@ SIGNATURES = {
     "cfm_abi_version": (c_int, []),
     "cfm_gemm_bias_stats_f32": (c_int, [_P, _P, _P, _P, _P, _L, _I, _I, _L, _L, _P]),
     "cfm_gemm_bias_residual_stats_f32": (c_int, [_P, _P, _P, _P, _F, _P, _P, _L, _I, _I, _L, _L, _L, _P]),
+    "cfm_gemm_splitk_f32": (c_int, [_I, _P, _P, _P, _P, _F, _P, _P, _I, _L, _I, _I, _L, _L, _L, _P]),
     "cfm_gemm_lnfold_f32": (c_int, [_I, _P, _P, _I, _F, _P, _P, _P, _P, _L, _I, _I, _L, _L, _P]),
     "cfm_layernorm_fwd_stats_f32": (c_int, [_P, _P, _P, _P, _P, _L, _I, _F, _P]),
     "cfm_strerror": (c_char_p, [_I]),

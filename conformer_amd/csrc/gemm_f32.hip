@@ -62,6 +62,10 @@ void gemm_f32_kernel(const GemmArgs g) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
     const int li = lane & 31, hf = lane >> 5;
+    // split-K stage (small M, long K: a wave that owns a whole-K output tile runs K / 2 dependent MFMAs however few tiles there
+    // are): slice blockIdx.y contracts [koff, koff + Kloc) and stores its raw partial tile into slab y
+    const int koff = g.ksplit_len > 0 ? (int)blockIdx.y * g.ksplit_len : 0;
+    const int Kloc = g.ksplit_len > 0 ? min(g.ksplit_len, g.K - koff) : g.K;
     if (g.trace && tid == 0) {                             // diagnostics only (tools/gemm_tune.py trace)
         g.trace[8 * blockIdx.x + 0] = __builtin_amdgcn_s_memrealtime();
         g.trace[8 * blockIdx.x + 2] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_ID
@@ -74,16 +78,16 @@ void gemm_f32_kernel(const GemmArgs g) {
     const float* a_ptr[PA];
     const float* w_ptr[PB];
 #pragma unroll
-    for (int i = 0; i < PA; ++i) a_ptr[i] = a_row_ptr<CONV>(g, m0 + srow + RPP * i);
+    for (int i = 0; i < PA; ++i) a_ptr[i] = a_row_ptr<CONV>(g, m0 + srow + RPP * i) + (CONV ? 0 : koff);
 #pragma unroll
-    for (int i = 0; i < PB; ++i) w_ptr[i] = w_row_ptr<EPI, BN>(g, n0, srow + RPP * i);
+    for (int i = 0; i < PB; ++i) w_ptr[i] = w_row_ptr<EPI, BN>(g, n0, srow + RPP * i) + koff;
 
-    const int nkt = (g.K + BK - 1) / BK;
+    const int nkt = (Kloc + BK - 1) / BK;
     f32x4 ra0[PA], rb0[PB], ra1[BK == 16 ? PA : 1], rb1[BK == 16 ? PB : 1];   // BK = 16: two staging sets (tiles t+1 and t+2 in flight)
     auto load_tile = [&](auto& ra, auto& rb, int kt) {
         const int k = kt * BK + chunk * 4;
         const int64_t aoff = a_k_offset<CONV>(g, kt * BK) + chunk * 4;
-        const bool ok = k < g.K;
+        const bool ok = k < Kloc;
 #pragma unroll
         for (int i = 0; i < PA; ++i)
             ra[i] = ok ? *reinterpret_cast<const f32x4*>(a_ptr[i] + aoff) : f32x4{0.f, 0.f, 0.f, 0.f};
@@ -233,7 +237,12 @@ void gemm_f32_kernel(const GemmArgs g) {
 
     // row-major write-out through a per-wave LDS tile (whole 256-byte row segments per store instruction) where the dead
     // staging buffers can hold it; the GLU tile pairs value and gate columns in one wave and stores straight from the accumulators
-    if constexpr (ROWS) {
+    if constexpr ((F & EPF_NO_BIAS) != 0) {                // split-K stage: this slice's slab
+        GemmArgs gl = g;
+        gl.C = g.C + (int64_t)blockIdx.y * g.M * g.ldc;
+        __syncthreads();
+        gemm_epilogue_rows<BM, BN, EPI, TM, TN, 2, false, F>(gl, acc, m0, n0, wr, wc, lane, lds + wave * 32 * (32 * TN + 4), rowstats);
+    } else if constexpr (ROWS) {
         __syncthreads();                                   // every wave is done reading the staging buffers
         gemm_epilogue_rows<BM, BN, EPI, TM, TN, 2, false, F>(g, acc, m0, n0, wr, wc, lane, lds + wave * 32 * (32 * TN + 4), rowstats);
     } else {
@@ -278,7 +287,8 @@ int launch_cfg(GemmArgs g, hipStream_t s) {
         const int per = (160 * 1024) / g.occ_cap;
         pad = per > kStatic ? (size_t)((per - kStatic) & ~255) : 0;
     }
-    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, EPI, CONV, LN, BK>), dim3(g.tiles_m * g.tiles_n), dim3(256), pad, s, g);
+    const unsigned gy = g.ksplit_len > 0 ? (unsigned)((g.K + g.ksplit_len - 1) / g.ksplit_len) : 1u;
+    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, EPI, CONV, LN, BK>), dim3(g.tiles_m * g.tiles_n, gy), dim3(256), pad, s, g);
     return cfm_launch_status();
 }
 
@@ -407,6 +417,61 @@ extern "C" int cfm_gemm_bias_residual_f32(const float* A, const float* W, const 
     CFM_REQUIRE(R != nullptr, CFM_ERR_NULL);
     CFM_REQUIRE(ldc >= N && ldr >= N, CFM_ERR_BAD_SHAPE);
     return launch<EPI_RESID, false, EPF_INFER>(g, static_cast<hipStream_t>(stream));
+}
+
+// ---- split-K for small M (streaming chunks, short utterances) --------------------------------------------------------
+// out = epi(sum_s slab_s + bias): the slabs are summed in a fixed order (bit-reproducible), four columns per thread
+namespace {
+template <int EPI>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slabs, int splits, const float* __restrict__ bias,
+                                                            const float* __restrict__ R, float alpha, float* __restrict__ C,
+                                                            int64_t M, int N, int64_t ldr, int64_t ldc) {
+    const int n4 = N >> 2;
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= M * n4) return;
+    const int64_t row = idx / n4;
+    const int col = (int)(idx - row * n4) * 4;
+    f32x4 acc = *reinterpret_cast<const f32x4*>(slabs + row * N + col);
+    for (int s = 1; s < splits; ++s) acc = acc + *reinterpret_cast<const f32x4*>(slabs + ((int64_t)s * M + row) * N + col);
+    acc = acc + *reinterpret_cast<const f32x4*>(bias + col);
+    if (EPI == EPI_SWISH) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] = swishf_acc(acc[e]);
+    }
+    if (EPI == EPI_RESID) acc = alpha * acc + *reinterpret_cast<const f32x4*>(R + row * ldr + col);
+    *reinterpret_cast<f32x4*>(C + row * ldc + col) = acc;
+}
+}  // namespace
+
+// C = epi(A.W^T + bias) with the contraction split into `splits` slices over gridDim.y (each a workgroup per output tile, raw partial
+// tiles into workspace (splits, M, N) fp32) and one reduce + epilogue pass.  epi: 0 bias | 1 +swish | 4 alpha*y + R.
+// N % 4 == 0, ldc / ldr % 4 == 0, 16-byte aligned C / R / bias / workspace.  For products whose M gives fewer 64x64 tiles than
+// the chip has CUs while K is long (FFN out at M = 1280: 63 -> ~25 us).
+extern "C" int cfm_gemm_splitk_f32(int epi, const float* A, const float* W, const float* bias, const float* R_or_null,
+                                   float alpha, float* C, float* workspace, int splits, int64_t M, int N, int K,
+                                   int64_t lda, int64_t ldr, int64_t ldc, cfm_stream_t stream) {
+    GEMM_ARGS_PLAIN(N);
+    int st = check(g); if (st) return st;
+    CFM_REQUIRE(workspace != nullptr, CFM_ERR_NULL);
+    CFM_REQUIRE(splits >= 2 && splits <= 16 && ldc >= N && (N & 3) == 0 && (ldc & 3) == 0, CFM_ERR_BAD_SHAPE);
+    CFM_REQUIRE(CFM_ALIGNED16(C) && CFM_ALIGNED16(bias) && CFM_ALIGNED16(workspace), CFM_ERR_ALIGN);
+    CFM_REQUIRE(epi == EPI_BIAS || epi == EPI_SWISH || epi == EPI_RESID, CFM_ERR_UNSUPPORTED);
+    if (epi == EPI_RESID) {
+        CFM_REQUIRE(R_or_null != nullptr, CFM_ERR_NULL);
+        CFM_REQUIRE(ldr >= N && (ldr & 3) == 0 && CFM_ALIGNED16(R_or_null), CFM_ERR_BAD_SHAPE);
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    g.ksplit_len = ((K + splits - 1) / splits + 15) / 16 * 16;
+    g.C = workspace; g.ldc = N;
+    st = launch<EPI_BIAS, false, EPF_INFER | EPF_NO_BIAS>(g, s, 3);            // 64x64 tiles: the most workgroups
+    if (st) return st;
+    const int nsl = (K + g.ksplit_len - 1) / g.ksplit_len;
+    const int64_t total = M * (N >> 2);
+    const dim3 grid((unsigned)((total + 255) / 256)), block(256);
+    if (epi == EPI_BIAS) hipLaunchKernelGGL(splitk_reduce_kernel<EPI_BIAS>, grid, block, 0, s, workspace, nsl, bias, R_or_null, alpha, C, M, N, ldr, ldc);
+    else if (epi == EPI_SWISH) hipLaunchKernelGGL(splitk_reduce_kernel<EPI_SWISH>, grid, block, 0, s, workspace, nsl, bias, R_or_null, alpha, C, M, N, ldr, ldc);
+    else hipLaunchKernelGGL(splitk_reduce_kernel<EPI_RESID>, grid, block, 0, s, workspace, nsl, bias, R_or_null, alpha, C, M, N, ldr, ldc);
+    return cfm_launch_status();
 }
 
 // ---- LayerNorm folded into its neighbours (inference) ---------------------------------------------------------------

@@ -10,8 +10,9 @@ enum Epi { EPI_BIAS = 0, EPI_SWISH = 1, EPI_RELU = 2, EPI_GLU = 3, EPI_RESID = 4
 //   EPF_LN_CONSUME / EPF_LN_PRODUCE  the folded-LayerNorm roles (see gemm_epilogue_apply);
 //   EPF_NO_DROPOUT                   no dropout mask code (g.drop_p is ignored: the entry point guarantees it is 0);
 //   EPF_F32_OUT                      C (and Z) are fp32: the 8-column 16-bit write-out path is not compiled.
+//   EPF_NO_BIAS                      the accumulators are stored as they are (split-K partial slabs)
 enum EpiFlags { EPF_LN_CONSUME = 1, EPF_LN_PRODUCE = 2, EPF_LN_MASK = 3, EPF_NO_DROPOUT = 4, EPF_F32_OUT = 8,
-                EPF_INFER = EPF_NO_DROPOUT | EPF_F32_OUT };
+                EPF_INFER = EPF_NO_DROPOUT | EPF_F32_OUT, EPF_NO_BIAS = 16 };
 // EPI_DSWISH (16-bit kernels, backward): C = alpha * acc * swish'(Z) [* the forward's dropout mask]; Z = g.Zsave (READ, leading
 // dimension g.ldr, type g.z_prec), no bias.  Vectorised epilogue only (the entry point checks the alignment conditions).
 
@@ -35,6 +36,8 @@ struct GemmArgs {
     const float* ln_stats;          // consumer (LN == 1): [M][ln_parts][2] partials of the UN-normalised A rows (equal column counts)
     const float* ln_colsum;         // consumer: colsum[n] = sum_k W'[n,k], W' = W.diag(gamma) (GLU: value rows then gate rows)
     int ln_parts; float ln_eps;
+    int ksplit_len;                 // fp32 kernel, split-K stage: > 0 = gridDim.y slices of this many contraction steps, slice y writes
+                                    // its raw partial products to C + y * M * ldc (summed by splitk_reduce_kernel)
 };
 
 // ---- shared pieces --------------------------------------------------------------------------------------------
@@ -112,7 +115,8 @@ __device__ __forceinline__ void gemm_epilogue_fetch_bias(const GemmArgs& g, int 
     constexpr int LN = F & EPF_LN_MASK;
     const int ncols = EPI == EPI_GLU ? g.n_out : g.N;
     const int cc = col < ncols ? col : 0;                              // (groups beyond the last column are never stored)
-    if (EPI != EPI_DSWISH) o.bb = *reinterpret_cast<const f32x4*>(g.bias + cc);
+    if (F & EPF_NO_BIAS) o.bb = f32x4{0.f, 0.f, 0.f, 0.f};
+    else if (EPI != EPI_DSWISH) o.bb = *reinterpret_cast<const f32x4*>(g.bias + cc);
     if (EPI == EPI_GLU) o.bg = *reinterpret_cast<const f32x4*>(g.bias + g.n_out + cc);
     if constexpr (LN == 1) {
         o.cs = *reinterpret_cast<const f32x4*>(g.ln_colsum + cc);

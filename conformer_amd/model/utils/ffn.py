@@ -49,6 +49,12 @@ class FeedForwardModule(nn.Module):
         else:
             h = ops.layernorm(x, self.layer_norm.weight, self.layer_norm.bias, self.layer_norm.eps, for_gemm=True)
             h = ops.linear(h, self.hidden_linear.weight, self.hidden_linear.bias, act="swish", for_gemm=True)
+        if emit_stats and ops._splitk(h.numel() // h.shape[-1], self.out_linear.out_features, self.out_linear.in_features):
+            # small M (a streaming chunk): the split-K form of this long-K product is worth more than the statistics its epilogue
+            # could emit -- the next sub-layer then runs its LayerNorm kernel (stats = None)
+            o = ops.linear(h, self.out_linear.weight, self.out_linear.bias) if residual is None else \
+                ops.linear_residual(h, self.out_linear.weight, self.out_linear.bias, residual, alpha)
+            return o, None
         if residual is None:
             if emit_stats:
                 return ops.linear(h, self.out_linear.weight, self.out_linear.bias, emit_stats=True)

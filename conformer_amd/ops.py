@@ -346,6 +346,26 @@ def _gemm_common(a: torch.Tensor, w: torch.Tensor, b: torch.Tensor):
     return a, w2, b, m, w2.shape[0], k
 
 
+def _splitk(m: int, n: int, k: int) -> int:
+    """Contraction slices for the native fp32 GEMM at SMALL M (0 = the ordinary kernel): when the product has fewer 64x64 tiles
+    than the chip has CUs and K is long, every wave would run K/2 dependent MFMAs on a mostly idle chip (FFN out of a streaming
+    chunk, M = 1280: 160 tiles, 63 us); the split form gives ~2-4 workgroups per CU and sums the partial tiles in a fixed order."""
+    tiles = ((m + 63) // 64) * ((n + 63) // 64)
+    if tiles > 192 or k < 1024 or n % 4 or m < 1:
+        return 0
+    return max(2, min(8, k // 512, -(-768 // tiles)))
+
+
+def _splitk_gemm(epi: int, a, w2, b, c, m, n, k, res=None, alpha: float = 1.0):
+    sp = _splitk(m, n, k)
+    if not sp or a.dtype != torch.float32 or c.dtype != torch.float32 or _fp32_planes or mfma16_prec():
+        return None
+    ws = torch.empty(sp * m * n, device=a.device, dtype=torch.float32)
+    _lib.check(_lib.load().cfm_gemm_splitk_f32(epi, a.data_ptr(), w2.data_ptr(), b.data_ptr(), _p(res), alpha, c.data_ptr(),
+                                               ws.data_ptr(), sp, m, n, k, k, n, n, _stream()), "cfm_gemm_splitk_f32")
+    return c
+
+
 def linear(a, w, b, act: str = "none", for_gemm: bool = False, emit_stats: bool = False):
     """y = act(a @ w.T + b); act in {none, swish, relu}.  for_gemm: see layernorm (y feeds a GEMM of contraction length n).
     emit_stats (native fp32, act none, ln_fold_ok(n)): returns (y, stats (rows, n/32, 2)) for a folded LayerNorm of y."""
@@ -364,6 +384,8 @@ def linear(a, w, b, act: str = "none", for_gemm: bool = False, emit_stats: bool 
     if prec:
         return _mfma16_gemm(prec, {"none": 0, "swish": 1, "relu": 2}[act], a, w2, b, c, m, n, k)
     if _split_gemm({"none": 0, "swish": 1, "relu": 2}[act], a, w2, b, c, m, n, k) is not None:
+        return c
+    if act != "relu" and _splitk_gemm({"none": 0, "swish": 1}[act], a, w2, b, c, m, n, k) is not None:
         return c
     fn = {"none": "cfm_gemm_bias_f32", "swish": "cfm_gemm_bias_swish_f32", "relu": "cfm_gemm_bias_relu_f32"}[act]
     st = getattr(_lib.load(), fn)(a.data_ptr(), w2.data_ptr(), b.data_ptr(), c.data_ptr(), m, n, k, k, n, _stream())
@@ -405,6 +427,8 @@ def linear_residual(a, w, b, res: torch.Tensor, alpha: float = 1.0, emit_stats: 
     if prec:
         return _mfma16_gemm(prec, 4, a, w2, b, c, m, n, k, res, alpha)
     if _split_gemm(4, a, w2, b, c, m, n, k, res, alpha) is not None:
+        return c
+    if _splitk_gemm(4, a, w2, b, c, m, n, k, res, alpha) is not None:
         return c
     st = _lib.load().cfm_gemm_bias_residual_f32(a.data_ptr(), w2.data_ptr(), b.data_ptr(), res.data_ptr(), alpha,
                                                 c.data_ptr(), m, n, k, k, n, n, _stream())

@@ -74,6 +74,14 @@ int cfm_gemm_bias_residual_f32(const float* A, const float* W, const float* bias
                                float alpha, float* C, int64_t M, int N, int K,
                                int64_t lda, int64_t ldr, int64_t ldc, cfm_stream_t stream);
 
+/* ---- split-K form of the three plain epilogues for SMALL M (streaming chunks: M = 1280): a wave that owns a whole-K output
+ *      tile runs K/2 dependent MFMAs however few tiles the product has, so the contraction is cut into `splits` slices (one
+ *      workgroup per tile and slice, raw partial tiles into workspace (splits, M, N) fp32) and summed in a fixed order by a
+ *      reduce + epilogue pass (bit-reproducible).  epi: 0 bias | 1 +swish | 4 alpha*y + R.  N, ldc, ldr % 4 == 0. */
+int cfm_gemm_splitk_f32(int epi, const float* A, const float* W, const float* bias, const float* R_or_null,
+                        float alpha, float* C, float* workspace, int splits, int64_t M, int N, int K,
+                        int64_t lda, int64_t ldr, int64_t ldc, cfm_stream_t stream);
+
 /* ---- LayerNorm folded into the GEMMs either side of it (inference, fp32 MFMA): the LayerNorms in front of the FFN, the
  *      attention projections and pointwise_conv_1 (ffn.py:16, attention.py:15, convolution.py:22) leave the launch list.
  *      Producer side: the GEMM (or LayerNorm) that WRITES a residual-stream row also writes its statistics partials,

@@ -129,3 +129,24 @@ def test_incremental_attention_rows_and_key_split(dev, T, q_begin, q_count, lens
         ops.relpos_attention_rows(qkv, pos, u, v, L, H, q_begin, q_count, ctx, keys_hint=hint)
         assert rel_l2(ctx[:, q_begin:q_begin + q_count], full[:, q_begin:q_begin + q_count]) < 2e-6
         assert torch.isnan(ctx[:, :q_begin]).all() and torch.isnan(ctx[:, q_begin + q_count:]).all()   # other rows untouched
+
+
+def test_graphed_chunk_steps_equal_eager(dev):
+    """StreamingEncoder(graphs=True): one hipGraph per distinct chunk step, captured on the first pass and replayed on the next
+    utterance batch -- same frames as the eager launches, for both passes (the state buffers are fixed, the graph's are not)."""
+    from conformer_amd.streaming import StreamingEncoder
+    P = O.make_params(vocab=8, n_mel=80, n_blocks=2, d=64, n_heads=4, ksize=31, lstm_hidden=8, seed=13, with_decoder=False)
+    enc = _encoder(P, 80, 2, 64, 4, 31, dev)
+    chunks = [70, 5, 64, 64, 1, 130]
+    T = sum(chunks)
+    xs = [torch.randn(2, 80, T, device=dev, generator=torch.Generator(device=dev).manual_seed(s)) for s in (1, 2)]
+    eager, graphed = StreamingEncoder(enc, 2, T), StreamingEncoder(enc, 2, T, graphs=True)
+    for x in xs:                                        # pass 1 captures, pass 2 replays
+        eager.reset(); graphed.reset()
+        t0 = 0
+        for c in chunks:
+            a, b = eager.step(x[:, :, t0:t0 + c]), graphed.step(x[:, :, t0:t0 + c])
+            assert a.shape == b.shape and torch.equal(a, b)
+            t0 += c
+        assert eager.frames == graphed.frames and eager.tail_len == graphed.tail_len
+    assert len(graphed._graphs) == sum(1 for _ in graphed._graphs) >= 4

@@ -21,14 +21,15 @@ def main():
     ap.add_argument("--frames", type=int, default=20000)
     ap.add_argument("--chunk", type=int, default=640)
     ap.add_argument("--repeats", type=int, default=3)
+    ap.add_argument("--graphs", action="store_true", help="replay one captured hipGraph per chunk step (StreamingEncoder(graphs=True))")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
     enc = Encoder(80, 16, 512, 8, 31, 0.0).to(dev).eval()
     x = torch.randn(args.batch, 80, args.frames, device=dev)
-    st = StreamingEncoder(enc, args.batch, args.frames)
+    st = StreamingEncoder(enc, args.batch, args.frames, graphs=args.graphs)
     best, lat = None, None
-    for _ in range(args.repeats + 1):                     # first pass = warm-up (packs, caches)
+    for _ in range(args.repeats + 1):                     # first pass = warm-up (packs, caches; --graphs: the chunk graphs are captured)
         st.reset()
         torch.cuda.synchronize()
         per = []
@@ -49,7 +50,7 @@ def main():
         torch.cuda.synchronize()
         full = time.perf_counter() - t0
     lat_sorted = sorted(lat)
-    print(json.dumps({"what": "cfg-5 streaming encoder: cached K/V + depthwise state", "batch": args.batch,
+    print(json.dumps({"what": "cfg-5 streaming encoder: cached K/V + depthwise state", "launch": "hipGraph per chunk step" if args.graphs else "eager", "batch": args.batch,
                       "mel_frames": args.frames, "chunk": args.chunk, "chunks": len(lat), "encoder_frames": st.frames,
                       "stream_ms": best * 1e3, "frames_per_sec": args.batch * args.frames / best,
                       "realtime_factor_per_stream": (args.frames * 0.010) / best,
