@@ -57,6 +57,8 @@ SIGNATURES = {
     "cfm_subsample_conv1_bwd_d16_f32": (c_int, [_I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "cfm_reflect_pad_f32": (c_int, [_P, _P, _I, _L, _I, _L, _P]),
     "cfm_power_mel_log_f32": (c_int, [_P, _L, _P, _P, _I, _I, _I, _I, _F, _P]),
+    "cfm_power_mel_log_mfma_f32": (c_int, [_P, _L, _P, _P, _I, _I, _I, _I, _I, _F, _P]),
+    "cfm_dft_frames_f32": (c_int, [_P, _P, _P, _L, _I, _I, _I, _P]),
     "cfm_specaugment_apply_f32": (c_int, [_P, _I, _I, _I, _P, _I, _F, _P]),
     "cfm_gemm_bias_swish_save_f32": (c_int, [_P, _P, _P, _P, _P, _L, _I, _I, _L, _L, _P]),
     "cfm_gemm_bwd_f32": (c_int, [_P, _I, _L, _P, _I, _L, _P, _L, _F, _P, _L, _I, _I, _L, _I, _P]),

@@ -53,6 +53,54 @@ __global__ __launch_bounds__(256) void power_mel_log_kernel(const float* __restr
     }
 }
 
+// Round 3: power + mel + log on the fp32 matrix pipe.  The first form (above) multiplied the 201 x 80 filterbank on the VALU with
+// one LDS read and one global read per FMA: ~220 of the front end's 359 us.  Here a workgroup takes 32 frames of one utterance;
+// the spectrum row layout is [Re 0..200 | 0-pad to 208 | Im 0..200 | 0-pad to 416] (the DFT basis is stored with those zero rows,
+// so Re and Im fragments are 16-byte aligned).  mel^T[m][t] = sum_bin fbT[m][bin] * power[bin][t] on v_mfma_f32_32x32x2_f32: the
+// B operand (lane = frame t, half hf, bins 8c+4hf+e at step e) is computed in registers from two 16-byte loads (Re, Im); the A
+// operand is the zero-padded transposed filterbank fbT (96 x 208) in the same k order.  The four waves split the 26 eight-bin
+// groups (7,7,6,6), their partial 96 x 32 tiles are summed through LDS in a fixed order, then log(max(., floor)) and 128-byte
+// runs along t.  Memory-bound: the spectrum is read once (53 MB at B = 32, 10 s).
+__global__ __launch_bounds__(256) void power_mel_log_mfma_kernel(const float* __restrict__ spec, int64_t lds_, int im_off,
+                                                                 const float* __restrict__ fbT, int nk, int n_mels, float floor_,
+                                                                 float* __restrict__ out, int T, int rpu) {
+    __shared__ __attribute__((aligned(16))) float part[4 * 96 * 32];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, hf = lane >> 5;
+    const int b = blockIdx.y, t0 = blockIdx.x * 32;
+    const int nt = min(32, T - t0);
+    const int ngroups = nk >> 3;                                        // 8-bin groups (nk = 208 -> 26)
+    const int g0 = (ngroups * wave) >> 2, g1 = (ngroups * (wave + 1)) >> 2;
+    const float* row = spec + ((int64_t)b * rpu + t0 + min(li, nt - 1)) * lds_ + 4 * hf;     // (frames beyond nt: clamped, never stored)
+    f32x16 acc[3];
+#pragma unroll
+    for (int m = 0; m < 3; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+    for (int c = g0; c < g1; ++c) {
+        const f32x4 re = *reinterpret_cast<const f32x4*>(row + 8 * c);
+        const f32x4 im = *reinterpret_cast<const f32x4*>(row + im_off + 8 * c);
+        f32x4 a[3];
+#pragma unroll
+        for (int m = 0; m < 3; ++m) a[m] = *reinterpret_cast<const f32x4*>(fbT + (int64_t)(32 * m + li) * nk + 8 * c + 4 * hf);
+        const f32x4 pw = re * re + im * im;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int m = 0; m < 3; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m][e], pw[e], acc[m], 0, 0, 0);
+    }
+    float* mine = part + wave * 96 * 32;
+#pragma unroll
+    for (int m = 0; m < 3; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mine[(32 * m + (r & 3) + 8 * (r >> 2) + 4 * hf) * 32 + li] = acc[m][r];
+    __syncthreads();
+    for (int i = tid; i < 96 * 32; i += 256) {
+        const int m = i >> 5, t = i & 31;
+        const float v = ((part[i] + part[96 * 32 + i]) + part[2 * 96 * 32 + i]) + part[3 * 96 * 32 + i];
+        if (m < n_mels && t < nt) out[((int64_t)b * n_mels + m) * T + t0 + t] = logf(fmaxf(v, floor_));
+    }
+}
+
 // bands: (n, 3) int32 rows {axis (1 = frequency, 2 = time), start, end}; every band masks all utterances (iid_masks=False)
 __global__ __launch_bounds__(256) void specaugment_kernel(float* __restrict__ spec, int B, int F, int T,
                                                           const int* __restrict__ bands, int nbands, float value) {
@@ -89,6 +137,22 @@ extern "C" int cfm_power_mel_log_f32(const float* spec, int64_t ld_spec, const f
     const dim3 grid((unsigned)((T + 31) / 32), (unsigned)B);
     hipLaunchKernelGGL(power_mel_log_kernel<201>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), spec, ld_spec, fb,
                        n_mels, floor_value, out, T);
+    return cfm_launch_status();
+}
+
+// spec rows: [Re bins 0..n_bins-1 | zeros to nk | Im bins | zeros to 2 nk], nk = n_bins rounded up to 8 (208); fbT: (96, nk) fp32 =
+// the filterbank transposed, zero rows / columns beyond (n_mels, n_bins).  ld_spec >= 2 nk, ld_spec % 4 == 0, n_mels <= 96.
+// rows_per_utt >= T: spectrum rows of utterance b start at row b * rows_per_utt (cfm_dft_frames_f32's layout).
+extern "C" int cfm_power_mel_log_mfma_f32(const float* spec, int64_t ld_spec, const float* fbT, float* out, int B, int T,
+                                          int rows_per_utt, int n_bins, int n_mels, float floor_value, cfm_stream_t stream) {
+    CFM_REQUIRE(spec && fbT && out, CFM_ERR_NULL);
+    const int nk = (n_bins + 7) / 8 * 8;
+    CFM_REQUIRE(B > 0 && T > 0 && rows_per_utt >= T && n_mels > 0 && n_bins > 0 && ld_spec >= 2 * nk && (ld_spec & 3) == 0, CFM_ERR_BAD_SHAPE);
+    CFM_REQUIRE(n_mels <= 96 && B <= 65535, CFM_ERR_UNSUPPORTED);
+    CFM_REQUIRE(CFM_ALIGNED16(spec) && CFM_ALIGNED16(fbT), CFM_ERR_ALIGN);
+    const dim3 grid((unsigned)((T + 31) / 32), (unsigned)B);
+    hipLaunchKernelGGL(power_mel_log_mfma_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), spec, ld_spec, nk, fbT, nk,
+                       n_mels, floor_value, out, T, rows_per_utt);
     return cfm_launch_status();
 }
 

@@ -474,6 +474,21 @@ extern "C" int cfm_gemm_splitk_f32(int epi, const float* A, const float* W, cons
     return cfm_launch_status();
 }
 
+// ---- the front end's DFT: frames are OVERLAPPING rows of the padded waveform ------------------------------------------
+// spec (rows, n_cols) = frames . basis^T with frame r = wave[r * hop : r * hop + n_fft] (lda = hop < K: rows overlap) on the tuned
+// forward kernel (no bias).  The caller lays the utterances out with a pitch that is a multiple of hop, so that row r = b * rpu + t
+// addresses frame t of utterance b (the last rpu - T rows of an utterance are junk frames, computed and ignored), and leaves
+// n_fft floats of slack behind the last utterance.  processor.py:155-158 (torch.stft inside MelSpectrogram).
+extern "C" int cfm_dft_frames_f32(const float* wave, const float* basis, float* spec, int64_t rows, int n_cols, int n_fft,
+                                  int hop, cfm_stream_t stream) {
+    CFM_REQUIRE(wave && basis && spec, CFM_ERR_NULL);
+    CFM_REQUIRE(rows > 0 && n_cols > 0 && n_fft > 0 && hop > 0 && (n_fft & 3) == 0 && (hop & 3) == 0 && (n_cols & 3) == 0, CFM_ERR_BAD_SHAPE);
+    CFM_REQUIRE(CFM_ALIGNED16(wave) && CFM_ALIGNED16(basis) && CFM_ALIGNED16(spec), CFM_ERR_ALIGN);
+    GemmArgs g{};
+    g.A = wave; g.W = basis; g.bias = basis; g.C = spec; g.M = rows; g.N = n_cols; g.K = n_fft; g.lda = hop; g.ldc = n_cols; g.alpha = 1.f;
+    return launch<EPI_BIAS, false, EPF_INFER | EPF_NO_BIAS>(g, static_cast<hipStream_t>(stream));
+}
+
 // ---- LayerNorm folded into its neighbours (inference) ---------------------------------------------------------------
 // producers: the plain / residual GEMM that also emits the LayerNorm statistics partials of the rows it stores
 extern "C" int cfm_gemm_bias_stats_f32(const float* A, const float* W, const float* bias, float* C, float* stats_out,

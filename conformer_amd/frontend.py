@@ -5,7 +5,8 @@ processing/augment.py:7-19).  The text/tokenizer half of ConformerProcessor is C
 MelSpectrogram(16 kHz, n_fft 400, win 400 periodic Hann, hop 160, centre reflect padding, power 2, 80 slaney/slaney mel
 bins 0-8000 Hz) -> log(clamp(., 1e-5)):
     cfm_reflect_pad_f32 -> ONE batched MFMA GEMM (frames are overlapping rows of the padded wave, lda = hop; the window is
-    folded into the (402, 400) [cos; -sin] basis) -> cfm_power_mel_log_f32 writes (B, 80, T) directly.
+    folded into the (416, 400) [cos; 0; -sin; 0] basis) -> cfm_power_mel_log_mfma_f32 (mel products on the matrix pipe) writes
+    (B, 80, T) directly.
 The DFT basis and the mel filterbank are built once on the host in float64 (they are constants of the configuration).
 Parity: torchaudio is not available to pin against -> "parity unpinned" (DESIGN.md); tests compare with an fp64 DFT.
 """
@@ -49,10 +50,19 @@ class ConformerAudioFrontend:
         win = 0.5 - 0.5 * torch.cos(2 * math.pi * n / win_length)                    # periodic Hann
         k = torch.arange(n_fft // 2 + 1, dtype=torch.float64)[:, None]
         ang = 2 * math.pi * k * n[None, :] / n_fft
-        basis = torch.cat([torch.cos(ang) * win, -torch.sin(ang) * win], dim=0)      # (402, 400)
+        nb = n_fft // 2 + 1
+        self.nk = (nb + 7) // 8 * 8                                                  # 208: Re / Im blocks start 16-byte aligned
+        basis = torch.zeros(2 * self.nk, n_fft, dtype=torch.float64)                 # (416, 400): [cos | 0 | -sin | 0] x window
+        basis[:nb] = torch.cos(ang) * win
+        basis[self.nk:self.nk + nb] = -torch.sin(ang) * win
         self.basis = basis.to(torch.float32).to(self.device).contiguous()
-        self.fb = _slaney_filterbank(n_fft // 2 + 1, n_mels, sample_rate, fmin, fmax).to(torch.float32) \
-            .to(self.device).contiguous()                                            # (201, 80)
+        fb = _slaney_filterbank(nb, n_mels, sample_rate, fmin, fmax)                 # (201, 80)
+        self.fb = fb.to(torch.float32).to(self.device).contiguous()
+        if n_mels > 96:
+            raise NotImplementedError("the matrix-pipe mel kernel holds at most 96 mel bins")
+        fbT = torch.zeros(96, self.nk, dtype=torch.float32)                          # transposed, zero-padded: the MFMA A operand
+        fbT[:n_mels, :nb] = fb.to(torch.float32).t()
+        self.fbT = fbT.to(self.device).contiguous()
 
     def mel_spectrogram(self, signal: torch.Tensor) -> torch.Tensor:
         """(B, L) fp32 on the HIP device -> log-mel (B, n_mels, L // hop + 1)   (processor.py:155-158)."""
@@ -64,18 +74,27 @@ class ConformerAudioFrontend:
         if L <= pad:
             raise _lib.ConformerHipError(f"signal of {L} samples is shorter than the reflect padding ({pad})")
         T = L // self.hop_length + 1
-        Lp = (L + 2 * pad + 3) // 4 * 4
+        hop = self.hop_length
+        rpu = T + (self.n_fft + hop - 1) // hop                       # rows per utterance: pitch rpu * hop >= L + n_fft
+        Lp = rpu * hop
         lib = _lib.load()
-        xp = torch.empty(B, Lp, device=x.device, dtype=torch.float32)
+        # (B, Lp) padded waves back to back + n_fft floats of slack: the junk frames behind the last utterance read into it (rows are
+        # independent: whatever those floats hold only reaches spectrum rows nobody reads)
+        xbuf = torch.empty(B * Lp + self.n_fft, device=x.device, dtype=torch.float32)
+        xp = xbuf[:B * Lp].view(B, Lp)
         _lib.check(lib.cfm_reflect_pad_f32(x.data_ptr(), xp.data_ptr(), B, L, pad, Lp, ops._stream()), "cfm_reflect_pad_f32")
-        nb2 = self.basis.shape[0]
-        lds = (nb2 + 3) // 4 * 4
-        spec = torch.empty(B * T, lds, device=x.device, dtype=torch.float32)
-        ops.gemm_bwd(xp, False, self.basis, False, T, nb2, self.n_fft, out=spec, lda=self.hop_length, ldb=self.n_fft,
-                     ldc=lds, nbatch=B, nb1=1, sa=(Lp, 0), sb=(0, 0), sc=(T * lds, 0))
+        nb2 = self.basis.shape[0]                                                    # 2 * nk = 416 DFT columns (Re | Im, zero-padded)
+        spec = torch.empty(B * rpu, nb2, device=x.device, dtype=torch.float32)
+        if hop % 4 == 0:
+            # frames = overlapping rows of the padded waves (row b * rpu + t); the tuned forward GEMM with lda = hop
+            _lib.check(lib.cfm_dft_frames_f32(xp.data_ptr(), self.basis.data_ptr(), spec.data_ptr(), B * rpu, nb2, self.n_fft, hop,
+                                              ops._stream()), "cfm_dft_frames_f32")
+        else:
+            ops.gemm_bwd(xp, False, self.basis, False, T, nb2, self.n_fft, out=spec, lda=hop, ldb=self.n_fft,
+                         ldc=nb2, nbatch=B, nb1=1, sa=(Lp, 0), sb=(0, 0), sc=(rpu * nb2, 0))
         out = torch.empty(B, self.n_mels, T, device=x.device, dtype=torch.float32)
-        _lib.check(lib.cfm_power_mel_log_f32(spec.data_ptr(), lds, self.fb.data_ptr(), out.data_ptr(), B, T,
-                                             self.n_fft // 2 + 1, self.n_mels, 1e-5, ops._stream()), "cfm_power_mel_log_f32")
+        _lib.check(lib.cfm_power_mel_log_mfma_f32(spec.data_ptr(), nb2, self.fbT.data_ptr(), out.data_ptr(), B, T, rpu,
+                                                  self.n_fft // 2 + 1, self.n_mels, 1e-5, ops._stream()), "cfm_power_mel_log_mfma_f32")
         return out
 
     def __call__(self, audios: Sequence[torch.Tensor], augment: Optional["ConformerAugment"] = None) -> Tuple[torch.Tensor, torch.Tensor]:

@@ -26,6 +26,7 @@ class FrontendPipeline:
             raise ValueError("depth must be >= 1")
         self.source, self.frontend, self.augment, self.depth = source, frontend, augment, depth
         self.stream = torch.cuda.Stream(device=frontend.device)
+        self.timeline: Optional[List[Tuple[torch.cuda.Event, torch.cuda.Event]]] = None   # set to [] to record (start, done) events per batch
 
     def _stage(self, audios: Sequence[torch.Tensor]):
         fe = self.frontend
@@ -35,6 +36,9 @@ class FrontendPipeline:
             host[i, :lengths[i]] = a
         host_len = torch.tensor(lengths, dtype=torch.int64).pin_memory()
         with torch.cuda.stream(self.stream):
+            if self.timeline is not None:
+                ev0 = torch.cuda.Event(enable_timing=True)
+                ev0.record(self.stream)
             wave = host.to(fe.device, non_blocking=True)
             n = host_len.to(fe.device, non_blocking=True)
             mels = fe.mel_spectrogram(wave)
@@ -43,8 +47,10 @@ class FrontendPipeline:
             frames = n // fe.hop_length + 1                                  # processor.py:392
             frames, order = torch.sort(frames, descending=True)              # dataset.py:97
             mels = mels.index_select(0, order)
-            ev = torch.cuda.Event()
+            ev = torch.cuda.Event(enable_timing=self.timeline is not None)
             ev.record(self.stream)
+            if self.timeline is not None:
+                self.timeline.append((ev0, ev))
         return mels, frames, order, ev, (host, host_len)                     # host buffers stay alive until consumed
 
     def __iter__(self) -> Iterator[Tuple[torch.Tensor, torch.Tensor, torch.Tensor]]:

@@ -257,6 +257,16 @@ int cfm_subsample_conv2_bwd_input_mfma16_f32(int prec, const float* dz2, const f
 int cfm_reflect_pad_f32(const float* x, float* xp, int B, int64_t L, int pad, int64_t ld_out, cfm_stream_t stream);
 int cfm_power_mel_log_f32(const float* spec, int64_t ld_spec, const float* fb, float* out, int B, int T,
                           int n_bins, int n_mels, float floor_value, cfm_stream_t stream);
+/*      the same on the fp32 matrix pipe (round 3): spec rows are [Re | 0-pad to nk | Im | 0-pad to 2 nk], nk = n_bins rounded up to
+ *      8, as written by a DFT GEMM whose basis carries those zero rows; fbT (96, nk) = the filterbank transposed and zero-padded.
+ *      One workgroup per 32 frames, mel products on v_mfma_f32_32x32x2_f32, the spectrum read once. */
+int cfm_power_mel_log_mfma_f32(const float* spec, int64_t ld_spec, const float* fbT, float* out, int B, int T,
+                               int rows_per_utt, int n_bins, int n_mels, float floor_value, cfm_stream_t stream);
+/*      the DFT in front of it on the tuned forward GEMM: spec (rows, n_cols) = frames . basis^T, frame r = wave[r*hop : r*hop+n_fft]
+ *      (overlapping rows).  Utterances are laid out with a pitch of rows_per_utt * hop floats (rows_per_utt >= T + 3 so that the
+ *      pitch covers L + n_fft), row b * rows_per_utt + t = frame t of utterance b; n_fft floats of slack behind the last one. */
+int cfm_dft_frames_f32(const float* wave, const float* basis, float* spec, int64_t rows, int n_cols, int n_fft,
+                       int hop, cfm_stream_t stream);
 int cfm_specaugment_apply_f32(float* spec, int B, int F, int T, const int* bands, int nbands, float value,
                               cfm_stream_t stream);
 

@@ -102,3 +102,44 @@ def test_frontend_pipeline_matches_serial_path():
         assert [len(src[i]) // 160 + 1 for i in order.tolist()] == frames.tolist()
         seen += 1
     assert seen == len(batches)
+
+
+@pytest.mark.gpu
+def test_frontend_pipeline_vs_oracle_and_collate_sort():
+    """N3 against the oracle (the previous check compared the pipeline with the serial path of the same front end):
+    every batch the side stream prepares equals oracle/frontend_oracle.py's log-mel of the zero-padded waveforms (processor.py:373-394)
+    re-ordered by the collate's descending length sort (dataset.py:97), lengths = samples // hop + 1 (processor.py:392), and the
+    recorded timeline shows the front end of batch n+1 starting before model step n's consumer work has finished."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from conformer_amd.frontend import ConformerAudioFrontend
+    from conformer_amd.pipeline import FrontendPipeline
+    dev = torch.device("cuda:0")
+    fe = ConformerAudioFrontend(device=dev)
+    g = torch.Generator().manual_seed(5)
+    batches = [[torch.randn(n, generator=g) * 0.3 for n in lens] for lens in ([16000, 4000, 12345], [800, 8000, 8000], [3200], [401, 16000, 7000, 160])]
+    pipe = FrontendPipeline(batches, fe)
+    pipe.timeline = []
+    busy = torch.randn(2048, 2048, device=dev)
+    marks = []
+    for (mels, frames, order), src in zip(pipe, batches):
+        for _ in range(4):
+            busy = busy @ busy * 1e-3                                   # the consumer's "model step"
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        marks.append(ev)
+        n = max(len(a) for a in src)
+        padded = torch.stack([torch.nn.functional.pad(a, (0, n - len(a))) for a in src])
+        ref = FO.log_mel(padded)                                        # (B, 80, T) float32 restatement of the torchaudio semantics
+        want_len = torch.tensor(FO.batch_lengths([len(a) for a in src]))
+        want_len_sorted, _ = torch.sort(want_len, descending=True)
+        assert torch.equal(frames.cpu(), want_len_sorted)
+        assert torch.equal(want_len[order.cpu()], want_len_sorted)      # a valid descending order of THIS batch
+        assert sorted(order.tolist()) == list(range(len(src)))
+        got = mels.cpu()
+        err = (got - ref[order.cpu()]).abs()
+        assert float(err.max()) < 5e-3 and float(err.mean()) < 1e-4
+    torch.cuda.synchronize()
+    assert len(pipe.timeline) == len(batches)
+    # batch 1's front end was started (side stream) before the consumer finished batch 0's work
+    assert pipe.timeline[1][0].elapsed_time(marks[0]) > 0
