@@ -103,23 +103,23 @@ def gemm_site_table(enc, x, iters):
     posw, posb = torch.cat([att.pos_proj.weight.detach()] * L, 0).contiguous(), torch.cat([att.pos_proj.bias.detach()] * L, 0).contiguous()
     if fold:
         # the folded-LayerNorm forms the forward really launches (ops.linear_lnfold consumers, emit_stats producers)
-        _, st = ops.linear_residual(a_d, att.out_proj.weight, att.out_proj.bias, res, 1.0, emit_stats=True)
+        _, stt = ops.linear_residual(a_d, att.out_proj.weight, att.out_proj.bias, res, 1.0, emit_stats=True)
         f1, fq, fc = (ops.fold_layernorm(w_, b_, ln.weight, ln.bias) for w_, b_, ln in (
             (lay.ffn_1.hidden_linear.weight, lay.ffn_1.hidden_linear.bias, lay.ffn_1.layer_norm), (qkvw, qkvb, lay.attention.layer_norm),
             (lay.conv.pointwise_conv_1.weight, lay.conv.pointwise_conv_1.bias, lay.conv.layer_norm)))
         sites = [
             ("gemm<relu,conv>  stem conv2 implicit GEMM", (B * Tp * Fp, d, 9 * d), 1, conv2),
             ("gemm<bias+stats> input linear", (N, d, Fp * d), 1, lambda: ops.linear(h2, wl, enc.linear.bias, emit_stats=True)),
-            ("gemm<LN,swish>   FFN hidden (LayerNorm folded)", (N, 4 * d, d), 2 * L, lambda: ops.linear_lnfold(a_d, st, *f1, 1e-5, act="swish")),
+            ("gemm<LN,swish>   FFN hidden (LayerNorm folded)", (N, 4 * d, d), 2 * L, lambda: ops.linear_lnfold(a_d, stt, *f1, 1e-5, act="swish")),
             ("gemm<resid+stats> FFN-1 out", (N, d, 4 * d), L,
              lambda: ops.linear_residual(a_4d, lay.ffn_1.out_linear.weight, lay.ffn_1.out_linear.bias, res, 0.5, emit_stats=True)),
             ("gemm<residual>   FFN-2 out", (N, d, 4 * d), L,
              lambda: ops.linear_residual(a_4d, lay.ffn_1.out_linear.weight, lay.ffn_1.out_linear.bias, res, 0.5)),
-            ("gemm<LN,bias>    fused QKV (LayerNorm folded)", (N, 3 * d, d), L, lambda: ops.linear_lnfold(a_d, st, *fq, 1e-5)),
+            ("gemm<LN,bias>    fused QKV (LayerNorm folded)", (N, 3 * d, d), L, lambda: ops.linear_lnfold(a_d, stt, *fq, 1e-5)),
             ("gemm<bias>       pos proj (all layers, one launch)", (P, L * d, d), 1, lambda: ops.linear(pe, posw, posb)),
             ("gemm<resid+stats> attn out / pw2", (N, d, d), 2 * L,
              lambda: ops.linear_residual(a_d, att.out_proj.weight, att.out_proj.bias, res, 1.0, emit_stats=True)),
-            ("gemm<LN,glu>     pw1+GLU (LayerNorm folded)", (N, 2 * d, d), L, lambda: ops.linear_lnfold(a_d, st, *fc, 1e-5, glu=True)),
+            ("gemm<LN,glu>     pw1+GLU (LayerNorm folded)", (N, 2 * d, d), L, lambda: ops.linear_lnfold(a_d, stt, *fc, 1e-5, glu=True)),
         ]
     else:
       sites = [

@@ -268,7 +268,10 @@ inline int choose_tile(int64_t M, int ncols, bool glu, int K) {
     if (glu) return 2;
     if (n128 > 690 && n128 <= 768) return 0;      // exactly one full round at 3 blocks/CU (fused QKV: 756 tiles)
     if (n128 >= 3 * 256) return 1;
-    // long contractions (the input Linear, K = 9728): 128x64 once it gives ~2 workgroups per CU: 639 vs 670 us on 64x64
+    // long contractions (the input Linear, K = 9728; FFN out, K = 2048) at N = 512: 64x128 once it gives ~2 workgroups per CU
+    // (round 3, tools/gemm_tune.py bk, medians of 7 interleaved rounds: input Linear 637 us vs 653 on 128x64 / 680 on 64x64; FFN out
+    // 139.8 vs 142.3 on 64x64)
+    if (K >= 2048 && ((M + 63) / 64) * ((ncols + 127) / 128) >= 448) return 2;
     if (K >= 4096 && ((M + 127) / 128) * ((ncols + 63) / 64) >= 448) return 1;
     return 3;
 }
