@@ -118,6 +118,7 @@ SIGNATURES = {
     "cfm_debug_set_bwd_tile": (c_int, [_I]),
     "cfm_debug_set_attention_waves": (c_int, [_I]),
     "cfm_debug_gemm_cfg_f32": (c_int, [_I, _P, _P, _P, _P, _F, _P, _L, _I, _I, _P, _P]),
+    "cfm_debug_set_conv2_bk": (c_int, [_I]),
     "cfm_relpos_table_f32": (c_int, [_P, _P, _I, _I, _P]),
     "cfm_relpos_attention_fwd_f32": (c_int, [_P, _P, _P, _L, _P, _L, _P, _P, _P, _P, _L, _P, _I, _I, _I, _I, _P]),
     "cfm_dwconv_bn_swish_fwd_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, _F, _P, _I, _I, _I, _I, _P]),

@@ -435,6 +435,238 @@ __global__ __launch_bounds__(64 * NW, 2) void relpos_attn_fwd_kernel(const AttnA
     }
 }
 
+// ---- round 3: the software-pipelined 8-wave form (inference: no weight dropout, no key split) -----------------------------
+// The phase stamps of the forms above (profiles/r03_attn_fwd_trace.txt, r03_attn8_interval_trace.txt) say that the matrix pipe idles
+// under every wave's OWN skew / softmax section (~250 VALU + 48 LDS instructions per key tile, ~3 us) and that pairing the two waves
+// of a SIMD differently does not cover it.  Here each wave covers it itself: ONE instruction stream in which the 64 matrix
+// instructions of key tile t+1 (content scores + positional band) are interleaved with the softmax of key tile t, and the 32 of
+// P.V(t) with the spill / skew / shift of tile t+1 -- the scores of a tile are finished one iteration before they are consumed.
+//   iteration t:   X   K(t+1), band block t+1-w  ->  sn, ga   (64 MFMAs)        ||  sc(t) -> p, alpha, l, m        (VALU)
+//                  Y   O *= alpha;  O += V(t)^T . p  (32 MFMAs)                  ||  ga -> skew tile -> sn += shift  (LDS, VALU)
+//                  staging: K(t+2), V(t+1), ring block t+2 from registers into the buffers last read in iteration t-1; one barrier
+// 8 waves = 256 query rows (a whole (batch, head) at T' = 249), K / V double-buffered, the positional band as the LDS ring of 32-row
+// table blocks (10 slots: block b is read in iterations b-1 .. b+6).  153 KB LDS, one workgroup per CU.
+template <int NC, int ND>
+__global__ __launch_bounds__(512, 2) void relpos_attn_fwd8p_kernel(const AttnArgs a) {
+    constexpr int NW = 8, RING = 10;
+    __shared__ __attribute__((aligned(16))) float smem[2 * 32 * KROW + 2 * 32 * 64 + NW * 32 * 32 + RING * 32 * KROW];
+    float* Ksb = smem;                           // [2][32][KROW]
+    float* Vsb = Ksb + 2 * 32 * KROW;            // [2][32][64]
+    float* gs = Vsb + 2 * 32 * 64 + (threadIdx.x >> 6) * 1024;   // per-wave skew tile [32][32]
+    float* ring = Vsb + 2 * 32 * 64 + NW * 32 * 32;              // [RING][32][KROW]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, hf = lane >> 5;
+    const int bh = blockIdx.y, b = bh / a.H, h = bh % a.H;
+    const int T = a.T, dh = a.dh;
+    const int q0 = a.q_begin + (int)blockIdx.x * 256;
+    const int i0 = q0 + wave * 32;
+    const bool active = i0 < a.q_end;                              // wave-uniform; idle waves still stage + barrier
+
+    int klen = T;
+    bool uniform = false;
+    if (a.lengths) {
+        const int64_t L = a.lengths[b];
+        if (L <= 0) uniform = true;
+        else if (L < T) klen = (int)L;
+    }
+    const int nt = (klen + 31) / 32;
+    const float* kbase = a.k + (int64_t)b * T * a.ld + h * dh;
+    const float* vbase = a.v + (int64_t)b * T * a.ld + h * dh;
+    const float* pbase = a.pos + h * dh;
+    const int jmax = 2 * T - 2;
+    const int R0 = T - 1 - q0;
+
+    // ---- cooperative staging: thread (row srow, 16-byte chunk sch) of a 32-row x 256-byte tile; tiles beyond the keys read clamped rows
+    const int srow = tid >> 4, sch = tid & 15;
+    const bool sok = sch * 4 < dh;
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 pk, pv, pr;
+    auto loadK = [&](int kt) { pk = sok ? *reinterpret_cast<const f32x4*>(kbase + (int64_t)min(32 * kt + srow, T - 1) * a.ld + sch * 4) : z4; };
+    auto loadV = [&](int kt) { pv = sok ? *reinterpret_cast<const f32x4*>(vbase + (int64_t)min(32 * kt + srow, T - 1) * a.ld + sch * 4) : z4; };
+    auto loadR = [&](int blk) { pr = sok ? *reinterpret_cast<const f32x4*>(pbase + (int64_t)max(0, min(R0 + 32 * blk + srow, jmax)) * a.ldp + sch * 4) : z4; };
+    auto ring_slot = [](int blk) { return ((blk % RING) + RING) % RING; };
+    auto storeK = [&](int buf) { *reinterpret_cast<f32x4*>(Ksb + buf * 32 * KROW + srow * KROW + sch * 4) = pk; };
+    auto storeV = [&](int buf) { *reinterpret_cast<f32x4*>(Vsb + buf * 32 * 64 + srow * 64 + sch * 4) = pv; };
+    auto storeR = [&](int blk) { *reinterpret_cast<f32x4*>(ring + (ring_slot(blk) * 32 + srow) * KROW + sch * 4) = pr; };
+    loadK(0); loadV(0); storeK(0); storeV(0);
+    for (int blk = -8; blk <= 1; ++blk) { loadR(blk); storeR(blk); }
+    loadK(1); storeK(1);
+    loadK(2); loadV(1); loadR(2);                                  // in flight: committed in iteration 0
+    __syncthreads();
+
+    // ---- (Q+u)^T and (Q+v)^T as MFMA B operands: lane (query li, half hf) holds dims 8c+4hf+e at step 4c+e
+    float qu[4 * NC], qv[4 * NC];
+    {
+        const int qi = min(i0 + li, T - 1);
+        const float* qrow = a.q + ((int64_t)b * T + qi) * a.ld + h * dh;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int dd = 8 * c + 4 * hf;
+            f32x4 x = z4, uu = z4, vv = z4;
+            if (dd < dh) {
+                x = *reinterpret_cast<const f32x4*>(qrow + dd);
+                uu = *reinterpret_cast<const f32x4*>(a.u + h * dh + dd);
+                vv = *reinterpret_cast<const f32x4*>(a.vb + h * dh + dd);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { qu[4 * c + e] = x[e] + uu[e]; qv[4 * c + e] = x[e] + vv[e]; }
+        }
+    }
+    f32x16 o[ND];
+#pragma unroll
+    for (int n = 0; n < ND; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[n][r] = 0.f;
+    float mrow = -INFINITY, lrow = 0.f;
+
+    // products of key tile kt: content scores S^T[key][query] from K buffer kt & 1, band tile of ring block blk (A-operand row li <->
+    // block row 31 - li)
+    auto content = [&](int kt) {
+        const float* Ks = Ksb + (kt & 1) * 32 * KROW + li * KROW + 4 * hf;
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const f32x4 kf = *reinterpret_cast<const f32x4*>(Ks + 8 * c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[e], qu[4 * c + e], acc, 0, 0, 0);
+        }
+        return acc;
+    };
+    auto band = [&](int blk) {
+        const float* rp = ring + (ring_slot(blk) * 32 + (31 - li)) * KROW + 4 * hf;
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const f32x4 f = *reinterpret_cast<const f32x4*>(rp + 8 * c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(f[e], qv[4 * c + e], acc, 0, 0, 0);
+        }
+        return acc;
+    };
+    auto spill_band = [&](const f32x16& ga) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) gs[((r & 3) + 8 * (r >> 2) + 4 * hf) * 32 + li] = ga[r];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    auto skew_reads = [&](float (&dst)[16]) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int jj = li - ((r & 3) + 8 * (r >> 2) + 4 * hf) + 31;     // 0..62
+            dst[r] = gs[(jj & 31) * 32 + li];
+        }
+    };
+    // sn += the shifted band: band tile 1 of the key tile (carried in skp: it was band tile 0 of the previous key tile) or band tile 0
+    auto shift_add = [&](f32x16& sn, float (&skp)[16], const float (&skn)[16]) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int jj = li - ((r & 3) + 8 * (r >> 2) + 4 * hf) + 31;
+            sn[r] += (jj >> 5) ? skp[r] : skn[r];
+            skp[r] = skn[r];
+        }
+    };
+
+    float skp[16];
+    f32x16 sc;                                                       // finished scores of the tile the softmax works on
+    if (active) {
+        // key tile 0: band tile 1 = block -w-1 (explicitly), then content + band tile 0 (block -w)
+        {
+            const f32x16 g1 = band(-wave - 1);
+            spill_band(g1);
+            skew_reads(skp);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+        sc = content(0);
+        const f32x16 g0 = band(-wave);
+        spill_band(g0);
+        float skn[16];
+        skew_reads(skn);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        shift_add(sc, skp, skn);
+    }
+    __syncthreads();                   // iteration 0 overwrites K buffer 0 (K(0)) and ring slot 2 (block -8), both read just above
+
+    for (int t = 0; t < nt; ++t) {
+        // ---- staging: the registers loaded one iteration ago go into the buffers whose last readers passed the previous barrier
+        storeK(t & 1);                 // K(t+2): K(t) was read in iteration t-1
+        storeV((t + 1) & 1);           // V(t+1): V(t-1) was read in iteration t-1
+        storeR(t + 2);
+        loadK(t + 3); loadV(t + 2); loadR(t + 3);
+        if (active) {
+            const int k0 = 32 * t;
+            // ---- X: the products of key tile t+1 (the compiler interleaves them with the softmax below: one basic block, no fences)
+            f32x16 sn = content(t + 1);
+            const f32x16 ga = band(t + 1 - wave);
+            float p[16];
+            float tmax = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int kk = (r & 3) + 8 * (r >> 2) + 4 * hf;
+                float sv = sc[r] * a.inv_sqrt_dh;
+                if (uniform) sv = 0.f;
+                if (k0 + kk >= klen) sv = -INFINITY;
+                p[r] = sv;
+                tmax = fmaxf(tmax, sv);
+            }
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+            const float mnew = fmaxf(mrow, tmax);                   // finite: key k0 (< klen) is always valid
+            const float alpha = exp_fast(mrow - mnew);
+            float psum = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { p[r] = exp_fast(p[r] - mnew); psum += p[r]; }
+            psum += __shfl_xor(psum, 32, 64);
+            lrow = lrow * alpha + psum;
+            mrow = mnew;
+#pragma unroll
+            for (int n = 0; n < ND; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[n][r] *= alpha;
+            // ---- Y: P.V of key tile t, with the spill / skew / shift of tile t+1's band riding beside its MFMAs
+            spill_band(ga);
+            float skn[16];
+            skew_reads(skn);
+            const float* Vs = Vsb + (t & 1) * 32 * 64;
+#pragma unroll
+            for (int n = 0; n < ND; ++n)
+#pragma unroll
+                for (int s = 0; s < 16; ++s) {
+                    const float vv = Vs[((s & 3) + 8 * (s >> 2) + 4 * hf) * 64 + ((32 * n + li) & 63)];
+                    o[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv, p[s], o[n], 0, 0, 0);
+                }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the skew reads have landed before the tile is rewritten
+            __builtin_amdgcn_wave_barrier();
+            shift_add(sn, skp, skn);
+            sc = sn;
+        }
+        __syncthreads();
+    }
+
+    // ---- normalise and store: lane = query row, registers = head dims (4 consecutive dims per r>>2 group)
+    if (active && i0 + li < a.q_end) {
+        const float inv = 1.0f / lrow;
+        float* orow = a.ctx + ((int64_t)b * T + i0 + li) * a.ldo + h * dh;
+#pragma unroll
+        for (int n = 0; n < ND; ++n)
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const int dd = 32 * n + 8 * gq + 4 * hf;
+                if (dd < dh) {
+                    f32x4 out = {o[n][4 * gq] * inv, o[n][4 * gq + 1] * inv, o[n][4 * gq + 2] * inv, o[n][4 * gq + 3] * inv};
+                    *reinterpret_cast<f32x4*>(orow + dd) = out;
+                }
+            }
+        if (a.lse && hf == 0) a.lse[((int64_t)b * a.H + h) * T + i0 + li] = mrow + logf(lrow);
+    }
+}
+
 // ctx[b, q_begin+il, h*dh + :] = sum_s exp(lse_s - lse) * part_s, lse = logsumexp over the splits that own keys of utterance b
 __global__ __launch_bounds__(256) void attn_merge_splits_kernel(const AttnArgs a) {
     const int qc = a.q_end - a.q_begin, d4 = a.dh / 4;
@@ -476,7 +708,7 @@ static int attention_launch(const float* q, const float* k, const float* v, int6
 static int g_attn_force_nw = 0;
 extern "C" int cfm_debug_set_attention_waves(int nw) {
     const int prev = g_attn_force_nw;
-    if (nw == 0 || nw == 4 || nw == 8) g_attn_force_nw = nw;
+    if (nw == 0 || nw == 4 || nw == 8 || nw == 9) g_attn_force_nw = nw;
     return prev;
 }
 
@@ -488,6 +720,7 @@ extern "C" int cfm_debug_attention_trace_f32(const float* q, const float* k, con
                                              int dh, void* trace, cfm_stream_t stream) {
     const int prev = g_attn_force_nw;
     if (prev != 8) g_attn_force_nw = 4;                // per-phase stamps: the 4-wave form; cfm_debug_set_attention_waves(8): per-interval stamps
+    else g_attn_force_nw = 8;
     const int st = attention_launch(q, k, v, ld, pos, ldp, u, vbias, lengths_or_null, ctx, ldo, nullptr, B, T, H, dh, 0.f, 0, stream,
                                     trace);
     g_attn_force_nw = prev;
@@ -549,9 +782,23 @@ static int attention_launch(const float* q, const float* k, const float* v, int6
                static_cast<unsigned long long*>(trace)};
     // 8-wave workgroups (256 query rows, the two halves half a key tile apart) once a launch has more than 128 query rows and
     // no key split; g_attn_force_nw (diagnostics) overrides
-    const int nw = g_attn_force_nw ? g_attn_force_nw : ((q_count > 128 && nsplit == 1) ? 8 : 4);
-    const dim3 grid((unsigned)((q_count + 32 * nw - 1) / (32 * nw)) * nsplit, (unsigned)(B * H)), block(64 * nw);
+    // force 9 = the software-pipelined 8-wave form (the built-in choice for > 128 query rows without weight dropout / key split)
+    const bool can_pipe = nsplit == 1 && drop_p == 0.f && !trace;
+    int nw = g_attn_force_nw ? g_attn_force_nw : ((q_count > 128 && nsplit == 1) ? (can_pipe ? 9 : 8) : 4);
+    if (nw == 9 && !can_pipe) nw = 8;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (nw == 9) {
+        const dim3 grid9((unsigned)((q_count + 255) / 256), (unsigned)(B * H)), block9(512);
+#define ATT_LAUNCH9(NC, ND) hipLaunchKernelGGL((relpos_attn_fwd8p_kernel<NC, ND>), grid9, block9, 0, s, a)
+        if (dh <= 8) ATT_LAUNCH9(1, 1);
+        else if (dh <= 16) ATT_LAUNCH9(2, 1);
+        else if (dh <= 32) ATT_LAUNCH9(4, 1);
+        else if (dh <= 40) ATT_LAUNCH9(5, 2);
+        else ATT_LAUNCH9(8, 2);
+#undef ATT_LAUNCH9
+        return cfm_launch_status();
+    }
+    const dim3 grid((unsigned)((q_count + 32 * nw - 1) / (32 * nw)) * nsplit, (unsigned)(B * H)), block(64 * nw);
 #define ATT_LAUNCH(NC, ND) do { if (nw == 8) hipLaunchKernelGGL((relpos_attn_fwd_kernel<NC, ND, 8>), grid, block, 0, s, a); \
                                 else hipLaunchKernelGGL((relpos_attn_fwd_kernel<NC, ND, 4>), grid, block, 0, s, a); } while (0)
     if (dh <= 8) ATT_LAUNCH(1, 1);

@@ -537,6 +537,7 @@ extern "C" int cfm_gemm_lnfold_f32(int epi, const float* A, const float* ln_stat
     return CFM_ERR_UNSUPPORTED;
 }
 
+static int g_conv2_bk = 16;
 // Implicit-GEMM second stem convolution (3x3, stride 2, channel-last input, packed weight).  Declared in the stem
 // section of the ABI; lives here to share the kernel templates.
 extern "C" int cfm_subsample_conv2_relu_f32(const float* h1, const float* w2p, const float* b2, float* h2, int B,
@@ -549,7 +550,15 @@ extern "C" int cfm_subsample_conv2_relu_f32(const float* h1, const float* w2p, c
     g.cT1 = T1; g.cF1 = F1; g.cC = C; g.cT2 = (T1 - 1) / 2; g.cF2 = (F1 - 1) / 2;
     g.A = h1; g.W = w2p; g.bias = b2; g.C = h2;
     g.M = (int64_t)B * g.cT2 * g.cF2; g.N = C; g.K = 9 * C; g.lda = 0; g.ldc = C; g.alpha = 1.f;
+    if (g_conv2_bk == 32 && C % 32 == 0) return launch<EPI_RELU, true, EPF_INFER, 32>(g, static_cast<hipStream_t>(stream));
     return launch<EPI_RELU, true, EPF_INFER>(g, static_cast<hipStream_t>(stream));
+}
+
+// diagnostics (tools/conv2_bk_ab.py): K-tile of the stem's implicit GEMM: 16 (default) | 32; returns the previous setting
+extern "C" int cfm_debug_set_conv2_bk(int bk) {
+    const int prev = g_conv2_bk;
+    if (bk == 16 || bk == 32) g_conv2_bk = bk;
+    return prev;
 }
 
 // Tuning / diagnostics: the residual-epilogue GEMM with a forced block-tile shape

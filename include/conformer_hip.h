@@ -393,6 +393,7 @@ int cfm_debug_gemm_mfma16_trace(void* trace_or_null);     /* per-K-tile stamps o
 int cfm_debug_gemm_cfg_f32(int cfg, const float* A, const float* W, const float* bias, const float* R,
                            float alpha, float* C, int64_t M, int N, int K, void* trace_or_null,
                            cfm_stream_t stream);
+int cfm_debug_set_conv2_bk(int bk);   /* K-tile of cfm_subsample_conv2_relu_f32: 16 (default) | 32; returns the previous setting */
 /*      cfg + 16: bias epilogue; cfg + 32: swish epilogue; cfg + 64: K-tile 32 (a staged row = one whole 128-byte line;
  *      measured slower than the K-tile 16 loop at every hot-path shape but one: kept for tools/gemm_tune.py bk). */
 

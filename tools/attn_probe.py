@@ -67,12 +67,18 @@ if len(sys.argv) > 1 and sys.argv[1] == "ab":
     import statistics
     from conformer_amd import _lib
     lib = _lib.load()
-    variants = [(4, 0), (8, 0)]                              # (waves, -)
+    variants = [(4, 0), (8, 0), (9, 0)]                      # (waves, -); 9 = the software-pipelined 8-wave form
     outs, times = {}, {vv: [] for vv in variants}
-    for nw in (4, 8):
+    Lr = torch.randint(1, T + 1, (B,), device=dev, generator=g)
+    Lr[0] = T
+    for nw in (4, 8, 9):
         lib.cfm_debug_set_attention_waves(nw)
         outs[nw] = ops.relpos_attention(qkv, pos, u, v, L, H).clone()
+        outs[nw, "ragged"] = ops.relpos_attention(qkv, pos, u, v, Lr, H).clone()
     print("bit-identical:", bool(torch.equal(outs[4], outs[8])), " rel-L2 difference:", float((outs[4] - outs[8]).norm() / outs[4].norm()))
+    for key in (9, (9, "ragged")):
+        ref = outs[4] if key == 9 else outs[4, "ragged"]
+        print(f"pipelined {key}: rel-L2 vs 4 waves {float((outs[key] - ref).norm() / ref.norm()):.3e}  max abs {float((outs[key] - ref).abs().max()):.3e}")
     for rnd in range(9):
         for vv in variants:
             lib.cfm_debug_set_attention_waves(vv[0])
@@ -87,5 +93,5 @@ if len(sys.argv) > 1 and sys.argv[1] == "ab":
     fl = 6.0 * B * T * T * d
     for vv in variants:
         med = statistics.median(times[vv])
-        print(f"{vv[0]} waves: median {med:.1f} us  min {min(times[vv]):.1f} us  {fl / med / 1e6:.1f} TFLOP/s = {fl / med / 1e6 / 157.3:.3f} of the fp32 MFMA peak")
+        print(f"{vv[0]} ({'pipelined 8' if vv[0] == 9 else 'waves'}): median {med:.1f} us  min {min(times[vv]):.1f} us  {fl / med / 1e6:.1f} TFLOP/s = {fl / med / 1e6 / 157.3:.3f} of the fp32 MFMA peak")
 print("done")
