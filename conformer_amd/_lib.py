@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CONFORMER_AMD_LIB") or os.path.join(_HERE, "lib", "libconformer_hip.so")
 
 _P, _I, _L, _F, _U = c_void_p, c_int, c_int64, c_float, c_uint64
-ABI_VERSION = 3        # CFM_ABI_VERSION of include/conformer_hip.h (checked in load())
+ABI_VERSION = 4        # CFM_ABI_VERSION of include/conformer_hip.h (checked in load())
 
 # name -> (restype, argtypes).  Mirrors include/conformer_hip.h one to one (checked by tests/test_abi.py).
 SIGNATURES = {
@@ -25,6 +25,9 @@ SIGNATURES = {
     "cfm_gemm_splitk_f32": (c_int, [_I, _P, _P, _P, _P, _F, _P, _P, _I, _L, _I, _I, _L, _L, _L, _P]),
     "cfm_gemm_lnfold_f32": (c_int, [_I, _P, _P, _I, _F, _P, _P, _P, _P, _L, _I, _I, _L, _L, _P]),
     "cfm_layernorm_fwd_stats_f32": (c_int, [_P, _P, _P, _P, _P, _L, _I, _F, _P]),
+    "cfm_ffn_pack_elems": (ctypes.c_int64, [_I, _I]),
+    "cfm_ffn_pack_f32": (c_int, [_P, _P, _P, _I, _I, _P]),
+    "cfm_ffn_fused_f32": (c_int, [_P, _L, _P, _I, _F, _P, _P, _P, _P, _F, _P, _L, _I, _P, _P, _P, _F, _L, _I, _I, _P]),
     "cfm_strerror": (c_char_p, [_I]),
     "cfm_device_check": (c_int, []),
     "cfm_subsampled_length": (c_int64, [_L]),
@@ -119,6 +122,9 @@ SIGNATURES = {
     "cfm_debug_set_attention_waves": (c_int, [_I]),
     "cfm_debug_gemm_cfg_f32": (c_int, [_I, _P, _P, _P, _P, _F, _P, _L, _I, _I, _P, _P]),
     "cfm_debug_set_conv2_bk": (c_int, [_I]),
+    "cfm_debug_ffn_trace": (c_int, [_P, _I]),
+    "cfm_debug_ffn_variant": (c_int, [_I]),
+    "cfm_debug_ffn_layout": (c_int, [_I, _I]),
     "cfm_relpos_table_f32": (c_int, [_P, _P, _I, _I, _P]),
     "cfm_relpos_attention_fwd_f32": (c_int, [_P, _P, _P, _L, _P, _L, _P, _P, _P, _P, _L, _P, _I, _I, _I, _I, _P]),
     "cfm_dwconv_bn_swish_fwd_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, _F, _P, _I, _I, _I, _I, _P]),

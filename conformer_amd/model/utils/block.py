@@ -3,7 +3,8 @@
 Each of the four residual sub-layers ends in an MFMA GEMM whose epilogue applies `alpha*y + x`
 (alpha = 1/2 for the two FFNs, block.py:19,25), so no stand-alone add/scale kernels run; the closing
 LayerNorm (block.py:27) is the wave-per-row kernel.  16 launches per block in total; 12 on the folded-LayerNorm
-inference path (fused_chain).
+inference path (fused_chain), 9 with the one-kernel feed-forward sub-layers (ops.ffn_fused: FFN2 also applies the closing
+LayerNorm).
 """
 from typing import Optional
 
@@ -56,8 +57,12 @@ class ConformerBlock(nn.Module):
         y, st = self.ffn_1.fused(x, residual=x, alpha=0.5, stats=x_stats, emit_stats=True)
         y, st = self.attention.fused(y, pos_table, lengths, residual=y, pos_projected=pos_projected, stats=st, emit_stats=True)
         y, st = self.conv.fused(y, residual=y, stats=st, emit_stats=True)
-        y = self.ffn_2.fused(y, residual=y, alpha=0.5, stats=st)
         ln = self.layer_norm
+        if self.ffn_2.fuses(y, y, st):                  # FFN2 + the closing LayerNorm in the one-kernel feed-forward
+            if want_stats:
+                return self.ffn_2.fused(y, residual=y, alpha=0.5, stats=st, emit_stats=True, closing_ln=ln)
+            return self.ffn_2.fused(y, residual=y, alpha=0.5, stats=st, closing_ln=ln), None
+        y = self.ffn_2.fused(y, residual=y, alpha=0.5, stats=st)
         if want_stats:
             return ops.layernorm(y, ln.weight, ln.bias, ln.eps, emit_stats=True)
         return ops.layernorm(y, ln.weight, ln.bias, ln.eps), None

@@ -306,6 +306,66 @@ def linear_lnfold(a, stats, wf, bf, cs, eps: float, act: str = "none", glu: bool
     return c
 
 
+# ---- fused feed-forward sub-layer (fp32 inference; csrc/ffn_fused_f32.hip) ---------------------------------------------------
+_FFN_FUSED = __import__("os").environ.get("CONFORMER_AMD_FFN_FUSED", "1") != "0"
+
+
+def set_ffn_fused(on: bool) -> bool:
+    """Enable / disable the one-kernel feed-forward sub-layer of the folded-LayerNorm inference path (default on;
+    CONFORMER_AMD_FFN_FUSED=0 disables).  Returns the previous setting.  Off = hidden GEMM + residual GEMM (two launches)."""
+    global _FFN_FUSED
+    prev, _FFN_FUSED = _FFN_FUSED, bool(on)
+    return prev
+
+
+def ffn_fused_ok(d: int, hidden: int, rows: int) -> bool:
+    """One workgroup per 32 rows: worth it once the rows fill the chip's 256 CUs (below that the two-GEMM path, with its
+    column-tile parallelism, is faster: a streaming chunk)."""
+    return bool(_FFN_FUSED and ln_fold_ok(d) and d in (128, 256, 512) and hidden % 128 == 0 and rows >= 32 * 192)
+
+
+def ffn_pack(w1f: torch.Tensor, w2: torch.Tensor) -> torch.Tensor:
+    """Both Linear weights of a FeedForwardModule in MFMA fragment order, slice by slice (once per weight version).
+    w1f: (hidden, d) = the LayerNorm-folded hidden weight (fold_layernorm); w2: (d, hidden)."""
+    w1f = _req(w1f, "W1f"); w2 = _req(w2, "W2")
+    hidden, d = w1f.shape
+    if tuple(w2.shape) != (d, hidden):
+        raise _lib.ConformerHipError(f"ffn_pack: W1f{tuple(w1f.shape)} and W2{tuple(w2.shape)} do not match")
+    lib = _lib.load()
+    wp = torch.zeros(int(lib.cfm_ffn_pack_elems(d, hidden)), device=w1f.device, dtype=torch.float32)   # (pads between tiles: zero)
+    _lib.check(lib.cfm_ffn_pack_f32(w1f.data_ptr(), w2.data_ptr(), wp.data_ptr(), d, hidden, _stream()), "cfm_ffn_pack_f32")
+    return wp
+
+
+def ffn_fused(x: torch.Tensor, stats: torch.Tensor, wp: torch.Tensor, b1f: torch.Tensor, cs: torch.Tensor, b2: torch.Tensor,
+              alpha: float, eps: float, emit_stats: bool = False, closing_ln=None):
+    """alpha * (swish(LN(x) @ W1.T + b1) @ W2.T + b2) + x in one kernel, LN folded (stats = the statistics partials of x's rows).
+    emit_stats: also return the statistics partials of the result's rows.  closing_ln = (weight, bias, eps): the result goes
+    through that LayerNorm (block.py:27) before it is stored; emit_stats then returns the (rows, 1, 2) statistics of ITS output."""
+    x = _req(x, "x"); stats = _req(stats, "ln_stats"); wp = _req(wp, "Wp"); b1f = _req(b1f, "b1f"); cs = _req(cs, "colsum")
+    b2 = _req(b2, "b2")
+    d = x.shape[-1]
+    rows = x.numel() // d
+    hidden = b1f.numel()
+    if stats.dim() != 3 or stats.shape[0] != rows or stats.shape[2] != 2 or wp.numel() != int(_lib.load().cfm_ffn_pack_elems(d, hidden)) or b2.numel() != d:
+        raise _lib.ConformerHipError(f"ffn_fused: x(...,{d}), stats{tuple(stats.shape)}, Wp({wp.numel()}), hidden {hidden} do not match")
+    y = torch.empty(x.shape, device=x.device, dtype=torch.float32)
+    st_out, g2, bt2, eps2, mode = None, None, None, 0.0, 0
+    if closing_ln is not None:
+        g2 = _req(closing_ln[0], "ln.weight"); bt2 = _req(closing_ln[1], "ln.bias"); eps2 = float(closing_ln[2]); mode = 2
+        if emit_stats:
+            st_out = torch.empty(rows, 1, 2, device=x.device, dtype=torch.float32)
+    elif emit_stats:
+        mode = 1
+        st_out = torch.empty(rows, d // 32, 2, device=x.device, dtype=torch.float32)
+    _lib.check(_lib.load().cfm_ffn_fused_f32(x.data_ptr(), d, stats.data_ptr(), stats.shape[1], float(eps), wp.data_ptr(),
+                                             b1f.data_ptr(), cs.data_ptr(), b2.data_ptr(), float(alpha), y.data_ptr(), d, mode,
+                                             None if st_out is None else st_out.data_ptr(),
+                                             None if g2 is None else g2.data_ptr(), None if bt2 is None else bt2.data_ptr(),
+                                             eps2, rows, d, hidden, _stream()), "cfm_ffn_fused_f32")
+    return (y, st_out) if emit_stats else y
+
+
 def layernorm(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, eps: float = 1e-5,
               out: Optional[torch.Tensor] = None, for_gemm: bool = False, emit_stats: bool = False):
     """for_gemm: the result only feeds GEMM operands -- under autocast it is written in the 16-bit matrix-pipe type (the

@@ -39,7 +39,7 @@ enum cfm_status {
 int cfm_version(void);                  /* library version, currently 1 */
 int cfm_abi_version(void);              /* CFM_ABI_VERSION this library was built against: bumped whenever an entry point's
                                            argument list changes or an entry point is removed; a binding refuses a mismatch */
-#define CFM_ABI_VERSION 3
+#define CFM_ABI_VERSION 4
 const char* cfm_strerror(int status);   /* static string */
 int cfm_device_check(void);             /* CFM_OK iff the current HIP device is gfx950 */
 
@@ -104,6 +104,21 @@ int cfm_gemm_lnfold_f32(int epi, const float* A, const float* ln_stats, int ln_p
                         int64_t M, int N, int K, int64_t lda, int64_t ldc, cfm_stream_t stream);
 int cfm_layernorm_fwd_stats_f32(const float* x, const float* gamma, const float* beta, float* y,
                                 float* stats_out, int64_t rows, int d, float eps, cfm_stream_t stream);
+
+/* ---- fused Macaron feed-forward sub-layer (inference, fp32 MFMA; round 3): ffn.py:15-23 + the residual of block.py:19,25 and,
+ *      in mode 2, the block-closing LayerNorm of block.py:27 -- ONE kernel per 32 rows, the (rows, hidden) activation stays on chip:
+ *        Y = alpha * (swish(LN(X).W1^T + b1).W2^T + b2) + X            (LN folded as in cfm_gemm_lnfold_f32: ln_stats of X's rows,
+ *                                                                        b1f / colsum1 = the folded bias / column sums of W1f)
+ *      mode 0: Y only | 1: + stats_out (M, d/32, 2), the statistics partials of the stored rows (as cfm_gemm_bias_residual_stats_f32)
+ *           | 2: Y = LayerNorm(...; gamma2, beta2, eps2), stats_out (M, 1, 2) of the LayerNorm OUTPUT or NULL.
+ *      Wp: both weights in MFMA fragment order (cfm_ffn_pack_f32 from W1f (hidden, d) = W1.diag(gamma) and W2 (d, hidden);
+ *      cfm_ffn_pack_elems floats; once per weight version).  d in {128, 256, 512}, hidden % 128 == 0; ln_parts in {1,...,16}. */
+int64_t cfm_ffn_pack_elems(int d, int hidden);
+int cfm_ffn_pack_f32(const float* W1f, const float* W2, float* Wp, int d, int hidden, cfm_stream_t stream);
+int cfm_ffn_fused_f32(const float* X, int64_t ldx, const float* ln_stats, int ln_parts, float ln_eps, const float* Wp,
+                      const float* b1f, const float* colsum1, const float* b2, float alpha, float* Y, int64_t ldy,
+                      int mode, float* stats_out, const float* gamma2, const float* beta2, float eps2, int64_t M,
+                      int d, int hidden, cfm_stream_t stream);
 
 /* ---- relative positional encoding table (RelativePositionalEncoding.forward, position.py:11-27,
  *      WITHOUT the batch repeat of position.py:26).  pe: (2T-1, d); row j encodes r = T-1-j:
@@ -393,6 +408,9 @@ int cfm_debug_gemm_mfma16_trace(void* trace_or_null);     /* per-K-tile stamps o
 int cfm_debug_gemm_cfg_f32(int cfg, const float* A, const float* W, const float* bias, const float* R,
                            float alpha, float* C, int64_t M, int N, int K, void* trace_or_null,
                            cfm_stream_t stream);
+int cfm_debug_ffn_trace(void* trace_or_null, int per_slice);   /* 128 x uint64 s_memrealtime stamps of cfm_ffn_fused_f32 (wave 0 of blocks 0 / 128), or NULL */
+int cfm_debug_ffn_variant(int v);               /* 0 | 1 = main loop without weight loads (wrong results: the pure MFMA rate) */
+int cfm_debug_ffn_layout(int pad_f4, int rotate); /* pad between packed tiles (16-byte units; < 0 keeps it) and the per-workgroup slice rotation: re-pack after changing */
 int cfm_debug_set_conv2_bk(int bk);   /* K-tile of cfm_subsample_conv2_relu_f32: 16 (default) | 32; returns the previous setting */
 /*      cfg + 16: bias epilogue; cfg + 32: swish epilogue; cfg + 64: K-tile 32 (a staged row = one whole 128-byte line;
  *      measured slower than the K-tile 16 loop at every hot-path shape but one: kept for tools/gemm_tune.py bk). */
