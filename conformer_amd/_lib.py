@@ -27,6 +27,11 @@ SIGNATURES = {
     "cfm_layernorm_fwd_stats_f32": (c_int, [_P, _P, _P, _P, _P, _L, _I, _F, _P]),
     "cfm_ffn_pack_elems": (ctypes.c_int64, [_I, _I]),
     "cfm_ffn_pack_f32": (c_int, [_P, _P, _P, _I, _I, _P]),
+    "cfm_rowgemm_pack_f32": (c_int, [_P, _P, _I, _I, _I, _P]),
+    "cfm_rowchain_f32": (c_int, [_I, _I, _I, _I, _P, _L, _P, _P, _P, _L, _P, _L, _P, _I, _F, _P, _P, _P, _P, _F, _I, _P, _L, _P, _P, _P, _F,
+                                 _P, _P, _P, _F, _P, _L, _L, _I, _P]),
+    "cfm_ffn_tile_stride_f4": (ctypes.c_int64, [_I]),
+    "cfm_ffn_rotate": (c_int, []),
     "cfm_ffn_fused_f32": (c_int, [_P, _L, _P, _I, _F, _P, _P, _P, _P, _F, _P, _L, _I, _P, _P, _P, _F, _L, _I, _I, _P]),
     "cfm_strerror": (c_char_p, [_I]),
     "cfm_device_check": (c_int, []),

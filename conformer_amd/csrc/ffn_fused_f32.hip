@@ -327,6 +327,8 @@ extern "C" int cfm_debug_ffn_layout(int pad_f4, int rotate) {           // diagn
     return CFM_OK;
 }
 static int64_t ffn_tile_stride(int d) { return (int64_t)2 * (d / 8) * 64 + g_ffn_pad; }
+extern "C" int64_t cfm_ffn_tile_stride_f4(int d) { return ffn_tile_stride(d); }   // (rowchain_f32.hip runs the same packed stream)
+extern "C" int cfm_ffn_rotate(void) { return g_ffn_rotate; }
 extern "C" int64_t cfm_ffn_pack_elems(int d, int hidden) { return ffn_tile_stride(d) * (hidden / 32) * 4; }
 
 extern "C" int cfm_ffn_pack_f32(const float* W1f, const float* W2, float* Wp, int d, int hidden, cfm_stream_t stream) {

@@ -16,6 +16,7 @@ from ... import ops
 from .attention import MultiHeadSelfAttentionModule
 from .convolution import ConvolutionModule
 from .ffn import FeedForwardModule
+from ._guard import refuse_dropout
 from .masking import lengths_from_key_padding_mask
 
 
@@ -54,6 +55,9 @@ class ConformerBlock(nn.Module):
             if ag.needs_grad(self.layer_norm, y):
                 return ag.LayerNormFn.apply(y, self.layer_norm.weight, self.layer_norm.bias, self.layer_norm.eps), None
             return ops.layernorm(y, self.layer_norm.weight, self.layer_norm.bias, self.layer_norm.eps), None
+        if x_stats is not None and x.is_contiguous() and ops.rowchain_ok(x.shape[-1], self.ffn_1.hidden_linear.out_features,
+                                                                          x.numel() // x.shape[-1]):
+            return self._row_chains(x, pos_table, lengths, pos_projected, x_stats, want_stats)
         y, st = self.ffn_1.fused(x, residual=x, alpha=0.5, stats=x_stats, emit_stats=True)
         y, st = self.attention.fused(y, pos_table, lengths, residual=y, pos_projected=pos_projected, stats=st, emit_stats=True)
         y, st = self.conv.fused(y, residual=y, stats=st, emit_stats=True)
@@ -66,6 +70,41 @@ class ConformerBlock(nn.Module):
         if want_stats:
             return ops.layernorm(y, ln.weight, ln.bias, ln.eps, emit_stats=True)
         return ops.layernorm(y, ln.weight, ln.bias, ln.eps), None
+
+    def _row_chains(self, x, pos_table, lengths, pos_projected, x_stats, want_stats):
+        """The block as 5 launches (ops.rowchain_*): K1 = FFN1 + q|k|v projection, attention, K2 = out_proj + pointwise_conv_1 + GLU,
+        depthwise conv + BatchNorm + Swish, K3 = pointwise_conv_2 + FFN2 + closing LayerNorm -- every row-local stretch of
+        block.py:17-29 in one kernel per 32 rows (csrc/rowchain_f32.hip)."""
+        f1, f2, att, cv = self.ffn_1, self.ffn_2, self.attention, self.conv
+        a, ln_a, ln_c, bn = att.attention, att.layer_norm, cv.layer_norm, cv.batch_norm
+        for m, name in ((f1, "FeedForwardModule"), (att, "MultiHeadSelfAttentionModule"), (a, "RelativeMultiHeadAttention"),
+                        (cv, "ConvolutionModule"), (f2, "FeedForwardModule")):
+            refuse_dropout(m, name)
+        ffn1 = f1._packs.get("ffn_pack", (f1.hidden_linear.weight, f1.hidden_linear.bias, f1.layer_norm.weight, f1.layer_norm.bias,
+                                          f1.out_linear.weight), f1._pack)
+        ffn2 = f2._packs.get("ffn_pack", (f2.hidden_linear.weight, f2.hidden_linear.bias, f2.layer_norm.weight, f2.layer_norm.bias,
+                                          f2.out_linear.weight), f2._pack)
+        wqkv, bqkv = a._qkv_params()
+
+        def fold_pack(w, b, ln, glu=False):
+            wf, bf, cs = ops.fold_layernorm(w, b, ln.weight, ln.bias)
+            return ops.rowgemm_pack(wf, glu=glu), bf, cs
+
+        wq_p, bq_f, csq = a._packs.get("qkv_chain", (wqkv, bqkv, ln_a.weight, ln_a.bias), lambda: fold_pack(wqkv, bqkv, ln_a))
+        wo_p = a._packs.get("out_chain", (a.out_proj.weight,), lambda: ops.rowgemm_pack(a.out_proj.weight.detach()))
+        pw1, pw2 = cv.pointwise_conv_1, cv.pointwise_conv_2
+        wg_p, bg_f, csg = cv._packs.get("pw1_chain", (pw1.weight, pw1.bias, ln_c.weight, ln_c.bias),
+                                        lambda: fold_pack(pw1.weight, pw1.bias, ln_c, glu=True))
+        w2_p = cv._packs.get("pw2_chain", (pw2.weight,), lambda: ops.rowgemm_pack(pw2.weight.detach()))
+        y, qkv = ops.rowchain_ffn_qkv(x, x_stats, ffn1, f1.out_linear.bias, 0.5, f1.layer_norm.eps, wq_p, bq_f, csq, ln_a.eps)
+        pos = pos_projected if pos_projected is not None else ops.linear(pos_table, a.pos_proj.weight, a.pos_proj.bias)
+        ctx = ops.relpos_attention(qkv, pos, a.content_bias, a.position_bias, lengths, a.n_heads)
+        y2, g = ops.rowchain_out_glu(ctx, wo_p, a.out_proj.bias, y, wg_p, bg_f, csg, ln_c.eps)
+        c = ops.dwconv_bn_swish(g, cv.deepwise_conv.weight, cv.deepwise_conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                                bn.eps)
+        ln = self.layer_norm
+        return ops.rowchain_pw2_ffn_ln(c, w2_p, pw2.bias, y2, ffn2, f2.out_linear.bias, 0.5, f2.layer_norm.eps,
+                                       (ln.weight, ln.bias, ln.eps), want_stats)
 
     def forward(self, x: torch.Tensor, pos_embedding: torch.Tensor, mask: Optional[torch.Tensor] = None) -> torch.Tensor:
         table = pos_embedding[0] if pos_embedding.dim() == 3 else pos_embedding

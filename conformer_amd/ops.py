@@ -366,6 +366,84 @@ def ffn_fused(x: torch.Tensor, stats: torch.Tensor, wp: torch.Tensor, b1f: torch
     return (y, st_out) if emit_stats else y
 
 
+# ---- row-local chains of a block (fp32 inference; csrc/rowchain_f32.hip) --------------------------------------------------------
+_ROWCHAIN = __import__("os").environ.get("CONFORMER_AMD_ROWCHAIN", "0") == "1"
+
+
+def set_rowchain(on: bool) -> bool:
+    """Enable / disable the three-kernel row-chain form of a block's row-local operators.  Default OFF (CONFORMER_AMD_ROWCHAIN=1
+    enables): measured inside the cfg-2 forward the chains are a wash against the kernels they merge (K1 378 vs 276 + 110 us,
+    K2 126 vs 43 + 77 us, K3 314 vs 43 + 272 us; forward 20.6 vs 20.5 ms -- DESIGN.md section 5, round 3).  Returns the previous
+    setting."""
+    global _ROWCHAIN
+    prev, _ROWCHAIN = _ROWCHAIN, bool(on)
+    return prev
+
+
+def rowchain_ok(d: int, hidden: int, rows: int) -> bool:
+    return bool(_ROWCHAIN and ffn_fused_ok(d, hidden, rows))
+
+
+def rowgemm_pack(w: torch.Tensor, glu: bool = False) -> torch.Tensor:
+    """A (N, d) Linear weight in MFMA fragment order per wave for the row chains (once per weight version); glu: (2 d, d), value
+    rows then gate rows."""
+    w = _req(w.reshape(w.shape[0], -1), "W")
+    n, d = w.shape
+    wp = torch.empty(n * d, device=w.device, dtype=torch.float32)
+    _lib.check(_lib.load().cfm_rowgemm_pack_f32(w.data_ptr(), wp.data_ptr(), n, d, 1 if glu else 0, _stream()), "cfm_rowgemm_pack_f32")
+    return wp
+
+
+def _rowchain(pre, core, post, mode, x, d, *, wpre=None, bpre=None, res=None, y1=None, stats=None, ln_eps=0.0, ffn=None, b2=None,
+              alpha=0.0, y=None, stats_out=None, ln2=None, wpost=None, bpost=None, cspost=None, post_eps=0.0, z=None):
+    rows = x.numel() // d
+    ptr = lambda t: None if t is None else t.data_ptr()   # noqa: E731
+    wp, b1f, cs1 = ffn if ffn is not None else (None, None, None)
+    hidden = 0 if b1f is None else b1f.numel()
+    g2, bt2, eps2 = ln2 if ln2 is not None else (None, None, 0.0)
+    st = _lib.load().cfm_rowchain_f32(pre, core, post, mode, x.data_ptr(), d, ptr(wpre), ptr(bpre), ptr(res), d, ptr(y1), d,
+                                      ptr(stats), 0 if stats is None else stats.shape[1], float(ln_eps), ptr(wp), ptr(b1f), ptr(cs1),
+                                      ptr(b2), float(alpha), hidden, ptr(y), d, ptr(stats_out), ptr(g2), ptr(bt2), float(eps2),
+                                      ptr(wpost), ptr(bpost), ptr(cspost), float(post_eps), ptr(z), 0 if z is None else z.shape[-1],
+                                      rows, d, _stream())
+    _lib.check(st, "cfm_rowchain_f32")
+
+
+def rowchain_ffn_qkv(x, stats, ffn, b2, alpha: float, ffn_eps: float, wqkv_p, bqkv_f, csqkv, att_eps: float):
+    """K1 (block.py:19-21): y = x + alpha FFN(x) [LN folded, `stats` of x's rows; ffn = (Wp, b1f, colsum1) of ffn_pack / fold_layernorm]
+    and qkv = LN_att(y) @ Wqkv.T + b (LN folded: wqkv_p = rowgemm_pack of the folded (3d, d) weight).  Returns (y, qkv)."""
+    x = _req(x, "x"); stats = _req(stats, "ln_stats")
+    d = x.shape[-1]
+    y = torch.empty(x.shape, device=x.device, dtype=torch.float32)
+    qkv = torch.empty(*x.shape[:-1], 3 * d, device=x.device, dtype=torch.float32)
+    _rowchain(0, 1, 1, 0, x, d, stats=stats, ln_eps=ffn_eps, ffn=ffn, b2=_req(b2, "b2"), alpha=alpha, y=y, wpost=wqkv_p,
+              bpost=bqkv_f, cspost=csqkv, post_eps=att_eps, z=qkv)
+    return y, qkv
+
+
+def rowchain_out_glu(ctx, wout_p, bout, res, wglu_p, bglu_f, csglu, conv_eps: float):
+    """K2 (block.py:21-23): y2 = ctx @ Wout.T + b + res and g = GLU(LN_conv(y2) @ Wpw1.T + b) (LN folded).  Returns (y2, g)."""
+    ctx = _req(ctx, "ctx"); res = _req(res, "residual")
+    d = ctx.shape[-1]
+    y2 = torch.empty(ctx.shape, device=ctx.device, dtype=torch.float32)
+    g = torch.empty(ctx.shape, device=ctx.device, dtype=torch.float32)
+    _rowchain(1, 0, 2, 0, ctx, d, wpre=wout_p, bpre=_req(bout, "bias"), res=res, y1=y2, ln_eps=conv_eps, wpost=wglu_p, bpost=bglu_f,
+              cspost=csglu, z=g)
+    return y2, g
+
+
+def rowchain_pw2_ffn_ln(c, wpw2_p, bpw2, res, ffn, b2, alpha: float, ffn_eps: float, closing_ln, want_stats: bool = False):
+    """K3 (block.py:23-27): y3 = c @ Wpw2.T + b + res; out = LayerNorm(y3 + alpha FFN(y3)) (closing_ln = (weight, bias, eps)).
+    Returns (out, statistics (rows, 1, 2) of out or None)."""
+    c = _req(c, "c"); res = _req(res, "residual")
+    d = c.shape[-1]
+    out = torch.empty(c.shape, device=c.device, dtype=torch.float32)
+    st = torch.empty(c.numel() // d, 1, 2, device=c.device, dtype=torch.float32) if want_stats else None
+    _rowchain(1, 1, 0, 2, c, d, wpre=wpw2_p, bpre=_req(bpw2, "bias"), res=res, ln_eps=ffn_eps, ffn=ffn, b2=_req(b2, "b2"), alpha=alpha,
+              y=out, stats_out=st, ln2=(_req(closing_ln[0], "ln.weight"), _req(closing_ln[1], "ln.bias"), float(closing_ln[2])))
+    return out, st
+
+
 def layernorm(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, eps: float = 1e-5,
               out: Optional[torch.Tensor] = None, for_gemm: bool = False, emit_stats: bool = False):
     """for_gemm: the result only feeds GEMM operands -- under autocast it is written in the 16-bit matrix-pipe type (the

@@ -120,6 +120,28 @@ int cfm_ffn_fused_f32(const float* X, int64_t ldx, const float* ln_stats, int ln
                       int mode, float* stats_out, const float* gamma2, const float* beta2, float eps2, int64_t M,
                       int d, int hidden, cfm_stream_t stream);
 
+/* ---- row-local chains of a Conformer block (inference, fp32 MFMA; round 3): everything between two operators that mix rows
+ *      (attention, the depthwise convolution) runs in ONE kernel per 32 rows, the rows resident in LDS, weights streamed in MFMA
+ *      fragment order (cfm_rowgemm_pack_f32 for the d-input Linear layers, cfm_ffn_pack_f32 for the feed-forward):
+ *        K1 = (pre 0, core 1, post 1, mode 0)  block.py:19-21: Y = x + FFN1(x)/2 (as cfm_ffn_fused_f32, ln_stats of x's rows);
+ *                                              Z (M, 3d) = LN(Y).Wqkv^T + b, the LayerNorm of attention.py:15 folded (Wpost = the
+ *                                              packed folded weight, bpost / cspost = folded bias / column sums, post_eps)
+ *        K2 = (pre 1, core 0, post 2)          block.py:21-23: Y1 = X.Wout^T + b + R (attention.py:90 + residual; stored);
+ *                                              Z (M, d) = GLU(LN(Y1).Wpw1^T + b), convolution.py:22-25 (ln_eps = that LayerNorm's)
+ *        K3 = (pre 1, core 1, post 0, mode 2)  block.py:23-27: Y1 = X.Wpw2^T + b + R (convolution.py:29 + residual; Y1 may be NULL);
+ *                                              Y = LayerNorm(Y1 + FFN2(Y1)/2; gamma2, beta2, eps2), stats_out (M, 1, 2) or NULL
+ *      Unused stage arguments are NULL / 0.  d in {128, 256, 512}; leading dimensions % 4 == 0, 16-byte aligned pointers.
+ *      cfm_rowgemm_pack_f32: W (N, d) -> packed (same element count); glu = 1: W is (2 d, d), value rows then gate rows. */
+int cfm_rowgemm_pack_f32(const float* W, float* Wp, int N, int d, int glu, cfm_stream_t stream);
+int cfm_rowchain_f32(int pre, int core, int post, int mode, const float* X, int64_t ldx, const float* Wpre_packed,
+                     const float* bpre, const float* R, int64_t ldr, float* Y1, int64_t ldy1, const float* ln_stats,
+                     int ln_parts, float ln_eps, const float* Wffn_packed, const float* b1f, const float* colsum1,
+                     const float* b2, float alpha, int hidden, float* Y, int64_t ldy, float* stats_out,
+                     const float* gamma2, const float* beta2, float eps2, const float* Wpost_packed, const float* bpost,
+                     const float* cspost, float post_eps, float* Z, int64_t ldz, int64_t M, int d, cfm_stream_t stream);
+int64_t cfm_ffn_tile_stride_f4(int d);   /* layout parameters of cfm_ffn_pack_f32 shared by the two kernels (internal) */
+int cfm_ffn_rotate(void);
+
 /* ---- relative positional encoding table (RelativePositionalEncoding.forward, position.py:11-27,
  *      WITHOUT the batch repeat of position.py:26).  pe: (2T-1, d); row j encodes r = T-1-j:
  *      pe[j,2c] = sin(r*div_term[c]), pe[j,2c+1] = cos(r*div_term[c]).  div_term: (d/2). */

@@ -104,6 +104,32 @@ def module_cases(tag, d, H, K, B, T, lengths, seed, param_grads=True):
     save(f"modules_{tag}", dict(cfg, B=B, T=T), **out)
 
 
+def stream_mask_case(tag, d, H, B, T, chunk_ends, seed):
+    """The attention half of the streaming PREFIX RULE pinned to the reference: MultiHeadSelfAttentionModule accepts any
+    broadcastable bool mask (attention.py:60-62, True = hidden), so a block-triangular (1, 1, T', T') mask -- row i hides keys
+    >= the end of its own chunk -- gives the reference's answer for 'chunk c attends to chunks <= c'.  (The depthwise-conv half
+    of the rule has no reference counterpart: nn.Conv1d cannot be masked per output row.)"""
+    cfg = dict(vocab=11, n_mel=80, n_blocks=1, d=d, n_heads=H, ksize=15, lstm_hidden=16, seed=seed)
+    P = O.make_params(**cfg)
+    g = torch.Generator().manual_seed(seed + 1)
+    x = torch.randn(B, T, d, generator=g)
+    rel = RelativePositionalEncoding(d)
+    rel.load_state_dict({"div_term": P["encoder.rel_pe.div_term"]})
+    pe = rel(x)
+    visible_end = torch.empty(T, dtype=torch.long)
+    start = 0
+    for e in chunk_ends:
+        visible_end[start:e] = e
+        start = e
+    assert start == T
+    mask = (torch.arange(T)[None, :] >= visible_end[:, None])[None, None]     # (1, 1, T, T), True = hidden
+    m = MultiHeadSelfAttentionModule(d, H).eval()
+    m.load_state_dict(sub(P, "encoder.layers.0.attention."))
+    with torch.no_grad():
+        y = m(x, pe, mask)
+    save(f"stream_mhsa_{tag}", dict(cfg, B=B, T=T), x=npy(x), chunk_ends=np.array(chunk_ends, dtype=np.int64), mhsa_y=npy(y))
+
+
 def stem_case(tag, d, B, T, seed):
     cfg = dict(vocab=11, n_mel=80, n_blocks=0, d=d, n_heads=1, ksize=3, lstm_hidden=8, seed=seed)
     P = O.make_params(**cfg)
@@ -161,6 +187,10 @@ def model_case(tag, vocab, n_blocks, d, H, K, hid, B, T, lengths, seed, tgt_len,
 
 if __name__ == "__main__":
     torch.manual_seed(0)
+    if sys.argv[1:] == ["stream"]:             # (added in round 3: only the streaming-mask goldens, the others stay as committed)
+        stream_mask_case("d64_t70", d=64, H=4, B=2, T=70, chunk_ends=[16, 32, 37, 70], seed=51)
+        stream_mask_case("d144_t49", d=144, H=4, B=1, T=49, chunk_ends=[1, 2, 40, 49], seed=52)
+        sys.exit(0)
     # T' in {1, 7, 48, 49}; ragged lengths; odd head dims; K=31 and a small K
     module_cases("d32_t7", d=32, H=4, K=31, B=3, T=7, lengths=[7, 5, 1], seed=11)
     module_cases("d32_t48", d=32, H=4, K=31, B=2, T=48, lengths=[48, 33], seed=12)
@@ -175,3 +205,5 @@ if __name__ == "__main__":
     # BASELINE cfg-1: Conformer-S, B=2, T=200, lengths [200,160]
     model_case("cfg1_S", vocab=370, n_blocks=4, d=144, H=4, K=31, hid=320, B=2, T=200, lengths=[200, 160],
                seed=41, tgt_len=[12, 9], with_grads=False)
+    stream_mask_case("d64_t70", d=64, H=4, B=2, T=70, chunk_ends=[16, 32, 37, 70], seed=51)
+    stream_mask_case("d144_t49", d=144, H=4, B=1, T=49, chunk_ends=[1, 2, 40, 49], seed=52)

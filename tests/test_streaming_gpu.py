@@ -150,3 +150,32 @@ def test_graphed_chunk_steps_equal_eager(dev):
             t0 += c
         assert eager.frames == graphed.frames and eager.tail_len == graphed.tail_len
     assert len(graphed._graphs) == sum(1 for _ in graphed._graphs) >= 4
+
+
+@pytest.mark.parametrize("case", ["stream_mhsa_d64_t70", "stream_mhsa_d144_t49"])
+def test_attention_rows_kernel_vs_reference_block_triangular_mask(dev, case):
+    """The incremental attention of the streaming path (cfm_relpos_attention_rows_f32: query rows of chunk c against the cached
+    keys of chunks <= c) against the REFERENCE's MultiHeadSelfAttentionModule under the block-triangular (1, 1, T', T') mask
+    that expresses the same rule (attention.py:60-62; golden from tests/golden/make_golden.py stream)."""
+    from conformer_amd import ops
+    from tests.util import cfg_params, load_golden
+    meta, g = load_golden(case)
+    P = {k: v.to(dev) for k, v in cfg_params(meta).items()}
+    a = "encoder.layers.0.attention."
+    x = g["x"].to(dev)
+    B, T, d = x.shape
+    H = meta["n_heads"]
+    xn = ops.layernorm(x, P[a + "layer_norm.weight"], P[a + "layer_norm.bias"])
+    wqkv = torch.cat([P[a + f"attention.{n}_proj.weight"] for n in ("query", "key", "value")]).contiguous()
+    bqkv = torch.cat([P[a + f"attention.{n}_proj.bias"] for n in ("query", "key", "value")]).contiguous()
+    qkv = ops.linear(xn, wqkv, bqkv)                                     # (B, T, 3d): the K/V cache of the whole utterance
+    pe = ops.relpos_table(P["encoder.rel_pe.div_term"][None], T)
+    pos = ops.linear(pe, P[a + "attention.pos_proj.weight"], P[a + "attention.pos_proj.bias"])
+    ctx = torch.zeros(B, T, d, device=dev)
+    start = 0
+    for e in g["chunk_ends"].tolist():
+        L = torch.full((B,), e, dtype=torch.int64, device=dev)          # keys of chunks <= c: the cache holds e frames
+        ops.relpos_attention_rows(qkv, pos, P[a + "attention.content_bias"], P[a + "attention.position_bias"], L, H, start, e - start, ctx)
+        start = e
+    y = ops.linear(ctx, P[a + "attention.out_proj.weight"], P[a + "attention.out_proj.bias"])
+    assert rel_l2(y, g["mhsa_y"]) < 2e-5
