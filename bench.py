@@ -110,11 +110,27 @@ def gemm_site_table(enc, x, iters):
         sites = [
             ("gemm<relu,conv>  stem conv2 implicit GEMM", (B * Tp * Fp, d, 9 * d), 1, conv2),
             ("gemm<bias+stats> input linear", (N, d, Fp * d), 1, lambda: ops.linear(h2, wl, enc.linear.bias, emit_stats=True)),
-            ("gemm<LN,swish>   FFN hidden (LayerNorm folded)", (N, 4 * d, d), 2 * L, lambda: ops.linear_lnfold(a_d, stt, *f1, 1e-5, act="swish")),
-            ("gemm<resid+stats> FFN-1 out", (N, d, 4 * d), L,
-             lambda: ops.linear_residual(a_4d, lay.ffn_1.out_linear.weight, lay.ffn_1.out_linear.bias, res, 0.5, emit_stats=True)),
-            ("gemm<residual>   FFN-2 out", (N, d, 4 * d), L,
-             lambda: ops.linear_residual(a_4d, lay.ffn_1.out_linear.weight, lay.ffn_1.out_linear.bias, res, 0.5)),
+        ]
+        if ops.ffn_fused_ok(d, 4 * d, N):
+            # the one-kernel feed-forward sub-layers (csrc/ffn_fused_f32.hip): (M, N, K) = (rows, 2 x 4d, d) carries the FLOPs of both products
+            wp, bf_, cs_ = lay.ffn_1._pack()
+            ln_b = lay.layer_norm
+            sites += [
+                ("ffn_fused<stats>  FFN-1: LN fold + Linear + Swish + Linear + x/2 residual", (N, 8 * d, d), L,
+                 lambda: ops.ffn_fused(a_d, stt, wp, bf_, cs_, lay.ffn_1.out_linear.bias, 0.5, 1e-5, emit_stats=True)),
+                ("ffn_fused<LN>     FFN-2 + the block's closing LayerNorm", (N, 8 * d, d), L,
+                 lambda: ops.ffn_fused(a_d, stt, wp, bf_, cs_, lay.ffn_1.out_linear.bias, 0.5, 1e-5, emit_stats=True,
+                                       closing_ln=(ln_b.weight, ln_b.bias, ln_b.eps))),
+            ]
+        else:
+            sites += [
+                ("gemm<LN,swish>   FFN hidden (LayerNorm folded)", (N, 4 * d, d), 2 * L, lambda: ops.linear_lnfold(a_d, stt, *f1, 1e-5, act="swish")),
+                ("gemm<resid+stats> FFN-1 out", (N, d, 4 * d), L,
+                 lambda: ops.linear_residual(a_4d, lay.ffn_1.out_linear.weight, lay.ffn_1.out_linear.bias, res, 0.5, emit_stats=True)),
+                ("gemm<residual>   FFN-2 out", (N, d, 4 * d), L,
+                 lambda: ops.linear_residual(a_4d, lay.ffn_1.out_linear.weight, lay.ffn_1.out_linear.bias, res, 0.5)),
+            ]
+        sites += [
             ("gemm<LN,bias>    fused QKV (LayerNorm folded)", (N, 3 * d, d), L, lambda: ops.linear_lnfold(a_d, stt, *fq, 1e-5)),
             ("gemm<bias>       pos proj (all layers, one launch)", (P, L * d, d), 1, lambda: ops.linear(pe, posw, posb)),
             ("gemm<resid+stats> attn out / pw2", (N, d, d), 2 * L,
@@ -506,8 +522,8 @@ def main():
             "algorithmic_bytes": dom.get("alg_bytes"),
             "mfma_util": (pmc_mfma_row(dom["pmc_name"]) or {}).get("mfma_util") if dom.get("pmc_name") else None,
             "pmc": {"dominant": pmc_mfma_row(dom["pmc_name"]) if dom.get("pmc_name") else None,
-                    "attention_forward": pmc_mfma_row("relpos_attn_fwd_kernel"),
-                    "ffn_hidden_gemm": pmc_mfma_row("gemm_f32_kernel<128, 64, 1, false")},
+                    "attention_forward": pmc_mfma_row("relpos_attn_fwd8p_kernel") or pmc_mfma_row("relpos_attn_fwd_kernel"),
+                    "ffn_fused": pmc_mfma_row("ffn_fused_f32_kernel<16, 1") or pmc_mfma_row("gemm_f32_kernel<128, 64, 1, false")},
             "avg_launch_ms": dom["avg_ms"], "launches_per_step": dom["launches_per_step"],
             "gemm_ms_per_step": tot, "gemm_share_of_step": tot / ms,
             "all_gemm_sites": [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in r.items()

@@ -48,6 +48,7 @@ SIGNATURES = {
     "cfm_cast16_f32": (c_int, [_I, _P, _P, _L, _P]),
     "cfm_cast16_multi_f32": (c_int, [_I, _P, _I, _P]),
     "cfm_relpos_attention_mfma16_f32": (c_int, [_I, _P, _P, _P, _L, _P, _L, _P, _P, _P, _P, _L, _P, _I, _I, _I, _I, _F, _U, _P]),
+    "cfm_relpos_attention_rows_mfma16_f32": (c_int, [_I, _P, _P, _P, _L, _P, _L, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _P]),
     "cfm_relpos_attention_io16_mfma16_f32": (c_int, [_I, _P, _P, _P, _I, _L, _P, _L, _P, _P, _P, _P, _I, _L, _I, _I, _I, _I, _P]),
     "cfm_subsample_conv2_relu_mfma16_f32": (c_int, [_I, _P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P]),
     "cfm_subsample_conv1_relu_out16_f32": (c_int, [_I, _P, _P, _P, _P, _I, _I, _I, _I, _P]),

@@ -31,6 +31,7 @@ struct Attn16Args {
     int qkv16;                   // q / k / v are stored in that type (ld in elements): what torch.autocast hands the attention core
     int B, T, H, dh; float inv_sqrt_dh;
     float drop_p; unsigned long long drop_seed;
+    int q_begin, q_end;          // query rows computed: [q_begin, q_end) (the whole utterance, or a streaming chunk against its K/V cache)
 };
 
 // QKV16: q / k / v are stored in T16 (compile-time: a run-time test around the loads costs their overlap -- the compiler waits
@@ -50,9 +51,9 @@ __global__ __launch_bounds__(256, 2) void relpos_attn_fwd_mfma16_kernel(const At
     const int li = lane & 31, hf = lane >> 5;
     const int bh = blockIdx.y, b = bh / a.H, h = bh % a.H;
     const int T = a.T, dh = a.dh;
-    const int q0 = blockIdx.x * 128;
+    const int q0 = a.q_begin + blockIdx.x * 128;
     const int i0 = q0 + wave * 32;
-    const bool active = i0 < T;
+    const bool active = i0 < a.q_end;
 
     int klen = T;
     bool uniform = false;
@@ -288,7 +289,7 @@ __global__ __launch_bounds__(256, 2) void relpos_attn_fwd_mfma16_kernel(const At
         if (kt + 1 < ntiles) __syncthreads();                       // one barrier per key tile
     }
 
-    if (active && i0 + li < T) {
+    if (active && i0 + li < a.q_end) {
         const float inv = 1.0f / lrow;
         float* orow = a.ctx + ((int64_t)b * T + i0 + li) * a.ldo + h * dh;
 #pragma unroll
@@ -314,7 +315,10 @@ __global__ __launch_bounds__(256, 2) void relpos_attn_fwd_mfma16_kernel(const At
 static int attn16_launch(int prec, const float* q, const float* k, const float* v, int64_t ld, const float* pos, int64_t ldp,
                          const float* u, const float* vbias, const int64_t* lengths_or_null, void* ctxv, int ctx16, int64_t ldo,
                          float* lse_or_null, int B, int T, int H, int dh, float drop_p, uint64_t drop_seed, cfm_stream_t stream,
-                         int qkv16 = 0) {
+                         int qkv16 = 0, int q_begin = 0, int q_count = -1) {
+    if (q_count < 0) q_count = T - q_begin;
+    CFM_REQUIRE(q_begin >= 0 && q_count >= 0 && q_begin + q_count <= T, CFM_ERR_BAD_SHAPE);
+    if (q_count == 0) return CFM_OK;
     float* ctx = static_cast<float*>(ctxv);
     CFM_REQUIRE(q && k && v && pos && u && vbias && ctx, CFM_ERR_NULL);
     CFM_REQUIRE(B > 0 && T > 0 && H > 0 && dh > 0 && (dh & 3) == 0, CFM_ERR_BAD_SHAPE);
@@ -324,8 +328,8 @@ static int attn16_launch(int prec, const float* q, const float* k, const float* 
                 CFM_ALIGNED16(vbias) && CFM_ALIGNED16(ctx), CFM_ERR_ALIGN);
     CFM_REQUIRE((int64_t)B * H <= 65535 && T < (1 << 28), CFM_ERR_UNSUPPORTED);
     const Attn16Args a{q, k, v, ld, pos, ldp, u, vbias, lengths_or_null, ctx, ldo, lse_or_null, ctx16, qkv16, B, T, H, dh,
-                       1.0f / sqrtf((float)dh), drop_p, drop_seed};
-    const dim3 grid((unsigned)((T + 127) / 128), (unsigned)(B * H)), block(256);
+                       1.0f / sqrtf((float)dh), drop_p, drop_seed, q_begin, q_begin + q_count};
+    const dim3 grid((unsigned)((q_count + 127) / 128), (unsigned)(B * H)), block(256);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (prec == CFM_PREC_BF16) {
         if (qkv16) hipLaunchKernelGGL((relpos_attn_fwd_mfma16_kernel<__bf16, true>), grid, block, 0, s, a);
@@ -344,6 +348,18 @@ extern "C" int cfm_relpos_attention_mfma16_f32(int prec, const float* q, const f
                                                cfm_stream_t stream) {
     return attn16_launch(prec, q, k, v, ld, pos, ldp, u, vbias, lengths_or_null, ctx, 0, ldo, lse_or_null, B, T, H, dh, drop_p,
                          drop_seed, stream);
+}
+// Incremental attention over a K/V cache under autocast (streaming: BASELINE cfg-5): the 16-bit form of
+// cfm_relpos_attention_rows_f32 -- only query rows [q_begin, q_begin + q_count) are computed, against keys < lengths[b]; q / k / v
+// are the fp32 cache (rounded to `prec` where they enter a product, as torch.autocast's attention core does), ctx fp32.  No key
+// split: a workgroup walks the whole cache.
+extern "C" int cfm_relpos_attention_rows_mfma16_f32(int prec, const float* q, const float* k, const float* v, int64_t ld,
+                                                    const float* pos, int64_t ldp, const float* u, const float* vbias,
+                                                    const int64_t* lengths, float* ctx, int64_t ldo, int B, int T, int H, int dh,
+                                                    int q_begin, int q_count, cfm_stream_t stream) {
+    CFM_REQUIRE(lengths != nullptr, CFM_ERR_NULL);
+    return attn16_launch(prec, q, k, v, ld, pos, ldp, u, vbias, lengths, ctx, 0, ldo, nullptr, B, T, H, dh, 0.f, 0, stream, 0, q_begin,
+                         q_count);
 }
 // Inference under autocast with 16-bit tensors either side of the core: qkv_is_16bit -- q / k / v stored in `prec` (ld in elements;
 // what torch.autocast's projections hand the attention: the reference rounds them there too); ctx_is_16bit -- the context stored in

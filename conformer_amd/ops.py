@@ -636,7 +636,7 @@ def relpos_attention_rows(qkv: torch.Tensor, pos: torch.Tensor, u: torch.Tensor,
     beyond `lengths` are ignored, every length >= 1), pos the projected (2Tmax-1,d) table; only query rows
     [q_begin, q_begin+q_count) are computed, into the same rows of `ctx` (B,Tmax,d).  keys_hint (host-side upper bound of
     `lengths`, default Tmax) picks the key split: few query rows against a long cache would otherwise occupy
-    B*H*ceil(q_count/128) workgroups only.  fp32 only (inference)."""
+    B*H*ceil(q_count/128) workgroups only.  Under torch.autocast the 16-bit form runs (cfm_relpos_attention_rows_mfma16_f32)."""
     qkv = _req(qkv, "qkv"); u = _req(u, "content_bias"); v = _req(v, "position_bias"); ctx = _req(ctx, "ctx")
     B, T, d3 = qkv.shape
     d = d3 // 3
@@ -645,6 +645,15 @@ def relpos_attention_rows(qkv: torch.Tensor, pos: torch.Tensor, u: torch.Tensor,
     if ctx.shape != (B, T, d) or not qkv.is_contiguous() or not ctx.is_contiguous():
         raise _lib.ConformerHipError("relpos_attention_rows: qkv (B,T,3d) and ctx (B,T,d) must be contiguous cache buffers")
     lengths = _req(lengths, "lengths", torch.int64)
+    prec = mfma16_prec()
+    if prec != PREC_F32:
+        # under autocast: the 16-bit matrix-pipe form (fp32 cache, operands rounded where they enter a product; no key split)
+        base = qkv.data_ptr()
+        st = _lib.load().cfm_relpos_attention_rows_mfma16_f32(prec, base, base + 4 * d, base + 8 * d, d3, pos.data_ptr(), pos.stride(0),
+                                                              u.data_ptr(), v.data_ptr(), lengths.data_ptr(), ctx.data_ptr(), d, B, T,
+                                                              n_heads, d // n_heads, int(q_begin), int(q_count), _stream())
+        _lib.check(st, "cfm_relpos_attention_rows_mfma16_f32")
+        return ctx
     tiles = ((T if keys_hint is None else min(int(keys_hint), T)) + 31) // 32
     blocks = B * n_heads * ((q_count + 127) // 128)
     nsplit = max(1, min(16, tiles // 8, -(-1024 // blocks)))          # >= 8 key tiles per split, aim at ~1024 workgroups

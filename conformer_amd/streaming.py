@@ -78,8 +78,6 @@ class StreamingEncoder:
     def step(self, mel_chunk: torch.Tensor) -> torch.Tensor:
         """mel_chunk (B, n_mel, Tc): the next Tc log-mel frames of every utterance (any Tc >= 1).  Returns the encoder
         frames that became computable, (B, k, d) with k = ((buffered-1)//2-1)//2 >= 0."""
-        if torch.is_autocast_enabled("cuda"):
-            raise RuntimeError("StreamingEncoder runs in fp32 only (the incremental attention kernel has no 16-bit form)")
         x_in = ops._req(mel_chunk, "mel_chunk")
         if self.mel_tail_buf is None:
             self.mel_tail_buf = torch.zeros(self.B, x_in.shape[1], 8, device=x_in.device, dtype=torch.float32)

@@ -224,6 +224,12 @@ int cfm_relpos_attention_mfma16_f32(int prec, const float* q, const float* k, co
                                     const float* pos, int64_t ldp, const float* u, const float* vbias,
                                     const int64_t* lengths_or_null, float* ctx, int64_t ldo, float* lse_or_null, int B,
                                     int T, int H, int dh, float drop_p, uint64_t drop_seed, cfm_stream_t stream);
+/* Streaming under autocast (round 3): the 16-bit form of cfm_relpos_attention_rows_f32 -- query rows [q_begin, q_begin + q_count)
+ * against keys < lengths[b] of the fp32 K/V cache (rounded to `prec` where they enter a product), fp32 ctx; no key split. */
+int cfm_relpos_attention_rows_mfma16_f32(int prec, const float* q, const float* k, const float* v, int64_t ld,
+                                         const float* pos, int64_t ldp, const float* u, const float* vbias,
+                                         const int64_t* lengths, float* ctx, int64_t ldo, int B, int T, int H, int dh,
+                                         int q_begin, int q_count, cfm_stream_t stream);
 /* Inference under autocast with 16-bit tensors either side of the core: qkv_is_16bit -- q / k / v stored in `prec` (ld in elements,
  * ld % 8 == 0: what autocast's projections hand the attention); ctx_is_16bit -- the context stored in `prec` (ldo in elements): its
  * only consumer is the out-projection GEMM, which rounds an fp32 context to that type anyway (bit-identical layer output). */

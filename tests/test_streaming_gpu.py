@@ -179,3 +179,47 @@ def test_attention_rows_kernel_vs_reference_block_triangular_mask(dev, case):
         start = e
     y = ops.linear(ctx, P[a + "attention.out_proj.weight"], P[a + "attention.out_proj.bias"])
     assert rel_l2(y, g["mhsa_y"]) < 2e-5
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+def test_attention_rows_16bit_form_vs_float64(dev, dt):
+    """cfm_relpos_attention_rows_mfma16_f32 (streaming under autocast): chunk rows against the cache == the float64 attention core
+    with the prefix rule, at the 16-bit operand-rounding tolerance (1e-2 bf16 / 3e-3 fp16, the autocast bars of tests/test_mfma16_gpu.py)."""
+    from conformer_amd import ops
+    B, T, H, dh = 3, 200, 4, 36
+    d = H * dh
+    g = torch.Generator().manual_seed(5)
+    qkv = torch.randn(B, T, 3 * d, generator=g)
+    pos = torch.randn(2 * T - 1, d, generator=g)
+    u, v = 0.3 * torch.randn(H, dh, generator=g), 0.3 * torch.randn(H, dh, generator=g)
+    ends = [33, 64, 190, 200]
+    ctx = torch.zeros(B, T, d, device=dev)
+    start = 0
+    with torch.autocast("cuda", dtype=dt):
+        for e in ends:
+            L = torch.full((B,), e, dtype=torch.int64, device=dev)
+            ops.relpos_attention_rows(qkv.to(dev), pos.to(dev), u.to(dev), v.to(dev), L, H, start, e - start, ctx)
+            start = e
+    visible_end = torch.empty(T, dtype=torch.long)
+    start = 0
+    for e in ends:
+        visible_end[start:e] = e
+        start = e
+    q, k, vv = (t.reshape(B, T, H, dh).double() for t in qkv.split(d, dim=-1))
+    ref = O.relpos_attention_core(q, k, vv, pos.double().view(2 * T - 1, H, dh), u.double(), v.double(), None, visible_end)
+    assert rel_l2(ctx, ref.reshape(B, T, d)) < (1e-2 if dt == torch.bfloat16 else 3e-3)
+
+
+def test_streaming_under_autocast_tracks_fp32_streaming(dev):
+    """StreamingEncoder inside torch.autocast (bf16): every GEMM and the incremental attention on the 16-bit matrix pipe; the
+    encoder output stays within the bf16 bar (1e-2 rel-L2 per tensor) of the fp32 streaming result."""
+    from conformer_amd.streaming import StreamingEncoder
+    d, H, L, K = 64, 4, 2, 31
+    P = O.make_params(vocab=8, n_mel=80, n_blocks=L, d=d, n_heads=H, ksize=K, lstm_hidden=8, seed=13, with_decoder=False)
+    enc = _encoder(P, 80, L, d, H, K, dev)
+    x = torch.randn(2, 80, 403, generator=torch.Generator().manual_seed(1)).to(dev)
+    ref = StreamingEncoder(enc, 2, 403).run(x, 128)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        out = StreamingEncoder(enc, 2, 403).run(x, 128)
+    assert out.dtype == torch.float32 and out.shape == ref.shape
+    assert rel_l2(out, ref) < 1e-2

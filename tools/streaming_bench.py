@@ -22,7 +22,11 @@ def main():
     ap.add_argument("--chunk", type=int, default=640)
     ap.add_argument("--repeats", type=int, default=3)
     ap.add_argument("--graphs", action="store_true", help="replay one captured hipGraph per chunk step (StreamingEncoder(graphs=True))")
+    ap.add_argument("--dtype", choices=["f32", "bf16", "f16"], default="f32", help="bf16 / f16: the whole stream under torch.autocast")
     args = ap.parse_args()
+    import contextlib
+    amp = contextlib.nullcontext if args.dtype == "f32" else \
+        (lambda: torch.autocast("cuda", dtype=torch.bfloat16 if args.dtype == "bf16" else torch.float16))
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
     enc = Encoder(80, 16, 512, 8, 31, 0.0).to(dev).eval()
@@ -36,13 +40,14 @@ def main():
         t0 = time.perf_counter()
         for t in range(0, args.frames, args.chunk):
             c0 = time.perf_counter()
-            st.step(x[:, :, t:t + args.chunk])
+            with amp():
+                st.step(x[:, :, t:t + args.chunk])
             torch.cuda.synchronize()                      # a streaming service hands each chunk's frames on
             per.append((time.perf_counter() - c0) * 1e3)
         dt = time.perf_counter() - t0
         if best is None or dt < best:
             best, lat = dt, per
-    with torch.no_grad():
+    with torch.no_grad(), amp():
         enc(x, None)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -50,7 +55,7 @@ def main():
         torch.cuda.synchronize()
         full = time.perf_counter() - t0
     lat_sorted = sorted(lat)
-    print(json.dumps({"what": "cfg-5 streaming encoder: cached K/V + depthwise state", "launch": "hipGraph per chunk step" if args.graphs else "eager", "batch": args.batch,
+    print(json.dumps({"what": "cfg-5 streaming encoder: cached K/V + depthwise state", "launch": "hipGraph per chunk step" if args.graphs else "eager", "dtype": args.dtype, "batch": args.batch,
                       "mel_frames": args.frames, "chunk": args.chunk, "chunks": len(lat), "encoder_frames": st.frames,
                       "stream_ms": best * 1e3, "frames_per_sec": args.batch * args.frames / best,
                       "realtime_factor_per_stream": (args.frames * 0.010) / best,
