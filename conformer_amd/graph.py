@@ -11,9 +11,11 @@ from typing import Optional, Tuple
 import torch
 
 
-def _weights_fingerprint(module: torch.nn.Module):
+def _weights_fingerprint(module: torch.nn.Module, tensors=None):
     from conformer_amd.model.utils._guard import _EPOCH, _ver
-    return (_EPOCH[0],) + tuple((t.data_ptr(), _ver(t)) for t in list(module.parameters()) + list(module.buffers()))
+    if tensors is None:
+        tensors = list(module.parameters()) + list(module.buffers())
+    return (_EPOCH[0],) + tuple((t.data_ptr(), _ver(t)) for t in tensors)
 
 
 class GraphedEncoder:
@@ -25,10 +27,13 @@ class GraphedEncoder:
     planes).  Every call compares the (address, in-place version) of each parameter and buffer with the capture-time
     record; after an optimizer step, `load_state_dict` or any in-place update the graph is captured again (the old one
     is dropped first) instead of replaying stale packs.  Writes that bypass the version counter (`param.data.copy_`)
-    need `conformer_amd.model.utils._guard.invalidate_weight_caches()`, which this check also sees."""
+    need `conformer_amd.model.utils._guard.invalidate_weight_caches()`, which this check also sees.
+    check_weights=False (frozen-weight serving) skips that per-call walk over the ~470 tensors of a Conformer-L (the list itself is
+    cached at capture time either way); a re-capture replaces `static_y`: outputs handed out earlier are invalid after it
+    (`captures` counts them)."""
 
     def __init__(self, encoder: torch.nn.Module, example_x: torch.Tensor, example_lengths: Optional[torch.Tensor],
-                 warmup: int = 2, autocast_dtype: Optional[torch.dtype] = None) -> None:
+                 warmup: int = 2, autocast_dtype: Optional[torch.dtype] = None, check_weights: bool = True) -> None:
         if encoder.training:
             raise ValueError("GraphedEncoder captures the inference path: call encoder.eval() first")
         self.encoder = encoder
@@ -37,6 +42,7 @@ class GraphedEncoder:
         self.warmup = warmup
         self.autocast_dtype = autocast_dtype             # bfloat16 / float16: capture the 16-bit matrix-pipe path
         self.captures = 0
+        self.check_weights = bool(check_weights)
         self._capture()
 
     def _capture(self) -> None:
@@ -54,7 +60,8 @@ class GraphedEncoder:
         self.graph = torch.cuda.CUDAGraph()
         with torch.no_grad(), torch.cuda.graph(self.graph), amp():
             self.static_y, self.static_out_len = encoder(self.static_x, self.static_len)
-        self._fingerprint = _weights_fingerprint(encoder)
+        self._tensors = list(encoder.parameters()) + list(encoder.buffers())     # (walked once per capture, not per replay)
+        self._fingerprint = _weights_fingerprint(encoder, self._tensors)
         self.captures += 1
 
     def __call__(self, x: torch.Tensor, lengths: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
@@ -62,7 +69,7 @@ class GraphedEncoder:
             raise ValueError(f"graph captured for input {tuple(self.static_x.shape)}, got {tuple(x.shape)}")
         if self.encoder.training:
             raise ValueError("GraphedEncoder replays the inference path: the wrapped encoder was switched to .train()")
-        if _weights_fingerprint(self.encoder) != self._fingerprint:
+        if self.check_weights and _weights_fingerprint(self.encoder, self._tensors) != self._fingerprint:
             self._capture()                              # weights changed since the capture: never replay stale packs
         if x.data_ptr() != self.static_x.data_ptr():
             self.static_x.copy_(x)

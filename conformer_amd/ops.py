@@ -766,8 +766,8 @@ def _zeros_split(device, dtype, *shapes):
     if total >= _ZERO_CHUNK // 4 or torch.cuda.is_current_stream_capturing():
         buf, off = torch.zeros(total, device=device, dtype=dtype), 0       # big requests (dqkv, ...) get their own fill
     else:
-        key = (device, dtype)
-        ent = _ZERO_ARENA.get(key)
+        key = (device, dtype, torch.cuda.current_stream(device).cuda_stream)   # (a chunk is zero-filled on the stream that made it:
+        ent = _ZERO_ARENA.get(key)                                                #  slices are only handed to work on that stream)
         if ent is None or ent[1] + total > ent[0].numel():
             ent = [torch.zeros(_ZERO_CHUNK, device=device, dtype=dtype), 0]
             _ZERO_ARENA[key] = ent
