@@ -61,11 +61,11 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_f32_kernel(const FfnArgs a) 
     // ---- the weight stream of this wave: slice s = packed tile 4 s + wave = 2 NL consecutive 1 KB wave loads
     const f32x4* wp = reinterpret_cast<const f32x4*>(a.Wp) + lane;
     const int64_t TILE = a.tile_stride;                                 // f32x4 from one packed tile to the next
-    // Every workgroup streams the SAME 2 x 4 MB of weights, and left alone they do it in lockstep: all CUs of an XCD ask its L2
-    // for the same lines at the same moment and the requests queue on a few channels (measured: 9 % on the whole kernel; with
-    // every slice re-reading one tile, 2x).  So workgroups start at different slices (rotation by the workgroup's index within
-    // its XCD) and consecutive tiles are padded apart so that tiles a multiple of the channel-interleave period apart do not
-    // fall on the same channels.  The slice order only changes the order in which a wave sums its slices (fixed per workgroup).
+    // Every workgroup streams the SAME 2 x 4 MB of weights, in lockstep.  Two ways of pulling the workgroups apart were measured
+    // and change NOTHING in time (seven layouts: 275-278 us): starting each workgroup at a different slice (rotation by its index
+    // within its XCD), and padding the packed tiles apart (against channel-interleave periods).  What the rotation does change is
+    // the traffic behind the L2: with all 31 workgroups of an XCD on the same slice the 4 MB L2 serves 30 of 31 reads (85 MB
+    // fetched per launch = 8 XCDs x the weights + the rows), rotated they thrash it (1.1 GB per launch, PMC FETCH_SIZE).  Off.
     const int rot = a.rotate ? (int)((blockIdx.x >> 3) % (unsigned)NS) : 0;
     f32x4 ring[RING];
     {
@@ -318,9 +318,10 @@ __global__ __launch_bounds__(256) void ffn_pack_kernel(const float* __restrict__
 
 }  // namespace
 
-// pad between packed tiles, in f32x4 (default 4 KB + 256 B: one step of either plausible L2 channel interleave)
-static int g_ffn_pad = 272;
-static int g_ffn_rotate = 1;
+// diagnostics: pad between packed tiles (f32x4) and per-workgroup slice rotation -- both measured neutral in time; the rotation
+// multiplies the fetch traffic behind the L2 by 13 (see the kernel): defaults 0 / off
+static int g_ffn_pad = 0;
+static int g_ffn_rotate = 0;
 extern "C" int cfm_debug_ffn_layout(int pad_f4, int rotate) {           // diagnostics: affects cfm_ffn_pack_* AND cfm_ffn_fused_f32 -- re-pack after it
     if (pad_f4 >= 0) g_ffn_pad = pad_f4;
     g_ffn_rotate = rotate != 0;

@@ -85,9 +85,21 @@ void gemm_f32_kernel(const GemmArgs g) {
     const int nkt = (Kloc + BK - 1) / BK;
     f32x4 ra0[PA], rb0[PB], ra1[BK == 16 ? PA : 1], rb1[BK == 16 ? PB : 1];   // BK = 16: two staging sets (tiles t+1 and t+2 in flight)
     auto load_tile = [&](auto& ra, auto& rb, int kt) {
-        const int k = kt * BK + chunk * 4;
-        const int64_t aoff = a_k_offset<CONV>(g, kt * BK) + chunk * 4;
-        const bool ok = k < Kloc;
+        int kb = kt * BK;
+        if constexpr (CONV == 1 && BK == 16) {
+            // The stem's implicit GEMM walks K = (tap, channel) CHANNEL-CHUNK-major: all nine taps of 32 channels, then the next 32
+            // (two K-tiles = one whole 128-byte line per tap).  In storage order (tap-major) an h1 line is needed again by another
+            // output position of the same row tile 1-6 x 512 K-steps later (stride 2: each input pixel feeds 2.25 outputs) --
+            // long after the 4 MB L2 has dropped it: 4.5 GB fetched per launch for 1.28 GB of h1 (PMC FETCH_SIZE).  Walked this way
+            // the 2.25 uses of a line fall inside 18 consecutive K-tiles.  The sum is the same, its order differs.
+            if (g.conv_kperm) {
+                const int c32 = kt / 18, r = kt - 18 * c32;
+                kb = (r >> 1) * g.cC + 32 * c32 + 16 * (r & 1);
+            }
+        }
+        const int k = kb + chunk * 4;
+        const int64_t aoff = a_k_offset<CONV>(g, kb) + chunk * 4;
+        const bool ok = kt * BK + chunk * 4 < Kloc;
 #pragma unroll
         for (int i = 0; i < PA; ++i)
             ra[i] = ok ? *reinterpret_cast<const f32x4*>(a_ptr[i] + aoff) : f32x4{0.f, 0.f, 0.f, 0.f};
@@ -538,6 +550,7 @@ extern "C" int cfm_gemm_lnfold_f32(int epi, const float* A, const float* ln_stat
 }
 
 static int g_conv2_bk = 16;
+static int g_conv2_kperm = 1;
 // Implicit-GEMM second stem convolution (3x3, stride 2, channel-last input, packed weight).  Declared in the stem
 // section of the ABI; lives here to share the kernel templates.
 extern "C" int cfm_subsample_conv2_relu_f32(const float* h1, const float* w2p, const float* b2, float* h2, int B,
@@ -550,6 +563,7 @@ extern "C" int cfm_subsample_conv2_relu_f32(const float* h1, const float* w2p, c
     g.cT1 = T1; g.cF1 = F1; g.cC = C; g.cT2 = (T1 - 1) / 2; g.cF2 = (F1 - 1) / 2;
     g.A = h1; g.W = w2p; g.bias = b2; g.C = h2;
     g.M = (int64_t)B * g.cT2 * g.cF2; g.N = C; g.K = 9 * C; g.lda = 0; g.ldc = C; g.alpha = 1.f;
+    g.conv_kperm = g_conv2_kperm && C % 32 == 0;
     if (g_conv2_bk == 32 && C % 32 == 0) return launch<EPI_RELU, true, EPF_INFER, 32>(g, static_cast<hipStream_t>(stream));
     return launch<EPI_RELU, true, EPF_INFER>(g, static_cast<hipStream_t>(stream));
 }
@@ -558,6 +572,7 @@ extern "C" int cfm_subsample_conv2_relu_f32(const float* h1, const float* w2p, c
 extern "C" int cfm_debug_set_conv2_bk(int bk) {
     const int prev = g_conv2_bk;
     if (bk == 16 || bk == 32) g_conv2_bk = bk;
+    if (bk == 0 || bk == 1) g_conv2_kperm = bk;            // 0 / 1: K walked in storage order / channel-chunk-major (default)
     return prev;
 }
 

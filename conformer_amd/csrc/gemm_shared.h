@@ -24,6 +24,7 @@ struct GemmArgs {
     int64_t M; int N; int K; int64_t lda, ldr, ldc; float alpha;
     int n_out;                      // GLU: output columns (N = 2*n_out)
     int cT2, cF2, cT1, cF1, cC;     // conv mode geometry
+    int conv_kperm;                 // fp32 kernel, CONV == 1: walk K channel-chunk-major (see load_tile)
     // CONV == 2 (16-bit kernel): transposed-conv parity class of the stem's conv2 backward (see gemm_bwd_args.h, GATHER 2): row
     // m = (b, a, c) of the class grid pA x pC, K-tile = tap (dt, df) of dz2 (B,T2,F2,C); output row = dh1 position (b, 2a+pt, 2c+pf)
     int pA, pC, pt, pf; int tap_dt[4], tap_df[4];

@@ -324,6 +324,9 @@ def ffn_fused_ok(d: int, hidden: int, rows: int) -> bool:
     return bool(_FFN_FUSED and ln_fold_ok(d) and d in (128, 256, 512) and hidden % 128 == 0 and rows >= 32 * 192)
 
 
+_FFN_LAYOUT_ENV = __import__("os").environ.get("CONFORMER_AMD_FFN_ROTATE")    # diagnostics: "0" = every workgroup walks the slices in order
+
+
 def ffn_pack(w1f: torch.Tensor, w2: torch.Tensor) -> torch.Tensor:
     """Both Linear weights of a FeedForwardModule in MFMA fragment order, slice by slice (once per weight version).
     w1f: (hidden, d) = the LayerNorm-folded hidden weight (fold_layernorm); w2: (d, hidden)."""
@@ -332,6 +335,8 @@ def ffn_pack(w1f: torch.Tensor, w2: torch.Tensor) -> torch.Tensor:
     if tuple(w2.shape) != (d, hidden):
         raise _lib.ConformerHipError(f"ffn_pack: W1f{tuple(w1f.shape)} and W2{tuple(w2.shape)} do not match")
     lib = _lib.load()
+    if _FFN_LAYOUT_ENV is not None:
+        lib.cfm_debug_ffn_layout(-1, int(_FFN_LAYOUT_ENV))
     wp = torch.zeros(int(lib.cfm_ffn_pack_elems(d, hidden)), device=w1f.device, dtype=torch.float32)   # (pads between tiles: zero)
     _lib.check(lib.cfm_ffn_pack_f32(w1f.data_ptr(), w2.data_ptr(), wp.data_ptr(), d, hidden, _stream()), "cfm_ffn_pack_f32")
     return wp

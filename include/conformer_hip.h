@@ -439,7 +439,7 @@ int cfm_debug_gemm_cfg_f32(int cfg, const float* A, const float* W, const float*
 int cfm_debug_ffn_trace(void* trace_or_null, int per_slice);   /* 128 x uint64 s_memrealtime stamps of cfm_ffn_fused_f32 (wave 0 of blocks 0 / 128), or NULL */
 int cfm_debug_ffn_variant(int v);               /* 0 | 1 = main loop without weight loads (wrong results: the pure MFMA rate) */
 int cfm_debug_ffn_layout(int pad_f4, int rotate); /* pad between packed tiles (16-byte units; < 0 keeps it) and the per-workgroup slice rotation: re-pack after changing */
-int cfm_debug_set_conv2_bk(int bk);   /* K-tile of cfm_subsample_conv2_relu_f32: 16 (default) | 32; returns the previous setting */
+int cfm_debug_set_conv2_bk(int bk);   /* K-tile of cfm_subsample_conv2_relu_f32: 16 (default) | 32; 0 / 1: K walked in storage order / channel-chunk-major (default); returns the previous K-tile */
 /*      cfg + 16: bias epilogue; cfg + 32: swish epilogue; cfg + 64: K-tile 32 (a staged row = one whole 128-byte line;
  *      measured slower than the K-tile 16 loop at every hot-path shape but one: kept for tools/gemm_tune.py bk). */
 

@@ -58,12 +58,12 @@ def layout(pad, rotate):
     """variant with its own packing: pad between tiles (16-byte units), slice rotation per workgroup"""
     _l.load().cfm_debug_ffn_layout(pad, rotate)
     wpl = ops.ffn_pack(wf, w2)
-    _l.load().cfm_debug_ffn_layout(272, 1)
+    _l.load().cfm_debug_ffn_layout(0, 0)
 
     def f():
         _l.load().cfm_debug_ffn_layout(pad, rotate)
         r = ops.ffn_fused(x, st, wpl, bf, cs, b2, 0.5, 1e-5, emit_stats=True)
-        _l.load().cfm_debug_ffn_layout(272, 1)
+        _l.load().cfm_debug_ffn_layout(0, 0)
         return r
     return f
 
