@@ -10,6 +10,8 @@
 // contiguous bytes = two full cache lines, 16 lanes x 16 B), registers -> bf16 -> LDS rows of 144 B (conflict-free
 // ds_read_b128: one read = the 8 k-values one lane feeds one MFMA), LDS double buffer, one barrier per K-tile.
 // Block tile 128x128 or 64x64, 4 waves (2x2); accumulators transposed (lanes = rows) for the shared 16-byte epilogue.
+#include <stdlib.h>
+
 #include "gemm_shared.h"
 
 namespace {
@@ -104,7 +106,13 @@ __global__ __launch_bounds__(WM * 128, 2) void gemm_mfma16_kernel(const GemmArgs
     constexpr bool DEEP = WM == 2;                            // 8-wave tiles: one set (the second one spills at 256x256)
     Stage st0, st1;
     auto load_tile = [&](Stage& t, int kt) {
-        const int k = kt * BK + sch * 4, kh = kt * BK + hch * 8;       // K % 4 == 0 (K % 8 == 0 for 16-bit operands)
+        int kb = kt * BK;
+        if constexpr (CONV == 1) {
+            // stem conv2: K = (tap, channel) walked channel-chunk-major -- the nine taps of 64 channels, then the next 64 -- so that the
+            // 2.25 uses of an h1 line (stride 2) fall within nine consecutive K-tiles instead of up to 6 x C K-steps apart (gemm_f32.hip)
+            if (g.conv_kperm) { const int c64 = kt / 9; kb = (kt - 9 * c64) * g.cC + 64 * c64; }
+        }
+        const int k = kb + sch * 4, kh = kb + hch * 8;                 // K % 4 == 0 (K % 8 == 0 for 16-bit operands)
         t.kvalid = k < g.K; t.kvalid_h = kh < g.K;
         const int kc = max(0, min(k, g.K - 4)), khc = max(0, min(kh, g.K - 8));
         if (A16 && CONV == 2) {
@@ -482,6 +490,7 @@ extern "C" int cfm_subsample_conv2_relu_mfma16_f32(int prec, const void* h1, int
     g.c_prec = h2_is_16bit ? prec : 0;
     g.M = (int64_t)B * g.cT2 * g.cF2; g.N = C; g.K = 9 * C; g.lda = 0; g.ldc = C; g.alpha = 1.f;
     g.occ_cap = g_gemm16_force_tile;
+    g.conv_kperm = C % 64 == 0 && getenv("CONFORMER_AMD_CONV2_KORDER_STORAGE") == nullptr;   // (the env var: A/B only)
     return launch<EPI_RELU, 1>(prec, g, h1_is_16bit ? 2 : (w_is_16bit ? 1 : 0), static_cast<hipStream_t>(stream));
 }
 
