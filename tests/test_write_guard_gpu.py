@@ -168,12 +168,69 @@ def test_inference_writes_stay_inside_their_buffers(dev, amp, d, heads, T):
             with (torch.autocast("cuda", dtype=amp) if amp else contextlib.nullcontext()):
                 logits, out_len = model(x, lengths)
             greedy_ctc_decode(logits.float(), 0, 1, out_len)
-            if amp is None:
-                from conformer_amd.streaming import StreamingEncoder
-                se = StreamingEncoder(model.encoder, 2, T)
-                for a in range(0, T, 64):
+            from conformer_amd.streaming import StreamingEncoder
+            se = StreamingEncoder(model.encoder, 2, T)
+            for a in range(0, T, 64):                                  # (under autocast: the 16-bit incremental attention)
+                with (torch.autocast("cuda", dtype=amp) if amp else contextlib.nullcontext()):
                     se.step(x[:, :, a:min(a + 64, T)])
             bad = gt.check()
             n = len(gt.allocs)
     assert n > 30 and not bad, f"{len(bad)} of {n} buffers were written outside their bounds: {bad[:5]}"
     assert rel_l2(logits, ref) < (1e-6 if amp is None else 2e-2)
+
+
+@pytest.mark.parametrize("M,d", [(333, 256), (97, 512), (1, 128)])
+def test_row_block_kernels_write_inside_their_buffers(dev, M, d):
+    """The one-kernel feed-forward and the three row chains at ragged row counts (the last workgroup holds 13 / 1 / 1 live rows of 32):
+    outputs, statistics partials, q|k|v and the stored intermediate rows are guarded."""
+    from conformer_amd import ops
+    g = torch.Generator().manual_seed(8)
+    R = lambda *s: torch.randn(*s, generator=g).to(dev)  # noqa: E731
+    x, ctx, c = R(M, d) + 0.3, R(M, d), R(M, d)
+    lw, lb = 1 + 0.1 * R(d), 0.1 * R(d)
+    w1, b1, w2, b2 = R(4 * d, d) / math.sqrt(d), 0.1 * R(4 * d), R(d, 4 * d) / math.sqrt(4 * d), 0.1 * R(d)
+    wq, bq, wo, bo, wg, bg = R(3 * d, d) / math.sqrt(d), 0.1 * R(3 * d), R(d, d) / math.sqrt(d), 0.1 * R(d), R(2 * d, d) / math.sqrt(d), 0.1 * R(2 * d)
+    xs = x.view(M, d // 32, 32)
+    st = torch.stack([xs.sum(-1), ((xs - xs.mean(-1, keepdim=True)) ** 2).sum(-1)], dim=-1).contiguous()
+    with guarded_allocations() as gt:
+        wf, bf, cs = ops.fold_layernorm(w1, b1, lw, lb)
+        ffn = (ops.ffn_pack(wf, w2), bf, cs)
+        ops.ffn_fused(x, st, ffn[0], bf, cs, b2, 0.5, 1e-5)
+        ops.ffn_fused(x, st, ffn[0], bf, cs, b2, 0.5, 1e-5, emit_stats=True)
+        ops.ffn_fused(x, st, ffn[0], bf, cs, b2, 0.5, 1e-5, emit_stats=True, closing_ln=(lw, lb, 1e-5))
+        wqf, bqf, csq = ops.fold_layernorm(wq, bq, lw, lb)
+        ops.rowchain_ffn_qkv(x, st, ffn, b2, 0.5, 1e-5, ops.rowgemm_pack(wqf), bqf, csq, 1e-5)
+        wgf, bgf, csg = ops.fold_layernorm(wg, bg, lw, lb)
+        ops.rowchain_out_glu(ctx, ops.rowgemm_pack(wo), bo, x, ops.rowgemm_pack(wgf, glu=True), bgf, csg, 1e-5)
+        ops.rowchain_pw2_ffn_ln(c, ops.rowgemm_pack(wo), bo, x, ffn, b2, 0.5, 1e-5, (lw, lb, 1e-5), want_stats=True)
+        bad = gt.check()
+        n = len(gt.allocs)
+    assert n >= 15 and not bad, f"{len(bad)} of {n} buffers were written outside their bounds: {bad[:5]}"
+
+
+def test_big_batch_block_writes_stay_inside_their_buffers(dev):
+    """One Conformer-L block at cfg-2 geometry (7968 rows: the one-kernel feed-forward path of ConformerBlock.fused_chain, then the
+    five-launch row-chain form): every buffer guarded."""
+    from conformer_amd import ops
+    from conformer_amd.model.utils.block import ConformerBlock
+    torch.manual_seed(3)
+    d, B, T = 512, 32, 249
+    blk = ConformerBlock(d, 8, 31).to(dev).eval()
+    x = torch.randn(B, T, d, device=dev) + 0.2
+    xs = x.view(B * T, d // 32, 32)
+    st = torch.stack([xs.sum(-1), ((xs - xs.mean(-1, keepdim=True)) ** 2).sum(-1)], dim=-1).contiguous()
+    table = ops.relpos_table(torch.exp(torch.arange(0, d, 2, device=dev) * -(math.log(10000.0) / d))[None], T)
+    L = torch.full((B,), T, dtype=torch.int64, device=dev)
+    with torch.no_grad(), guarded_allocations() as gt:
+        import conformer_amd.model.utils.block as blockmod                 # (the block allocates nothing itself: ops does)
+        assert ops.ffn_fused_ok(d, 4 * d, B * T)
+        a, _ = blk.fused_chain(x, table, L, x_stats=st, want_stats=True)
+        prev = ops.set_rowchain(True)
+        try:
+            b, _ = blk.fused_chain(x, table, L, x_stats=st, want_stats=True)
+        finally:
+            ops.set_rowchain(prev)
+        bad = gt.check()
+        n = len(gt.allocs)
+    assert n >= 20 and not bad, f"{len(bad)} of {n} buffers were written outside their bounds: {bad[:5]}"
+    assert rel_l2(b, a) < 1e-5
