@@ -124,3 +124,51 @@ def test_subsampled_lengths_floor_division(ops, n, data):
     L = torch.tensor(vals, dtype=torch.int64)
     want = torch.div(torch.div(L - 1, 2, rounding_mode="floor") - 1, 2, rounding_mode="floor")
     assert torch.equal(ops.subsampled_lengths(L.cuda()).cpu(), want)
+
+
+def _partials(y, parts):
+    g = y.double().reshape(y.shape[0], parts, -1)
+    return torch.stack([g.sum(-1), ((g - g.mean(-1, keepdim=True)) ** 2).sum(-1)], dim=-1).float()
+
+
+@settings(max_examples=20, **SET)
+@given(M=st.integers(1, 200), d=st.sampled_from([128, 256, 512]), hid128=st.integers(1, 6), lp=st.integers(0, 4),
+       mean=st.floats(-1.5, 1.5), scale=st.floats(0.3, 3.0), seed=st.integers(0, 10 ** 6))
+def test_ffn_fused_any_rows_hidden_statistics(ops, M, d, hid128, lp, mean, scale, seed):
+    """One-kernel feed-forward: any row count (ragged last workgroup), hidden = 128 .. 768 (1 .. 6 slices per wave), 1 .. 16 incoming
+    statistics partials, rows with a mean up to 1.5 standard deviations (the fold's cancellation term), all three finish modes."""
+    import torch.nn.functional as F
+    hidden, parts = 128 * hid128, 1 << lp
+    x = rnd(M, d, seed=seed) * scale + mean * scale
+    lw, lb = 1 + 0.3 * rnd(d, seed=seed + 1), 0.2 * rnd(d, seed=seed + 2)
+    w1, b1 = rnd(hidden, d, seed=seed + 3) / math.sqrt(d), 0.1 * rnd(hidden, seed=seed + 4)
+    w2, b2 = rnd(d, hidden, seed=seed + 5) / math.sqrt(hidden), 0.1 * rnd(d, seed=seed + 6)
+    wf, bf, cs = ops.fold_layernorm(w1.cuda(), b1.cuda(), lw.cuda(), lb.cuda())
+    wp = ops.ffn_pack(wf, w2.cuda())
+    st_in = _partials(x, parts).cuda()
+    h = F.layer_norm(x.double(), (d,), lw.double(), lb.double(), 1e-5) @ w1.double().T + b1.double()
+    ref = 0.5 * ((h * torch.sigmoid(h)) @ w2.double().T + b2.double()) + x.double()
+    y, st = ops.ffn_fused(x.cuda(), st_in, wp, bf, cs, b2.cuda(), 0.5, 1e-5, emit_stats=True)
+    tol = TOL * max(1.0, math.sqrt(1 + mean * mean))                  # (the documented amplification of the folded LayerNorm)
+    assert rel_l2(y, ref) < tol
+    rp = _partials(y.cpu(), d // 32)
+    assert rel_l2(st[..., 0], rp[..., 0]) < 1e-5 and rel_l2(st[..., 1], rp[..., 1]) < 1e-4
+    g2, bt2 = 1 + 0.2 * rnd(d, seed=seed + 7), 0.3 * rnd(d, seed=seed + 8)
+    y2 = ops.ffn_fused(x.cuda(), st_in, wp, bf, cs, b2.cuda(), 0.5, 1e-5, closing_ln=(g2.cuda(), bt2.cuda(), 1e-5))
+    assert rel_l2(y2, F.layer_norm(ref, (d,), g2.double(), bt2.double(), 1e-5)) < 2 * tol
+
+
+@settings(max_examples=12, **SET)
+@given(M=st.integers(1, 150), d=st.sampled_from([128, 256, 512]), seed=st.integers(0, 10 ** 6))
+def test_row_chain_out_glu_any_rows(ops, M, d, seed):
+    """K2 of the row chains (PRE + POST without the feed-forward core: in-kernel row statistics, GLU store staging) at any row count."""
+    import torch.nn.functional as F
+    ctx, res = rnd(M, d, seed=seed), rnd(M, d, seed=seed + 1) * 1.5 + 0.4
+    wo, bo = rnd(d, d, seed=seed + 2) / math.sqrt(d), 0.1 * rnd(d, seed=seed + 3)
+    wg, bg = rnd(2 * d, d, seed=seed + 4) / math.sqrt(d), 0.1 * rnd(2 * d, seed=seed + 5)
+    lw, lb = 1 + 0.3 * rnd(d, seed=seed + 6), 0.2 * rnd(d, seed=seed + 7)
+    wgf, bgf, csg = ops.fold_layernorm(wg.cuda(), bg.cuda(), lw.cuda(), lb.cuda())
+    y2, g = ops.rowchain_out_glu(ctx.cuda(), ops.rowgemm_pack(wo.cuda()), bo.cuda(), res.cuda(), ops.rowgemm_pack(wgf, glu=True), bgf, csg, 1e-5)
+    y_ref = ctx.double() @ wo.double().T + bo.double() + res.double()
+    hh = F.layer_norm(y_ref, (d,), lw.double(), lb.double(), 1e-5) @ wg.double().T + bg.double()
+    assert rel_l2(y2, y_ref) < TOL and rel_l2(g, hh[:, :d] * torch.sigmoid(hh[:, d:])) < TOL
