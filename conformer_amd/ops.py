@@ -319,9 +319,14 @@ def set_ffn_fused(on: bool) -> bool:
 
 
 def ffn_fused_ok(d: int, hidden: int, rows: int) -> bool:
-    """One workgroup per 32 rows: worth it once the rows fill the chip's 256 CUs (below that the two-GEMM path, with its
-    column-tile parallelism, is faster: a streaming chunk)."""
-    return bool(_FFN_FUSED and ln_fold_ok(d) and d in (128, 256, 512) and hidden % 128 == 0 and rows >= 32 * 192)
+    """One workgroup per 32 rows, one workgroup per CU: worth it when the row blocks fill whole rounds of the chip's 256 CUs to
+    >= 70 % (7968 rows = 249 blocks: 0.97; a streaming chunk of 1280 rows, or 257 blocks = one full round + one block, are
+    not: there the two-GEMM path, with its column-tile parallelism, is faster)."""
+    if not (_FFN_FUSED and ln_fold_ok(d) and d in (128, 256, 512) and hidden % 128 == 0):
+        return False
+    blocks = (rows + 31) // 32
+    rounds = (blocks + 255) // 256
+    return blocks >= 0.7 * 256 * rounds
 
 
 _FFN_LAYOUT_ENV = __import__("os").environ.get("CONFORMER_AMD_FFN_ROTATE")    # diagnostics: "0" = every workgroup walks the slices in order
