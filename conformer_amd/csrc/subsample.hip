@@ -9,6 +9,7 @@ namespace {
 // A workgroup owns one (utterance, output frame t1) row of h1 -- F1 x C contiguous outputs -- and walks f1: no index
 // arithmetic per position.  (The first version flattened (b, t1, f1) into one 64-bit position index and paid two 64-bit
 // divisions per position and thread: it ran at 1.9 TB/s of stores, ALU-bound on the divisions, not write-bound.)
+// h1 (1.28 GB at cfg-2, read back only after the whole tensor is written) is stored NON-TEMPORALLY: 356 -> 245 us (3.6 -> 5.2 TB/s).
 // CPT channels per thread: 4 (one 16-byte fp32 store) or, for a 16-bit h1, 8 (one 16-byte store of eight values: the write-out
 // is bound by the number of store instructions, not by their width).
 template <typename TOUT, int CPT>   // TOUT: float, or the 16-bit matrix-pipe type when h1 only feeds the 16-bit conv2 GEMM
@@ -54,12 +55,12 @@ __global__ __launch_bounds__(256) void conv1_relu_kernel(const float* __restrict
             }
             if constexpr (sizeof(TOUT) == 4) {
                 static_assert(sizeof(TOUT) != 4 || CPT == 4, "fp32 h1: 4 channels per thread");
-                *reinterpret_cast<f32x4*>(hrow + (int64_t)f1 * C) = f32x4{o[0], o[1], o[2], o[3]};
+                __builtin_nontemporal_store(f32x4{o[0], o[1], o[2], o[3]}, reinterpret_cast<f32x4*>(hrow + (int64_t)f1 * C));
             } else if constexpr (CPT == 8) {
                 typename Lowp<TOUT>::x8 r;
 #pragma unroll
                 for (int i = 0; i < 8; ++i) r[i] = (TOUT)o[i];
-                *reinterpret_cast<typename Lowp<TOUT>::x8*>(hrow + (int64_t)f1 * C) = r;
+                __builtin_nontemporal_store(r, reinterpret_cast<typename Lowp<TOUT>::x8*>(hrow + (int64_t)f1 * C));
             } else {
                 *reinterpret_cast<typename Lowp<TOUT>::x4*>(hrow + (int64_t)f1 * C) = Lowp<TOUT>::cvt4(f32x4{o[0], o[1], o[2], o[3]});
             }
