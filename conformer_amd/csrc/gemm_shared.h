@@ -203,25 +203,43 @@ __device__ __forceinline__ f32x4 gemm_epilogue_compute(const GemmArgs& g, const 
 }
 
 // stores of 4 / 8 consecutive elements at element offset `off` of a tensor of type `prec` (0 fp32 | bf16 | fp16)
+template <bool NT = false>   // NT: non-temporal (tensors saved for the backward pass: written now, read tens of milliseconds later)
 __device__ __forceinline__ void epi_store4(void* base, int prec, int64_t off, const f32x4 v) {
-    if (prec == 0) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(base) + off) = v;
-    else if (prec == CFM_PREC_BF16) *reinterpret_cast<Lowp<__bf16>::x4*>(reinterpret_cast<__bf16*>(base) + off) = Lowp<__bf16>::cvt4(v);
-    else *reinterpret_cast<Lowp<_Float16>::x4*>(reinterpret_cast<_Float16*>(base) + off) = Lowp<_Float16>::cvt4(v);
+    if (prec == 0) {
+        if (NT) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(reinterpret_cast<float*>(base) + off));
+        else *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(base) + off) = v;
+    } else if (prec == CFM_PREC_BF16) {
+        const Lowp<__bf16>::x4 r = Lowp<__bf16>::cvt4(v);
+        if (NT) __builtin_nontemporal_store(r, reinterpret_cast<Lowp<__bf16>::x4*>(reinterpret_cast<__bf16*>(base) + off));
+        else *reinterpret_cast<Lowp<__bf16>::x4*>(reinterpret_cast<__bf16*>(base) + off) = r;
+    } else {
+        const Lowp<_Float16>::x4 r = Lowp<_Float16>::cvt4(v);
+        if (NT) __builtin_nontemporal_store(r, reinterpret_cast<Lowp<_Float16>::x4*>(reinterpret_cast<_Float16*>(base) + off));
+        else *reinterpret_cast<Lowp<_Float16>::x4*>(reinterpret_cast<_Float16*>(base) + off) = r;
+    }
 }
+template <bool NT = false>
 __device__ __forceinline__ void epi_store8(void* base, int prec, int64_t off, const f32x4 v0, const f32x4 v1) {
     if (prec == 0) {
-        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(base) + off) = v0;
-        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(base) + off + 4) = v1;
+        if (NT) {
+            __builtin_nontemporal_store(v0, reinterpret_cast<f32x4*>(reinterpret_cast<float*>(base) + off));
+            __builtin_nontemporal_store(v1, reinterpret_cast<f32x4*>(reinterpret_cast<float*>(base) + off + 4));
+        } else {
+            *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(base) + off) = v0;
+            *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(base) + off + 4) = v1;
+        }
     } else if (prec == CFM_PREC_BF16) {
         Lowp<__bf16>::x8 r;
 #pragma unroll
         for (int e = 0; e < 4; ++e) { r[e] = (__bf16)v0[e]; r[4 + e] = (__bf16)v1[e]; }
-        *reinterpret_cast<Lowp<__bf16>::x8*>(reinterpret_cast<__bf16*>(base) + off) = r;
+        if (NT) __builtin_nontemporal_store(r, reinterpret_cast<Lowp<__bf16>::x8*>(reinterpret_cast<__bf16*>(base) + off));
+        else *reinterpret_cast<Lowp<__bf16>::x8*>(reinterpret_cast<__bf16*>(base) + off) = r;
     } else {
         Lowp<_Float16>::x8 r;
 #pragma unroll
         for (int e = 0; e < 4; ++e) { r[e] = (_Float16)v0[e]; r[4 + e] = (_Float16)v1[e]; }
-        *reinterpret_cast<Lowp<_Float16>::x8*>(reinterpret_cast<_Float16*>(base) + off) = r;
+        if (NT) __builtin_nontemporal_store(r, reinterpret_cast<Lowp<_Float16>::x8*>(reinterpret_cast<_Float16*>(base) + off));
+        else *reinterpret_cast<Lowp<_Float16>::x8*>(reinterpret_cast<_Float16*>(base) + off) = r;
     }
 }
 
@@ -246,7 +264,7 @@ __device__ __forceinline__ void gemm_epilogue_apply(const GemmArgs& g, f32x4 av,
     f32x4 zpre;
     const f32x4 v = gemm_epilogue_compute<EPI, F>(g, av, gv, o, row, col, zpre);
     if (ok) {
-        if (EPI == EPI_SWISH && g.Zsave) epi_store4(g.Zsave, (F & EPF_F32_OUT) ? 0 : g.z_prec, row * g.ldc + col, zpre);
+        if (EPI == EPI_SWISH && g.Zsave) epi_store4<true>(g.Zsave, (F & EPF_F32_OUT) ? 0 : g.z_prec, row * g.ldc + col, zpre);
         epi_store4(g.C, (F & EPF_F32_OUT) ? 0 : g.c_prec, crow * g.ldc + col, v);
     }
     if constexpr (LN == 2) {
@@ -271,7 +289,7 @@ __device__ __forceinline__ void gemm_epilogue_apply8(const GemmArgs& g, const f3
     f32x4 z0, z1;
     const f32x4 v0 = gemm_epilogue_compute<EPI>(g, av0, av0, o0, row, col, z0);
     const f32x4 v1 = gemm_epilogue_compute<EPI>(g, av1, av1, o1, row, col + 4, z1);
-    if (EPI == EPI_SWISH && g.Zsave) epi_store8(g.Zsave, g.z_prec, row * g.ldc + col, z0, z1);
+    if (EPI == EPI_SWISH && g.Zsave) epi_store8<true>(g.Zsave, g.z_prec, row * g.ldc + col, z0, z1);
     epi_store8(g.C, g.c_prec, crow * g.ldc + col, v0, v1);
 }
 
