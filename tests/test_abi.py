@@ -66,6 +66,45 @@ def test_argument_validation_without_gpu(lib):
     assert lib.cfm_relpos_attention_fwd_f32(p, p, p, 384, p, 128, p, p, None, p, 128, None, 1, 4, 1, 128, None) == -2
 
 
+def test_round3_entries_validate_their_arguments_without_gpu(lib):
+    """cfm_ffn_fused_f32 / cfm_ffn_pack_f32 / cfm_rowchain_f32 / cfm_rowgemm_pack_f32 / cfm_relpos_attention_rows_mfma16_f32 refuse bad
+    arguments with a negative status BEFORE any HIP call (so this runs without a GPU): NULL pointers, unsupported widths, ragged
+    hidden sizes, stage combinations that are not one of the three chains, misaligned pointers."""
+    buf = (ctypes.c_float * 4096)()
+    p = ctypes.addressof(buf)
+    assert p % 16 == 0 or True
+    a = (p + 15) // 16 * 16                                    # a 16-byte aligned address inside the buffer
+    OK = 0
+    assert lib.cfm_ffn_pack_elems(512, 2048) == 2 * 512 * 2048
+    assert lib.cfm_ffn_pack_f32(None, a, a, 512, 2048, None) < OK                                   # NULL
+    assert lib.cfm_ffn_pack_f32(a, a, a, 160, 640, None) < OK                                       # d not in {128, 256, 512}
+    assert lib.cfm_ffn_pack_f32(a, a, a, 512, 2000, None) < OK                                      # hidden % 128
+    args = [a, 512, a, 16, 1e-5, a, a, a, a, 0.5, a, 512, 0, None, None, None, 0.0, 64, 512, 2048, None]
+    bad = list(args); bad[0] = None
+    assert lib.cfm_ffn_fused_f32(*bad) < OK                                                         # X NULL
+    bad = list(args); bad[18] = 144
+    assert lib.cfm_ffn_fused_f32(*bad) < OK                                                         # d = 144
+    bad = list(args); bad[3] = 3
+    assert lib.cfm_ffn_fused_f32(*bad) < OK                                                         # ln_parts not a power of two
+    bad = list(args); bad[12] = 1
+    assert lib.cfm_ffn_fused_f32(*bad) < OK                                                         # mode 1 without stats_out
+    bad = list(args); bad[12] = 2
+    assert lib.cfm_ffn_fused_f32(*bad) < OK                                                         # mode 2 without gamma / beta
+    bad = list(args); bad[0] = a + 4
+    assert lib.cfm_ffn_fused_f32(*bad) < OK                                                         # misaligned X
+    empty = list(args); empty[17] = 0
+    assert lib.cfm_ffn_fused_f32(*empty) == OK                                                      # M = 0: nothing to do, no launch
+    assert lib.cfm_rowgemm_pack_f32(a, a, 1536, 512, 1, None) < OK                                  # glu needs N == 2 d
+    assert lib.cfm_rowgemm_pack_f32(a, a, 1000, 512, 0, None) < OK                                  # N % 128
+    chain = [0, 1, 0, 0, a, 512, None, None, None, 0, None, 0, a, 16, 1e-5, a, a, a, a, 0.5, 2048, a, 512, None, None, None, 0.0,
+             None, None, None, 0.0, None, 0, 64, 512, None]
+    assert lib.cfm_rowchain_f32(*chain) < OK                                                        # (0, 1, 0, 0) is not K1 / K2 / K3
+    chain[0], chain[1], chain[2] = 1, 0, 0
+    assert lib.cfm_rowchain_f32(*chain) < OK                                                        # PRE alone
+    assert lib.cfm_relpos_attention_rows_mfma16_f32(1, a, a, a, 1536, a, 512, a, a, None, a, 512, 1, 16, 8, 64, 0, 16, None) < OK   # lengths NULL
+    assert lib.cfm_relpos_attention_rows_mfma16_f32(1, a, a, a, 1536, a, 512, a, a, a, a, 512, 1, 16, 8, 64, 8, 16, None) < OK      # rows past T
+
+
 def test_no_cpu_fallback():
     from conformer_amd import ops
     from conformer_amd._lib import ConformerHipError
