@@ -8,7 +8,9 @@
 // Structure (4 waves = one per SIMD, each with the whole 512-register budget; no barrier in the main loop):
 //   * the workgroup's 32 un-normalised rows of X sit in LDS for the whole kernel (MFMA B operand of stage 1; residual at the end);
 //   * the hidden dimension is cut into 32-unit SLICES; wave w owns slices w, w+4, ... (split-K of the second product over waves);
-//   * stage 1 of a slice:  H^T (32 hidden x 32 rows) = W1f[slice] . X^T     d/2 MFMAs (v_mfma_f32_32x32x2_f32), two chains
+//   * stage 1 of a slice:  H^T (32 hidden x 32 rows) = W1f[slice] . X^T     d/2 MFMAs (v_mfma_f32_32x32x2_f32), ONE dependent chain
+//     (two chains -- 32 accumulator registers beside the 256 of stage 2 -- made the compiler park two output tiles in VGPRs around
+//     every slice: 268 us against 264)
 //     epilogue (registers): LN fold  rstd * (acc - mean * colsum) + b1f,  Swish
 //   * stage 2 of a slice:  Y^T (d x 32 rows) += W2[:, slice] . swish(H)^T -- the stage-1 accumulator layout (lane = row, registers
 //     = 16 hidden units) IS the B-operand layout of a 32x32x2 MFMA whose contraction runs over those hidden units: no LDS round
@@ -122,10 +124,10 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_f32_kernel(const FfnArgs a) 
             csv[q] = *reinterpret_cast<const f32x4*>(a.cs1 + g * 32 + 8 * q + 4 * hf);
             b1v[q] = *reinterpret_cast<const f32x4*>(a.b1f + g * 32 + 8 * q + 4 * hf);
         }
-        // ---- stage 1: H^T = W1f[slice] . X^T, contraction over the d input dims (8 per load), even / odd steps in two chains
-        f32x16 ha, hb;
+        // ---- stage 1: H^T = W1f[slice] . X^T, contraction over the d input dims (8 per load)
+        f32x16 ha;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { ha[r] = 0.f; hb[r] = 0.f; }
+        for (int r = 0; r < 16; ++r) ha[r] = 0.f;
         f32x4 xv = *reinterpret_cast<const f32x4*>(xrow);
 #pragma unroll
         for (int c = 0; c < NL; ++c) {
@@ -136,9 +138,9 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_f32_kernel(const FfnArgs a) 
             const f32x4 wv = ring[c % RING];
             if (DBG != 1) ring[c % RING] = sb[(c + RING) * 64];
             ha = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[0], xv[0], ha, 0, 0, 0);
-            hb = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[1], xv[1], hb, 0, 0, 0);
+            ha = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[1], xv[1], ha, 0, 0, 0);
             ha = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[2], xv[2], ha, 0, 0, 0);
-            hb = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[3], xv[3], hb, 0, 0, 0);
+            ha = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[3], xv[3], ha, 0, 0, 0);
             xv = xn;
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -146,7 +148,7 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_f32_kernel(const FfnArgs a) 
         float sw[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const float v = rstd * ((ha[r] + hb[r]) - mean * csv[r >> 2][r & 3]) + b1v[r >> 2][r & 3];
+            const float v = rstd * (ha[r] - mean * csv[r >> 2][r & 3]) + b1v[r >> 2][r & 3];
             sw[r] = swishf_acc(v);
         }
         if (a.trace_detail) FFN_STAMP(2 + 2 * s);

@@ -209,9 +209,9 @@ __global__ __launch_bounds__(256, 1) void rowchain_f32_kernel(const ChainArgs a)
                 csv[q] = *reinterpret_cast<const f32x4*>(a.cs1 + g * 32 + 8 * q + 4 * hf);
                 b1v[q] = *reinterpret_cast<const f32x4*>(a.b1f + g * 32 + 8 * q + 4 * hf);
             }
-            f32x16 ha, hb;
+            f32x16 ha;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { ha[r] = 0.f; hb[r] = 0.f; }
+            for (int r = 0; r < 16; ++r) ha[r] = 0.f;
             f32x4 xv = *reinterpret_cast<const f32x4*>(xrow);
 #pragma unroll
             for (int c = 0; c < NL; ++c) {
@@ -219,16 +219,16 @@ __global__ __launch_bounds__(256, 1) void rowchain_f32_kernel(const ChainArgs a)
                 const f32x4 wv = ring[c % RING];
                 ring[c % RING] = sb[(c + RING) * 64];
                 ha = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[0], xv[0], ha, 0, 0, 0);
-                hb = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[1], xv[1], hb, 0, 0, 0);
+                ha = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[1], xv[1], ha, 0, 0, 0);
                 ha = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[2], xv[2], ha, 0, 0, 0);
-                hb = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[3], xv[3], hb, 0, 0, 0);
+                ha = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[3], xv[3], ha, 0, 0, 0);
                 xv = xn;
                 __builtin_amdgcn_sched_barrier(0);
             }
             float sw[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float v = rstd * ((ha[r] + hb[r]) - mean * csv[r >> 2][r & 3]) + b1v[r >> 2][r & 3];
+                const float v = rstd * (ha[r] - mean * csv[r >> 2][r & 3]) + b1v[r >> 2][r & 3];
                 sw[r] = swishf_acc(v);
             }
 #pragma unroll
