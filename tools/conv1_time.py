@@ -1,3 +1,5 @@
+#!/usr/bin/env python3
+"""The stem's first convolution at cfg-2 (B=32, 80 x 1000 mel frames -> h1 (32, 499, 39, 512) fp32 = 1.28 GB): time and write rate."""
 import torch, sys, os
 sys.path.insert(0, os.getcwd())
 from conformer_amd import _lib

@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""Which kernels surround the ATen fill kernels of a traced run (rocprofv3 --kernel-trace CSV directory as argv[1]): tells one-time
+state initialisation (long runs of consecutive fills: FusedAdam's moments on the first step) from per-step zero fills."""
 import csv, glob, sys, collections
 path = sorted(glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True))[-1]
 rows = list(csv.DictReader(open(path)))
