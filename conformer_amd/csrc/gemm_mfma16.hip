@@ -490,7 +490,8 @@ extern "C" int cfm_subsample_conv2_relu_mfma16_f32(int prec, const void* h1, int
     g.c_prec = h2_is_16bit ? prec : 0;
     g.M = (int64_t)B * g.cT2 * g.cF2; g.N = C; g.K = 9 * C; g.lda = 0; g.ldc = C; g.alpha = 1.f;
     g.occ_cap = g_gemm16_force_tile;
-    g.conv_kperm = C % 64 == 0 && getenv("CONFORMER_AMD_CONV2_KORDER_STORAGE") == nullptr;   // (the env var: A/B only)
+    static const bool storage_order = getenv("CONFORMER_AMD_CONV2_KORDER_STORAGE") != nullptr;   // (A/B only; read once)
+    g.conv_kperm = C % 64 == 0 && !storage_order;
     return launch<EPI_RELU, 1>(prec, g, h1_is_16bit ? 2 : (w_is_16bit ? 1 : 0), static_cast<hipStream_t>(stream));
 }
 
