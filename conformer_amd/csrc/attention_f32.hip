@@ -518,7 +518,8 @@ __global__ __launch_bounds__(512, 2) void relpos_attn_fwd8p_kernel(const AttnArg
     for (int n = 0; n < ND; ++n)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[n][r] = 0.f;
-    float mrow = -INFINITY, lrow = 0.f;
+    float mrow = -INFINITY, lrow = 0.f;                              // running maximum in the log2 domain (scores * scale2), row sum
+    const float scale2 = a.inv_sqrt_dh * 1.44269504088896340736f;
 
     // products of key tile kt: content scores S^T[key][query] from K buffer kt & 1, band tile of ring block blk (A-operand row li <->
     // block row 31 - li)
@@ -605,23 +606,32 @@ __global__ __launch_bounds__(512, 2) void relpos_attn_fwd8p_kernel(const AttnArg
             // ---- X: the products of key tile t+1 (the compiler interleaves them with the softmax below: one basic block, no fences)
             f32x16 sn = content(t + 1);
             const f32x16 ga = band(t + 1 - wave);
+            // (VALU / LDS issue and the fp32 matrix instructions of a SIMD do not overlap on this part -- SQ_VALU_MFMA_COEXEC_CYCLES is 0
+            //  for every fp32 kernel -- so every instruction of this section is time: the scores live in the log2 domain (one multiply
+            //  by inv_sqrt_dh * log2(e) instead of a scale and a second multiply inside exp), and the key-padding selects run only in
+            //  the tile that holds the end of the utterance)
             float p[16];
             float tmax = -INFINITY;
+            if (uniform || k0 + 32 > klen) {                        // (wave-uniform) the last key tile, or an all-masked utterance
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int kk = (r & 3) + 8 * (r >> 2) + 4 * hf;
-                float sv = sc[r] * a.inv_sqrt_dh;
-                if (uniform) sv = 0.f;
-                if (k0 + kk >= klen) sv = -INFINITY;
-                p[r] = sv;
-                tmax = fmaxf(tmax, sv);
+                for (int r = 0; r < 16; ++r) {
+                    const int kk = (r & 3) + 8 * (r >> 2) + 4 * hf;
+                    float sv = sc[r] * scale2;
+                    if (uniform) sv = 0.f;
+                    if (k0 + kk >= klen) sv = -INFINITY;
+                    p[r] = sv;
+                    tmax = fmaxf(tmax, sv);
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { p[r] = sc[r] * scale2; tmax = fmaxf(tmax, p[r]); }
             }
             tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
             const float mnew = fmaxf(mrow, tmax);                   // finite: key k0 (< klen) is always valid
-            const float alpha = exp_fast(mrow - mnew);
+            const float alpha = __builtin_amdgcn_exp2f(mrow - mnew);
             float psum = 0.f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { p[r] = exp_fast(p[r] - mnew); psum += p[r]; }
+            for (int r = 0; r < 16; ++r) { p[r] = __builtin_amdgcn_exp2f(p[r] - mnew); psum += p[r]; }
             psum += __shfl_xor(psum, 32, 64);
             lrow = lrow * alpha + psum;
             mrow = mnew;
@@ -663,7 +673,7 @@ __global__ __launch_bounds__(512, 2) void relpos_attn_fwd8p_kernel(const AttnArg
                     *reinterpret_cast<f32x4*>(orow + dd) = out;
                 }
             }
-        if (a.lse && hf == 0) a.lse[((int64_t)b * a.H + h) * T + i0 + li] = mrow + logf(lrow);
+        if (a.lse && hf == 0) a.lse[((int64_t)b * a.H + h) * T + i0 + li] = mrow * 0.69314718055994530942f + logf(lrow);
     }
 }
 
