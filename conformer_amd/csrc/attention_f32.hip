@@ -165,7 +165,8 @@ __global__ __launch_bounds__(64 * NW, 2) void relpos_attn_fwd_kernel(const AttnA
     for (int n = 0; n < ND; ++n)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[n][r] = 0.f;
-    float mrow = -INFINITY, lrow = 0.f;
+    float mrow = -INFINITY, lrow = 0.f;                              // running maximum in the log2 domain (scores * scale2), row sum
+    const float scale2 = a.inv_sqrt_dh * 1.44269504088896340736f;
 
 #define ATT_STAMP(i) do { if (tracer) a.trace[16 * kt + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
     // ---- positional band G^T[jj][query], jj = 32*mt + row <-> table row j = jbase - jj (jbase = T-1-i0+k0+31), and the
@@ -308,23 +309,30 @@ __global__ __launch_bounds__(64 * NW, 2) void relpos_attn_fwd_kernel(const AttnA
         }
         ATT_STAMP(5);
         // scale + mask, online softmax (query = lane column; keys = registers x 2 halves)
+        // (log2 domain: one multiply by inv_sqrt_dh * log2 e, v_exp_f32 directly; the key-padding selects run only in the tile that
+        //  holds the end of the utterance -- the same arithmetic as the pipelined form below: results are bit-identical across forms)
         float p[16];
         float tmax = -INFINITY;
+        if (uniform || k0 + 32 > klen) {                        // (wave-uniform)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int kk = (r & 3) + 8 * (r >> 2) + 4 * hf;
-            float s = sc[r] * a.inv_sqrt_dh;
-            if (uniform) s = 0.f;
-            if (k0 + kk >= klen) s = -INFINITY;
-            p[r] = s;
-            tmax = fmaxf(tmax, s);
+            for (int r = 0; r < 16; ++r) {
+                const int kk = (r & 3) + 8 * (r >> 2) + 4 * hf;
+                float s = sc[r] * scale2;
+                if (uniform) s = 0.f;
+                if (k0 + kk >= klen) s = -INFINITY;
+                p[r] = s;
+                tmax = fmaxf(tmax, s);
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { p[r] = sc[r] * scale2; tmax = fmaxf(tmax, p[r]); }
         }
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
         const float mnew = fmaxf(mrow, tmax);                   // finite: key k0 (< klen) is always valid
-        const float alpha = exp_fast(mrow - mnew);
+        const float alpha = __builtin_amdgcn_exp2f(mrow - mnew);
         float psum = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { p[r] = exp_fast(p[r] - mnew); psum += p[r]; }
+        for (int r = 0; r < 16; ++r) { p[r] = __builtin_amdgcn_exp2f(p[r] - mnew); psum += p[r]; }
         psum += __shfl_xor(psum, 32, 64);
         lrow = lrow * alpha + psum;
         mrow = mnew;
@@ -424,9 +432,9 @@ __global__ __launch_bounds__(64 * NW, 2) void relpos_attn_fwd_kernel(const AttnA
                 }
             }
         if (a.nsplit > 1) {
-            if (hf == 0) a.part_lse[(((int64_t)split * a.B + b) * a.H + h) * qc + il] = mrow + logf(lrow);
+            if (hf == 0) a.part_lse[(((int64_t)split * a.B + b) * a.H + h) * qc + il] = mrow * 0.69314718055994530942f + logf(lrow);
         } else if (a.lse && hf == 0) {
-            a.lse[((int64_t)b * a.H + h) * T + i0 + li] = mrow + logf(lrow);
+            a.lse[((int64_t)b * a.H + h) * T + i0 + li] = mrow * 0.69314718055994530942f + logf(lrow);
         }
     }
     if (tracer) {
@@ -792,9 +800,11 @@ static int attention_launch(const float* q, const float* k, const float* v, int6
                static_cast<unsigned long long*>(trace)};
     // 8-wave workgroups (256 query rows, the two halves half a key tile apart) once a launch has more than 128 query rows and
     // no key split; g_attn_force_nw (diagnostics) overrides
-    // force 9 = the software-pipelined 8-wave form (the built-in choice for > 128 query rows without weight dropout / key split)
+    // force 9 = the software-pipelined 8-wave form (inference only: no weight dropout / key split)
     const bool can_pipe = nsplit == 1 && drop_p == 0.f && !trace;
-    int nw = g_attn_force_nw ? g_attn_force_nw : ((q_count > 128 && nsplit == 1) ? (can_pipe ? 9 : 8) : 4);
+    // (after the instruction diet of the softmax section the half-tile-staggered 8-wave form is the fastest again: 69.8 us against
+    //  71.4 us pipelined and 74.2 us with 4 waves, profiles/r03_attn_ab.txt; force 9 selects the pipelined form)
+    int nw = g_attn_force_nw ? g_attn_force_nw : ((q_count > 128 && nsplit == 1) ? 8 : 4);
     if (nw == 9 && !can_pipe) nw = 8;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (nw == 9) {

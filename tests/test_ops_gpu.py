@@ -154,3 +154,28 @@ def test_errors_are_loud(ops):
     with pytest.raises(ConformerHipError):
         ops.relpos_attention(G(torch.zeros(1, 4, 3 * 128)), G(torch.zeros(7, 128)), G(torch.zeros(1, 128)),
                              G(torch.zeros(1, 128)), None, 1)                        # dh = 128 unsupported
+
+
+def test_relpos_attention_forms_agree(ops):
+    """The three forms of the fp32 attention forward (4 waves; 8 waves half a key tile apart = the default above 128 query rows;
+    8 waves software-pipelined) on one input with ragged lengths: the pipelined form shares the 4-wave arithmetic bit for bit, the
+    staggered form sums its scores in two chains (<= 1e-6)."""
+    from conformer_amd import _lib
+    lib = _lib.load()
+    B, T, H, dh = 3, 249, 4, 64
+    d = H * dh
+    qkv, pos = rnd(B, T, 3 * d, seed=21), rnd(2 * T - 1, d, seed=22)
+    u, v = rnd(H, dh, seed=23, scale=0.3), rnd(H, dh, seed=24, scale=0.3)
+    L = torch.tensor([249, 131, 17], dtype=torch.int64)
+    outs = {}
+    try:
+        for nw in (4, 8, 9):
+            lib.cfm_debug_set_attention_waves(nw)
+            outs[nw] = ops.relpos_attention(G(qkv), G(pos), G(u), G(v), G(L), H).clone()
+    finally:
+        lib.cfm_debug_set_attention_waves(0)
+    assert torch.equal(outs[9], outs[4])
+    assert rel_l2(outs[8], outs[4].double()) < 1e-6
+    q, k, vv = (t.reshape(B, T, H, dh).double() for t in qkv.split(d, dim=-1))
+    ref = O.relpos_attention_core(q, k, vv, pos.double().view(2 * T - 1, H, dh), u.double(), v.double(), L)
+    assert rel_l2(outs[8], ref) < TOL
