@@ -163,7 +163,8 @@ __global__ __launch_bounds__(256, 2) void relpos_attn_fwd_mfma16_kernel(const At
     for (int n = 0; n < 2; ++n)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[n][r] = 0.f;
-    float mrow = -INFINITY, lrow = 0.f;
+    float mrow = -INFINITY, lrow = 0.f;                              // running maximum in the log2 domain, row sum
+    const float scale2 = a.inv_sqrt_dh * 1.44269504088896340736f;
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
     // Positional band: one 32-row band tile per key tile (band tile 1 of key tile kt+1 = band tile 0 of key tile kt, and the
@@ -230,23 +231,30 @@ __global__ __launch_bounds__(256, 2) void relpos_attn_fwd_mfma16_kernel(const At
                 skp[r] = skn[r];
             }
             // ---- scale + mask, online softmax
+            // (log2 domain: one multiply by inv_sqrt_dh * log2 e, v_exp_f32 directly; the key-padding selects only in the tile that holds
+            //  the end of the utterance: this section, not the matrix pipe, bounds the kernel)
             float p[16];
             float tmax = -INFINITY;
+            if (uniform || k0 + 32 > klen) {                    // (wave-uniform)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int kk = (r & 3) + 8 * (r >> 2) + 4 * hf;
-                float s = (sc[r] + sk[r]) * a.inv_sqrt_dh;
-                if (uniform) s = 0.f;
-                if (k0 + kk >= klen) s = -INFINITY;
-                p[r] = s;
-                tmax = fmaxf(tmax, s);
+                for (int r = 0; r < 16; ++r) {
+                    const int kk = (r & 3) + 8 * (r >> 2) + 4 * hf;
+                    float s = (sc[r] + sk[r]) * scale2;
+                    if (uniform) s = 0.f;
+                    if (k0 + kk >= klen) s = -INFINITY;
+                    p[r] = s;
+                    tmax = fmaxf(tmax, s);
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { p[r] = (sc[r] + sk[r]) * scale2; tmax = fmaxf(tmax, p[r]); }
             }
             tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
             const float mnew = fmaxf(mrow, tmax);
-            const float alpha = exp_fast(mrow - mnew);
+            const float alpha = __builtin_amdgcn_exp2f(mrow - mnew);
             float psum = 0.f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { p[r] = exp_fast(p[r] - mnew); psum += p[r]; }
+            for (int r = 0; r < 16; ++r) { p[r] = __builtin_amdgcn_exp2f(p[r] - mnew); psum += p[r]; }
             psum += __shfl_xor(psum, 32, 64);
             lrow = lrow * alpha + psum;
             mrow = mnew;
@@ -305,7 +313,7 @@ __global__ __launch_bounds__(256, 2) void relpos_attn_fwd_mfma16_kernel(const At
                     else *reinterpret_cast<f32x4*>(orow + dd) = out;
                 }
             }
-        if (a.lse && hf == 0) a.lse[((int64_t)b * a.H + h) * T + i0 + li] = mrow + logf(lrow);
+        if (a.lse && hf == 0) a.lse[((int64_t)b * a.H + h) * T + i0 + li] = mrow * 0.69314718055994530942f + logf(lrow);
     }
 }
 
