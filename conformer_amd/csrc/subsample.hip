@@ -2,6 +2,8 @@
 // activation h1 (B,T1,F1,C), plus the two one-time weight re-layouts that let the second conv and the input
 // Linear run as plain K-contiguous MFMA GEMMs (gemm_f32.hip).  conv1 is write-bound (C*4 bytes per 9 FMAs):
 // each thread owns 4 consecutive channels (one 16-byte store) and keeps its 36 taps in registers.
+#include <stdlib.h>
+
 #include "cfm_common.h"
 
 namespace {
@@ -9,10 +11,11 @@ namespace {
 // A workgroup owns one (utterance, output frame t1) row of h1 -- F1 x C contiguous outputs -- and walks f1: no index
 // arithmetic per position.  (The first version flattened (b, t1, f1) into one 64-bit position index and paid two 64-bit
 // divisions per position and thread: it ran at 1.9 TB/s of stores, ALU-bound on the divisions, not write-bound.)
-// h1 (1.28 GB at cfg-2, read back only after the whole tensor is written) is stored NON-TEMPORALLY: 356 -> 245 us (3.6 -> 5.2 TB/s).
+// h1 (1.28 GB at cfg-2, read back only after the whole tensor is written) is stored NON-TEMPORALLY: 356 -> 245 us (3.6 -> 5.2 TB/s);
+// the 16-bit h1 of the autocast path: 256 -> 172 us (tools/conv1_time.py; NT = false restores plain stores for an A/B).
 // CPT channels per thread: 4 (one 16-byte fp32 store) or, for a 16-bit h1, 8 (one 16-byte store of eight values: the write-out
 // is bound by the number of store instructions, not by their width).
-template <typename TOUT, int CPT>   // TOUT: float, or the 16-bit matrix-pipe type when h1 only feeds the 16-bit conv2 GEMM
+template <typename TOUT, int CPT, bool NT = true>   // TOUT: float, or the 16-bit matrix-pipe type when h1 only feeds the 16-bit conv2 GEMM
 __global__ __launch_bounds__(256) void conv1_relu_kernel(const float* __restrict__ x, const float* __restrict__ w1,
                                                          const float* __restrict__ b1, TOUT* __restrict__ h1,
                                                          int B, int F, int T, int C, int F1, int T1, int ppb) {
@@ -60,7 +63,8 @@ __global__ __launch_bounds__(256) void conv1_relu_kernel(const float* __restrict
                 typename Lowp<TOUT>::x8 r;
 #pragma unroll
                 for (int i = 0; i < 8; ++i) r[i] = (TOUT)o[i];
-                __builtin_nontemporal_store(r, reinterpret_cast<typename Lowp<TOUT>::x8*>(hrow + (int64_t)f1 * C));
+                if constexpr (NT) __builtin_nontemporal_store(r, reinterpret_cast<typename Lowp<TOUT>::x8*>(hrow + (int64_t)f1 * C));
+                else *reinterpret_cast<typename Lowp<TOUT>::x8*>(hrow + (int64_t)f1 * C) = r;
             } else {
                 *reinterpret_cast<typename Lowp<TOUT>::x4*>(hrow + (int64_t)f1 * C) = Lowp<TOUT>::cvt4(f32x4{o[0], o[1], o[2], o[3]});
             }

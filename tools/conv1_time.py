@@ -19,3 +19,14 @@ for r in range(7):
     for _ in range(10): run()
     e1.record(); torch.cuda.synchronize(); ts.append(e0.elapsed_time(e1)/10*1e3)
 print("conv1 median %.1f us min %.1f us  %.2f TB/s written"%(sorted(ts)[3],min(ts),h1.numel()*4/sorted(ts)[3]/1e6))
+
+h16 = torch.empty(B, T1, F1, C, device=dev, dtype=torch.bfloat16)
+def run16(): _lib.check(lib.cfm_subsample_conv1_relu_out16_f32(1, x.data_ptr(), w1.data_ptr(), b1.data_ptr(), h16.data_ptr(), B, F, T, C, st), "c1-16")
+for _ in range(3): run16()
+ts = []
+for r in range(7):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10): run16()
+    e1.record(); torch.cuda.synchronize(); ts.append(e0.elapsed_time(e1) / 10 * 1e3)
+print("conv1 (bf16 h1) median %.1f us min %.1f us  %.2f TB/s written" % (sorted(ts)[3], min(ts), h16.numel() * 2 / sorted(ts)[3] / 1e6))
