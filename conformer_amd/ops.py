@@ -319,14 +319,14 @@ def set_ffn_fused(on: bool) -> bool:
 
 
 def ffn_fused_ok(d: int, hidden: int, rows: int) -> bool:
-    """One workgroup per 32 rows, one workgroup per CU: worth it when the row blocks fill whole rounds of the chip's 256 CUs to
-    >= 70 % (7968 rows = 249 blocks: 0.97; a streaming chunk of 1280 rows, or 257 blocks = one full round + one block, are
-    not: there the two-GEMM path, with its column-tile parallelism, is faster)."""
+    """One workgroup per 32 rows, one workgroup per CU, ~264 us per round whatever the fill: worth it when the row blocks fill whole
+    rounds of the chip's 256 CUs to >= 90 % (measured: 7968 rows = 249 blocks 264 vs 287 us for the two GEMMs, 15936 rows = 498
+    blocks 527 vs 560 us, but 6144 rows = 192 blocks 262 vs 226 us: the two-GEMM path scales with the rows, ~36 ns per row)."""
     if not (_FFN_FUSED and ln_fold_ok(d) and d in (128, 256, 512) and hidden % 128 == 0):
         return False
     blocks = (rows + 31) // 32
     rounds = (blocks + 255) // 256
-    return blocks >= 0.7 * 256 * rounds
+    return blocks >= 0.9 * 256 * rounds
 
 
 _FFN_LAYOUT_ENV = __import__("os").environ.get("CONFORMER_AMD_FFN_ROTATE")    # diagnostics: "0" = every workgroup walks the slices in order

@@ -77,13 +77,13 @@ def test_kernel_outputs_state_their_dtype():
 
 
 def test_fused_feed_forward_gating_follows_cu_rounds():
-    """ops.ffn_fused_ok: one workgroup per 32 rows and per CU -- taken when the row blocks fill whole rounds of 256 CUs to >= 70 %."""
+    """ops.ffn_fused_ok: one workgroup per 32 rows and per CU -- taken when the row blocks fill whole rounds of 256 CUs to >= 90 %."""
     from conformer_amd import ops
     prev_fold, prev_ffn = ops.set_ln_fold(True), ops.set_ffn_fused(True)
     try:
         assert ops.ffn_fused_ok(512, 2048, 7968)            # cfg-2: 249 blocks
         assert ops.ffn_fused_ok(512, 2048, 15936)           # cfg-3 geometry: 498 blocks = two rounds
-        assert ops.ffn_fused_ok(256, 1024, 32 * 180)
+        assert ops.ffn_fused_ok(256, 1024, 32 * 240) and not ops.ffn_fused_ok(256, 1024, 32 * 192)   # 0.94 / 0.75 of a round
         assert not ops.ffn_fused_ok(512, 2048, 1280)        # a streaming chunk
         assert not ops.ffn_fused_ok(512, 2048, 32 * 257)    # one full round + one block
         assert not ops.ffn_fused_ok(144, 576, 7968) and not ops.ffn_fused_ok(512, 2000, 7968)
